@@ -1,0 +1,145 @@
+"""ctypes mirror of ``AdmpcConfig`` / ``AdmpcGp`` (include/admpc.h) plus the reference's shipped values.
+
+Every default cites the reference line it comes from (paths relative to
+``data_driven_mpc/ros_gp_mpc`` of HMCL-UNIST/AD_MPC).
+"""
+import ctypes as C
+
+import numpy as np
+
+NX, NU, NY = 7, 2, 9
+MAX_N = 128
+GP_MAX = 4
+GP_MAX_POINTS = 32
+
+
+class AdmpcGp(C.Structure):
+    _fields_ = [
+        ("feat", C.c_int32),
+        ("out", C.c_int32),
+        ("n_points", C.c_int32),
+        ("_pad", C.c_int32),
+        ("sigma_f", C.c_double),
+        ("inv_l2", C.c_double),
+        ("ymean", C.c_double),
+        ("Z", C.c_double * GP_MAX_POINTS),
+        ("alpha", C.c_double * GP_MAX_POINTS),
+    ]
+
+
+class AdmpcConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("ipm_iter_max", C.c_int32),
+        ("sqp_iters", C.c_int32),
+        ("n_gp", C.c_int32),
+        ("Ts", C.c_double),
+        ("W", C.c_double * NY),
+        ("We", C.c_double * NX),
+        ("lbu", C.c_double * NU),
+        ("ubu", C.c_double * NU),
+        ("lbx_delta", C.c_double),
+        ("ubx_delta", C.c_double),
+        ("zl", C.c_double),
+        ("zu", C.c_double),
+        ("mass", C.c_double),
+        ("L_F", C.c_double),
+        ("L_R", C.c_double),
+        ("Iz", C.c_double),
+        ("Cf", C.c_double),
+        ("Cr", C.c_double),
+        ("ipm_mu0", C.c_double),
+        ("ipm_thr0", C.c_double),
+        ("ipm_tol_comp", C.c_double),
+        ("ipm_tol_res", C.c_double),
+        ("ipm_tol_step", C.c_double),
+        ("gp", AdmpcGp * GP_MAX),
+    ]
+
+    def copy(self):
+        other = AdmpcConfig()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(AdmpcConfig))
+        return other
+
+
+# --- vehicle constants: src/ad_mpc/ad_3d.py:47-71 (the 3.14195 "pi" is part of the model) -----------
+VEH_MASS = 1500.0
+VEH_F_MASS = 900.0
+VEH_R_MASS = VEH_MASS - VEH_F_MASS
+VEH_L = 2.7
+VEH_L_F = VEH_L * (1 - VEH_F_MASS / VEH_MASS)
+VEH_L_R = VEH_L * (1 - VEH_R_MASS / VEH_MASS)
+VEH_IZ = VEH_L_F * VEH_L_R * (VEH_R_MASS + VEH_F_MASS)
+VEH_CF = VEH_F_MASS * 0.5 * 9.81 * 0.165 * 180 / 3.14195
+VEH_CR = VEH_R_MASS * 0.5 * 9.81 * 0.165 * 180 / 3.14195
+BLEND_MAX = 110.0
+BLEND_MIN = 100.0
+STEERING_MIN, STEERING_MAX = -0.52, 0.52
+STEERING_RATE_MIN, STEERING_RATE_MAX = -3.0, 3.0
+ACC_MIN, ACC_MAX = -10.0, 5.0
+
+# --- cost weights used by the node: src/ad_mpc/create_ros_ad_mpc.py:58-59 ---------------------------
+Q_DIAG_ROS = (10.0, 10.0, 100.0, 0.0, 0.0, 0.0, 0.0)
+R_DIAG_ROS = (1.0, 100.0)
+# optimizer-level defaults (unused by the node): src/ad_mpc/ad_3d_optimizer.py:42-45
+Q_DIAG_OPT = (10.0, 10.0, 50.0, 0.0, 0.0, 0.0, 1.0)
+R_DIAG_OPT = (1.0, 100.0)
+TERMINAL_SCALE = 1e-6      # ocp.cost.W_e = diag(q)*1e-6, src/ad_mpc/ad_3d_optimizer.py:151
+SLACK_L1 = 10.0            # ocp.cost.zl = zu = 1e1, src/ad_mpc/ad_3d_optimizer.py:171-173
+
+# --- interior point defaults (ours; the reference delegates to HPIPM mode BALANCE, iter_max 50,
+#     c_generated_code/acados_solver_sim_car.c:688-692) ---------------------------------------------
+IPM_ITER_MAX = 50
+IPM_MU0 = 1.0
+IPM_THR0 = 0.1
+IPM_TOL_COMP = 1e-11
+IPM_TOL_RES = 1e-9
+IPM_TOL_STEP = 1e-7
+
+
+def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TERMINAL_SCALE, sqp_iters=1):
+    """The reference's shipped OCP for horizon ``N`` and sampling time ``Ts``."""
+    if not (2 <= N <= MAX_N):
+        raise ValueError("N must be in [2, %d]" % MAX_N)
+    c = AdmpcConfig()
+    c.N = int(N)
+    c.ipm_iter_max = IPM_ITER_MAX
+    c.sqp_iters = int(sqp_iters)
+    c.n_gp = 0
+    c.Ts = float(Ts)
+    for i in range(NX):
+        c.W[i] = float(q[i])
+        c.We[i] = float(q[i]) * terminal_scale
+    for j in range(NU):
+        c.W[NX + j] = float(r[j])
+    c.lbu[0], c.lbu[1] = ACC_MIN, STEERING_RATE_MIN
+    c.ubu[0], c.ubu[1] = ACC_MAX, STEERING_RATE_MAX
+    c.lbx_delta, c.ubx_delta = STEERING_MIN, STEERING_MAX
+    c.zl = c.zu = SLACK_L1
+    c.mass, c.L_F, c.L_R, c.Iz, c.Cf, c.Cr = VEH_MASS, VEH_L_F, VEH_L_R, VEH_IZ, VEH_CF, VEH_CR
+    c.ipm_mu0, c.ipm_thr0 = IPM_MU0, IPM_THR0
+    c.ipm_tol_comp, c.ipm_tol_res, c.ipm_tol_step = IPM_TOL_COMP, IPM_TOL_RES, IPM_TOL_STEP
+    return c
+
+
+def set_gp(cfg, gps):
+    """Install residual GPs.  ``gps``: iterable of dicts with keys feat, out, Z, alpha, length_scale,
+    sigma_f, ymean (1-D squared-exponential GPs, src/model_fitting/gp.py:81-138,446-471)."""
+    gps = list(gps)
+    if len(gps) > GP_MAX:
+        raise ValueError("at most %d GPs" % GP_MAX)
+    cfg.n_gp = len(gps)
+    for g, d in enumerate(gps):
+        Z = np.asarray(d["Z"], dtype=np.float64).reshape(-1)
+        al = np.asarray(d["alpha"], dtype=np.float64).reshape(-1)
+        if Z.size != al.size or Z.size > GP_MAX_POINTS:
+            raise ValueError("bad GP size")
+        s = cfg.gp[g]
+        s.feat, s.out, s.n_points = int(d["feat"]), int(d["out"]), int(Z.size)
+        s.sigma_f = float(d.get("sigma_f", 1.0))
+        s.inv_l2 = 1.0 / float(d["length_scale"]) ** 2
+        s.ymean = float(d.get("ymean", 0.0))
+        for i in range(GP_MAX_POINTS):
+            s.Z[i] = float(Z[i]) if i < Z.size else 0.0
+            s.alpha[i] = float(al[i]) if i < Z.size else 0.0
+    return cfg

@@ -1,0 +1,687 @@
+/*
+ * admpc_oracle.c -- CPU restatement (plain scalar C, fp64) of the reference's AD-MPC solve path.
+ *
+ * TEST INFRASTRUCTURE ONLY: loaded by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the checker / timed CPU baseline.  The product never links or calls it.
+ *
+ * What it restates (paths relative to /root/reference/data_driven_mpc/ros_gp_mpc):
+ *   model f(x,u,p)            src/ad_mpc/ad_3d_optimizer.py:280-310, constants src/ad_mpc/ad_3d.py:47-64
+ *                             (twin: c_generated_code/sim_car_model/sim_car_expl_ode_fun.c:52-290)
+ *   forward sensitivities     c_generated_code/sim_car_model/sim_car_expl_vde_forw.c:120 (CasADi AD of f)
+ *   integrator                ERK4, one step per interval: c_generated_code/acados_solver_sim_car.c:655-665
+ *   cost                      LINEAR_LS, Gauss-Newton, scaling Ts: ad_3d_optimizer.py:146-161,
+ *                             acados_solver_sim_car.c:362-366,379-499
+ *   constraints               soft u box (L1, zl=zu=10, Zl=Zu=0), hard delta box on stages 1..N-1,
+ *                             x0 equality: ad_3d_optimizer.py:163-199, acados_solver_sim_car.c:505-605
+ *   NLP step                  SQP_RTI, full step: ad_3d_optimizer.py:201-205, acados_solver_sim_car.c:647-681
+ *   GP residual (config 3)    src/model_fitting/gp.py:81-138,446-471; wiring src/quad_mpc/quad_3d_optimizer.py:289-327
+ *
+ * Third-party arithmetic that is NOT in the reference tree: acados @91a01d4c (requirements.txt:1) with its
+ * HPIPM/BLASFEO submodules.  acados condenses the stage QP and HPIPM solves it with a Mehrotra
+ * primal-dual interior point method.  The QP is strictly convex in the inputs (R > 0), so its primal
+ * minimiser is unique; this file solves the SAME QP with a stage-wise Riccati
+ * factorisation inside a Mehrotra predictor-corrector IPM and is pinned by
+ *   (1) tests/golden/shooting.json   : f, RK4, A, B from the reference's compiled CasADi C (oracle/_ref)
+ *   (2) tests/golden/kat_sim_car_iterate.json : the converged acados iterate shipped in the reference
+ *       (src/ad_mpc/sim_car_iterate.json), see oracle/make_golden.py.
+ */
+#include "admpc_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifdef ORACLE_LONG_DOUBLE
+typedef long double real;
+#define R_SIN sinl
+#define R_COS cosl
+#define R_EXP expl
+#define R_FABS fabsl
+#else
+typedef double real;
+#define R_SIN sin
+#define R_COS cos
+#define R_EXP exp
+#define R_FABS fabs
+#endif
+
+#define NX ADMPC_NX
+#define NU ADMPC_NU
+#define NY ADMPC_NY
+#define MAXN ADMPC_MAX_N
+#define IPM_FLOOR ((real)1e-40)   /* keeps t, lam away from underflow; never active before convergence */
+
+/* ------------------------------------------------------------------------------------------ */
+/* model                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* mean and derivative of one 1-D SE GP (gp.py:81-138 kernel, :446-471 mean, :140-165 derivative) */
+static void gp_eval(const AdmpcGp* g, real z, real* mu, real* dmu)
+{
+    real m = 0, d = 0;
+    for (int i = 0; i < g->n_points; ++i) {
+        real dz = z - (real)g->Z[i];
+        real k = (real)g->sigma_f * R_EXP(-(real)0.5 * dz * dz * (real)g->inv_l2);
+        m += k * (real)g->alpha[i];
+        d -= k * dz * (real)g->inv_l2 * (real)g->alpha[i];
+    }
+    *mu = m + (real)g->ymean;
+    *dmu = d;
+}
+
+static void model_f(const AdmpcConfig* c, const real* x, const real* u, real p, real* f)
+{
+    const real psi = x[2], vx = x[3], vy = x[4], r = x[5], dl = x[6];
+    const real m = c->mass, LF = c->L_F, LR = c->L_R, Iz = c->Iz, Cf = c->Cf, Cr = c->Cr;
+    const real cp = R_COS(psi), sp = R_SIN(psi);
+    f[0] = vx * cp - vy * sp;                                   /* ad_3d_optimizer.py:281 */
+    f[1] = vx * sp + vy * cp;                                   /* :284 */
+    f[2] = r;                                                   /* :287 */
+    const real v = vx + (real)1e-99;
+    const real Ffy = 2 * Cf * (dl - (vy + LF * r) / v);         /* :290 */
+    const real Fry = 2 * Cr * (LR * r - vy) / v;                /* :296 */
+    const real dyn3 = u[0] - (1 / m) * Ffy * R_SIN(dl) + vy * r;            /* :291 */
+    const real kin3 = u[0];                                                  /* :292 */
+    const real dyn4 = (1 / m) * (Fry + Ffy * R_COS(dl)) - vx * r;           /* :298 */
+    const real kin4 = (u[1] * vx + dl * u[0]) * LR / (LR + LF);             /* :299 */
+    const real dyn5 = (1 / Iz) * (LF * Ffy * R_COS(dl) - LR * Fry);         /* :305 */
+    const real kin5 = (u[1] * vx + dl * u[0]) / (LR + LF);                  /* :306 */
+    f[3] = p * dyn3 + (1 - p) * kin3;                           /* :293 */
+    f[4] = p * dyn4 + (1 - p) * kin4;                           /* :300 */
+    f[5] = p * dyn5 + (1 - p) * kin5;                           /* :307 */
+    f[6] = u[1];                                                /* :310 */
+    for (int g = 0; g < c->n_gp; ++g) {                         /* quad_3d_optimizer.py:315 */
+        const AdmpcGp* gp = &c->gp[g];
+        real z = gp->feat < NX ? x[gp->feat] : u[gp->feat - NX];
+        real mu, dmu;
+        gp_eval(gp, z, &mu, &dmu);
+        f[gp->out] += mu;
+    }
+}
+
+/* analytic Jacobians of model_f (derived by hand from the lines cited above) */
+static void model_jac(const AdmpcConfig* c, const real* x, const real* u, real p, real Jx[NX][NX], real Ju[NX][NU])
+{
+    const real psi = x[2], vx = x[3], vy = x[4], r = x[5], dl = x[6];
+    const real m = c->mass, LF = c->L_F, LR = c->L_R, Iz = c->Iz, Cf = c->Cf, Cr = c->Cr;
+    const real L = LR + LF;
+    const real cp = R_COS(psi), sp = R_SIN(psi), cd = R_COS(dl), sd = R_SIN(dl);
+    memset(Jx, 0, sizeof(real) * NX * NX);
+    memset(Ju, 0, sizeof(real) * NX * NU);
+    Jx[0][2] = -vx * sp - vy * cp; Jx[0][3] = cp; Jx[0][4] = -sp;
+    Jx[1][2] = vx * cp - vy * sp;  Jx[1][3] = sp; Jx[1][4] = cp;
+    Jx[2][5] = 1;
+    const real v = vx + (real)1e-99;
+    const real Ffy = 2 * Cf * (dl - (vy + LF * r) / v);
+    const real Fry = 2 * Cr * (LR * r - vy) / v;
+    /* gradients w.r.t. (vx, vy, r, delta) */
+    const real gF[4] = { 2 * Cf * (vy + LF * r) / (v * v), -2 * Cf / v, -2 * Cf * LF / v, 2 * Cf };
+    const real gR[4] = { -Fry / v, -2 * Cr / v, 2 * Cr * LR / v, 0 };
+    real d3[4], d4[4], d5[4];
+    for (int i = 0; i < 4; ++i) {
+        d3[i] = -gF[i] * sd / m;
+        d4[i] = (gR[i] + gF[i] * cd) / m;
+        d5[i] = (LF * gF[i] * cd - LR * gR[i]) / Iz;
+    }
+    d3[1] += r;  d3[2] += vy; d3[3] += -Ffy * cd / m;
+    d4[0] += -r; d4[2] += -vx; d4[3] += -Ffy * sd / m;
+    d5[3] += -LF * Ffy * sd / Iz;
+    const real k4[4] = { u[1] * LR / L, 0, 0, u[0] * LR / L };
+    const real k5[4] = { u[1] / L, 0, 0, u[0] / L };
+    for (int i = 0; i < 4; ++i) {
+        Jx[3][3 + i] = p * d3[i];
+        Jx[4][3 + i] = p * d4[i] + (1 - p) * k4[i];
+        Jx[5][3 + i] = p * d5[i] + (1 - p) * k5[i];
+    }
+    Ju[3][0] = 1;
+    Ju[4][0] = (1 - p) * dl * LR / L; Ju[4][1] = (1 - p) * vx * LR / L;
+    Ju[5][0] = (1 - p) * dl / L;      Ju[5][1] = (1 - p) * vx / L;
+    Ju[6][1] = 1;
+    for (int g = 0; g < c->n_gp; ++g) {
+        const AdmpcGp* gp = &c->gp[g];
+        real z = gp->feat < NX ? x[gp->feat] : u[gp->feat - NX];
+        real mu, dmu;
+        gp_eval(gp, z, &mu, &dmu);
+        if (gp->feat < NX) Jx[gp->out][gp->feat] += dmu; else Ju[gp->out][gp->feat - NX] += dmu;
+    }
+}
+
+/* classic RK4 on the augmented system (x, Sx, Su), Sx(0)=I, Su(0)=0 */
+static void rk4_sens(const AdmpcConfig* c, const real* x, const real* u, real p, real h,
+                     real* phi, real A[NX][NX], real Bm[NX][NU])
+{
+    static const real cstage[4] = { 0, 0.5, 0.5, 1.0 };
+    static const real wstage[4] = { 1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6 };
+    real kx[NX] = {0}, kS[NX][NX], kU[NX][NU];
+    real accx[NX] = {0}, accS[NX][NX], accU[NX][NU];
+    memset(kS, 0, sizeof kS); memset(kU, 0, sizeof kU);
+    memset(accS, 0, sizeof accS); memset(accU, 0, sizeof accU);
+    for (int s = 0; s < 4; ++s) {
+        real X[NX], S[NX][NX], U[NX][NU];
+        for (int i = 0; i < NX; ++i) {
+            X[i] = x[i] + cstage[s] * h * kx[i];
+            for (int j = 0; j < NX; ++j) S[i][j] = (i == j ? 1 : 0) + cstage[s] * h * kS[i][j];
+            for (int j = 0; j < NU; ++j) U[i][j] = cstage[s] * h * kU[i][j];
+        }
+        real Jx[NX][NX], Ju[NX][NU];
+        model_f(c, X, u, p, kx);
+        model_jac(c, X, u, p, Jx, Ju);
+        for (int i = 0; i < NX; ++i) {
+            for (int j = 0; j < NX; ++j) {
+                real a = 0;
+                for (int l = 0; l < NX; ++l) a += Jx[i][l] * S[l][j];
+                kS[i][j] = a;
+            }
+            for (int j = 0; j < NU; ++j) {
+                real a = Ju[i][j];
+                for (int l = 0; l < NX; ++l) a += Jx[i][l] * U[l][j];
+                kU[i][j] = a;
+            }
+        }
+        for (int i = 0; i < NX; ++i) {
+            accx[i] += wstage[s] * kx[i];
+            for (int j = 0; j < NX; ++j) accS[i][j] += wstage[s] * kS[i][j];
+            for (int j = 0; j < NU; ++j) accU[i][j] += wstage[s] * kU[i][j];
+        }
+    }
+    for (int i = 0; i < NX; ++i) {
+        phi[i] = x[i] + h * accx[i];
+        for (int j = 0; j < NX; ++j) A[i][j] = (i == j ? 1 : 0) + h * accS[i][j];
+        for (int j = 0; j < NU; ++j) Bm[i][j] = h * accU[i][j];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the QP of one RTI step and its interior point solve                    */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    int N;
+    real A[MAXN][NX][NX], B[MAXN][NX][NU], b[MAXN][NX];
+    real Qd[NX], Rd[NU], Qe[NX];           /* Ts*q, Ts*r, W_e (all diagonal)                 */
+    real q[MAXN + 1][NX], r[MAXN][NU];     /* gradients of the GN model at the iterate       */
+    real dlu[MAXN][NU], duu[MAXN][NU];     /* lbu-ubar, ubu-ubar                              */
+    real dld[MAXN], dud[MAXN];             /* delta bounds minus xbar[k][6], k=1..N-1         */
+    real dx0[NX];
+    real rho_l, rho_u;                     /* Ts*zl, Ts*zu                                    */
+} StageQP;
+
+typedef struct {
+    real t[MAXN][NU][4], lam[MAXN][NU][4];   /* 0: lower soft, 1: upper soft, 2: sl>=0, 3: su>=0 */
+    real td[MAXN][2], lamd[MAXN][2];         /* delta lower / upper, k = 1..N-1                   */
+    real du[MAXN][NU], sl[MAXN][NU], su[MAXN][NU];
+    real dx[MAXN + 1][NX], pi[MAXN][NX];     /* pi[k]: multiplier of dx[k+1] = A dx[k] + B du[k] + b */
+} IpmState;
+
+typedef struct {
+    real K[MAXN][NU][NX];
+    real Li[MAXN][3];       /* inverse of Huu: [i00 i01 i11] */
+    real P[MAXN + 1][NX][NX];
+} RicFactor;
+
+/* Backward Riccati recursion for the matrices.  Rt/Qt66 = barrier-augmented diagonals. */
+static void riccati_factor(const StageQP* qp, const real Rt[][NU], const real* Qt66, RicFactor* F)
+{
+    const int N = qp->N;
+    memset(F->P[N], 0, sizeof(F->P[N]));
+    for (int i = 0; i < NX; ++i) F->P[N][i][i] = qp->Qe[i];
+    for (int k = N - 1; k >= 0; --k) {
+        real (*P)[NX] = F->P[k + 1];
+        real PA[NX][NX], PB[NX][NU];
+        for (int i = 0; i < NX; ++i) {
+            for (int j = 0; j < NX; ++j) { real a = 0; for (int l = 0; l < NX; ++l) a += P[i][l] * qp->A[k][l][j]; PA[i][j] = a; }
+            for (int j = 0; j < NU; ++j) { real a = 0; for (int l = 0; l < NX; ++l) a += P[i][l] * qp->B[k][l][j]; PB[i][j] = a; }
+        }
+        real Huu[NU][NU], Hux[NU][NX], Hxx[NX][NX];
+        for (int i = 0; i < NU; ++i) {
+            for (int j = 0; j < NU; ++j) { real a = 0; for (int l = 0; l < NX; ++l) a += qp->B[k][l][i] * PB[l][j]; Huu[i][j] = a; }
+            for (int j = 0; j < NX; ++j) { real a = 0; for (int l = 0; l < NX; ++l) a += qp->B[k][l][i] * PA[l][j]; Hux[i][j] = a; }
+            Huu[i][i] += Rt[k][i];
+        }
+        for (int i = 0; i < NX; ++i)
+            for (int j = 0; j < NX; ++j) { real a = 0; for (int l = 0; l < NX; ++l) a += qp->A[k][l][i] * PA[l][j]; Hxx[i][j] = a; }
+        for (int i = 0; i < NX; ++i) Hxx[i][i] += (i == 6 && k >= 1) ? Qt66[k] : qp->Qd[i];
+        /* 2x2 inverse */
+        real det = Huu[0][0] * Huu[1][1] - Huu[0][1] * Huu[1][0];
+        real i00 = Huu[1][1] / det, i01 = -Huu[0][1] / det, i11 = Huu[0][0] / det;
+        F->Li[k][0] = i00; F->Li[k][1] = i01; F->Li[k][2] = i11;
+        for (int j = 0; j < NX; ++j) {
+            F->K[k][0][j] = -(i00 * Hux[0][j] + i01 * Hux[1][j]);
+            F->K[k][1][j] = -(i01 * Hux[0][j] + i11 * Hux[1][j]);
+        }
+        /* P_k = Hxx + Hxu K, symmetrised */
+        for (int i = 0; i < NX; ++i)
+            for (int j = 0; j <= i; ++j) {
+                real a = Hxx[i][j] + Hux[0][i] * F->K[k][0][j] + Hux[1][i] * F->K[k][1][j];
+                real bsym = Hxx[j][i] + Hux[0][j] * F->K[k][0][i] + Hux[1][j] * F->K[k][1][i];
+                real s = (real)0.5 * (a + bsym);
+                F->P[k][i][j] = s; F->P[k][j][i] = s;
+            }
+    }
+}
+
+/* Vector part for the Newton step: backward sweep of the gradient, forward roll-out from ddx[0]=0.
+ *   minimise sum 1/2 dz'H~dz + gx'ddx + gu'ddu   s.t.  ddx[k+1] = A ddx[k] + B ddu[k] + beq[k]
+ * also returns the multiplier step dpi[k] = P[k+1] ddx[k+1] + p[k+1]. */
+static void riccati_solve(const StageQP* qp, const RicFactor* F, const real gx[][NX], const real gu[][NU], const real beq[][NX],
+                          real ddu[][NU], real ddx[][NX], real dpi[][NX])
+{
+    const int N = qp->N;
+    real pv[MAXN + 1][NX], kff[MAXN][NU];
+    for (int i = 0; i < NX; ++i) pv[N][i] = gx[N][i];
+    for (int k = N - 1; k >= 0; --k) {
+        const real (*P)[NX] = F->P[k + 1];
+        real w[NX], hx[NX], hu[NU];
+        for (int i = 0; i < NX; ++i) { real a = pv[k + 1][i]; for (int l = 0; l < NX; ++l) a += P[i][l] * beq[k][l]; w[i] = a; }
+        for (int j = 0; j < NU; ++j) { real a = gu[k][j]; for (int l = 0; l < NX; ++l) a += qp->B[k][l][j] * w[l]; hu[j] = a; }
+        for (int j = 0; j < NX; ++j) { real a = gx[k][j]; for (int l = 0; l < NX; ++l) a += qp->A[k][l][j] * w[l]; hx[j] = a; }
+        kff[k][0] = -(F->Li[k][0] * hu[0] + F->Li[k][1] * hu[1]);
+        kff[k][1] = -(F->Li[k][1] * hu[0] + F->Li[k][2] * hu[1]);
+        for (int j = 0; j < NX; ++j) pv[k][j] = hx[j] + F->K[k][0][j] * hu[0] + F->K[k][1][j] * hu[1];
+    }
+    for (int i = 0; i < NX; ++i) ddx[0][i] = 0;
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) { real a = kff[k][j]; for (int l = 0; l < NX; ++l) a += F->K[k][j][l] * ddx[k][l]; ddu[k][j] = a; }
+        for (int i = 0; i < NX; ++i) {
+            real a = beq[k][i];
+            for (int l = 0; l < NX; ++l) a += qp->A[k][i][l] * ddx[k][l];
+            for (int l = 0; l < NU; ++l) a += qp->B[k][i][l] * ddu[k][l];
+            ddx[k + 1][i] = a;
+        }
+        for (int i = 0; i < NX; ++i) { real a = pv[k + 1][i]; for (int l = 0; l < NX; ++l) a += F->P[k + 1][i][l] * ddx[k + 1][l]; dpi[k][i] = a; }
+    }
+}
+
+typedef struct {
+    /* residuals */
+    real ru[MAXN][NU], rx[MAXN + 1][NX], rsl[MAXN][NU], rsu[MAXN][NU], req[MAXN][NX];
+    real rd[MAXN][NU][4], rdd[MAXN][2];
+    real rc[MAXN][NU][4], rcd[MAXN][2];          /* complementarity rhs (lam*t, + corrector terms) */
+    /* reduced system */
+    real Rt[MAXN][NU], Qt66[MAXN], gu[MAXN][NU], gx[MAXN + 1][NX], e1[MAXN][NU], e2[MAXN][NU];
+    /* steps */
+    real ddu[MAXN][NU], ddx[MAXN + 1][NX], dpi[MAXN][NX], dsl[MAXN][NU], dsu[MAXN][NU];
+    real dt[MAXN][NU][4], dlam[MAXN][NU][4], dtd[MAXN][2], dlamd[MAXN][2];
+} IpmWork;
+
+/* all linear residuals at the current iterate; returns their max-norm */
+static real ipm_residuals(const StageQP* qp, const IpmState* s, IpmWork* w)
+{
+    const int N = qp->N;
+    real m = 0;
+#define UPD(v) do { real a_ = R_FABS(v); if (a_ > m || !(a_ == a_)) m = a_; } while (0)
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) {
+            real a = qp->Rd[j] * s->du[k][j] + qp->r[k][j] - s->lam[k][j][0] + s->lam[k][j][1];
+            for (int l = 0; l < NX; ++l) a += qp->B[k][l][j] * s->pi[k][l];
+            w->ru[k][j] = a; UPD(a);
+            w->rsl[k][j] = qp->rho_l - s->lam[k][j][0] - s->lam[k][j][2]; UPD(w->rsl[k][j]);
+            w->rsu[k][j] = qp->rho_u - s->lam[k][j][1] - s->lam[k][j][3]; UPD(w->rsu[k][j]);
+            w->rd[k][j][0] = s->du[k][j] + s->sl[k][j] - qp->dlu[k][j] - s->t[k][j][0];
+            w->rd[k][j][1] = -s->du[k][j] + s->su[k][j] + qp->duu[k][j] - s->t[k][j][1];
+            w->rd[k][j][2] = s->sl[k][j] - s->t[k][j][2];
+            w->rd[k][j][3] = s->su[k][j] - s->t[k][j][3];
+            for (int i = 0; i < 4; ++i) UPD(w->rd[k][j][i]);
+        }
+        for (int i = 0; i < NX; ++i) {
+            real a = qp->b[k][i] - s->dx[k + 1][i];
+            for (int l = 0; l < NX; ++l) a += qp->A[k][i][l] * s->dx[k][l];
+            for (int l = 0; l < NU; ++l) a += qp->B[k][i][l] * s->du[k][l];
+            w->req[k][i] = a; UPD(a);
+        }
+        if (k >= 1) {
+            for (int i = 0; i < NX; ++i) {
+                real a = qp->Qd[i] * s->dx[k][i] + qp->q[k][i] - s->pi[k - 1][i];
+                for (int l = 0; l < NX; ++l) a += qp->A[k][l][i] * s->pi[k][l];
+                w->rx[k][i] = a;
+            }
+            w->rx[k][6] += -s->lamd[k][0] + s->lamd[k][1];
+            for (int i = 0; i < NX; ++i) UPD(w->rx[k][i]);
+            w->rdd[k][0] = s->dx[k][6] - qp->dld[k] - s->td[k][0]; UPD(w->rdd[k][0]);
+            w->rdd[k][1] = qp->dud[k] - s->dx[k][6] - s->td[k][1]; UPD(w->rdd[k][1]);
+        } else {
+            for (int i = 0; i < NX; ++i) w->rx[0][i] = 0;
+        }
+    }
+    for (int i = 0; i < NX; ++i) { w->rx[N][i] = qp->Qe[i] * s->dx[N][i] + qp->q[N][i] - s->pi[N - 1][i]; UPD(w->rx[N][i]); }
+#undef UPD
+    return m;
+}
+
+/* eliminate slacks / inequality multipliers: barrier-augmented diagonals and gradients */
+static void ipm_reduce(const StageQP* qp, const IpmState* s, IpmWork* w, int hessian_too)
+{
+    const int N = qp->N;
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) w->gx[k][i] = w->rx[k][i];
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) {
+            const real* t = s->t[k][j]; const real* l = s->lam[k][j]; const real* rc = w->rc[k][j]; const real* rd = w->rd[k][j];
+            real G0 = l[0] / t[0], G1 = l[1] / t[1], G2 = l[2] / t[2], G3 = l[3] / t[3];
+            real e1 = w->rsl[k][j] + rc[0] / t[0] + rc[2] / t[2] + G0 * rd[0] + G2 * rd[2];
+            real e2 = w->rsu[k][j] + rc[1] / t[1] + rc[3] / t[3] + G1 * rd[1] + G3 * rd[3];
+            real etal = rc[0] / t[0] + G0 * rd[0] - G0 * e1 / (G0 + G2);
+            real etau = -rc[1] / t[1] - G1 * rd[1] + G1 * e2 / (G1 + G3);
+            if (hessian_too) w->Rt[k][j] = qp->Rd[j] + G0 * G2 / (G0 + G2) + G1 * G3 / (G1 + G3);
+            w->gu[k][j] = w->ru[k][j] + etal + etau;
+            w->e1[k][j] = e1; w->e2[k][j] = e2;
+        }
+        if (k >= 1) {
+            real G5 = s->lamd[k][0] / s->td[k][0], G6 = s->lamd[k][1] / s->td[k][1];
+            if (hessian_too) w->Qt66[k] = qp->Qd[6] + G5 + G6;
+            w->gx[k][6] += (w->rcd[k][0] / s->td[k][0] + G5 * w->rdd[k][0]) - (w->rcd[k][1] / s->td[k][1] + G6 * w->rdd[k][1]);
+        } else if (hessian_too) w->Qt66[k] = qp->Qd[6];
+    }
+}
+
+/* recover the slack / t / lam steps from (ddu, ddx) */
+static void ipm_expand(const StageQP* qp, const IpmState* s, IpmWork* w)
+{
+    const int N = qp->N;
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) {
+            const real* t = s->t[k][j]; const real* l = s->lam[k][j]; const real* rc = w->rc[k][j]; const real* rd = w->rd[k][j];
+            real G[4] = { l[0] / t[0], l[1] / t[1], l[2] / t[2], l[3] / t[3] };
+            real u = w->ddu[k][j];
+            real dsl = -(w->e1[k][j] + G[0] * u) / (G[0] + G[2]);
+            real dsu = -(w->e2[k][j] - G[1] * u) / (G[1] + G[3]);
+            real dtv[4] = { u + dsl + rd[0], -u + dsu + rd[1], dsl + rd[2], dsu + rd[3] };
+            for (int i = 0; i < 4; ++i) { w->dt[k][j][i] = dtv[i]; w->dlam[k][j][i] = -rc[i] / t[i] - G[i] * dtv[i]; }
+            w->dsl[k][j] = dsl; w->dsu[k][j] = dsu;
+        }
+        if (k >= 1) {
+            real G5 = s->lamd[k][0] / s->td[k][0], G6 = s->lamd[k][1] / s->td[k][1];
+            real x6 = w->ddx[k][6];
+            w->dtd[k][0] = x6 + w->rdd[k][0];  w->dlamd[k][0] = -w->rcd[k][0] / s->td[k][0] - G5 * w->dtd[k][0];
+            w->dtd[k][1] = -x6 + w->rdd[k][1]; w->dlamd[k][1] = -w->rcd[k][1] / s->td[k][1] - G6 * w->dtd[k][1];
+        }
+    }
+}
+
+static real ipm_max_step(const StageQP* qp, const IpmState* s, const IpmWork* w)
+{
+    const int N = qp->N;
+    real a = 1;
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j)
+            for (int i = 0; i < 4; ++i) {
+                if (w->dt[k][j][i] < 0)   { real c = -s->t[k][j][i] / w->dt[k][j][i];     if (c < a) a = c; }
+                if (w->dlam[k][j][i] < 0) { real c = -s->lam[k][j][i] / w->dlam[k][j][i]; if (c < a) a = c; }
+            }
+        if (k >= 1)
+            for (int i = 0; i < 2; ++i) {
+                if (w->dtd[k][i] < 0)   { real c = -s->td[k][i] / w->dtd[k][i];     if (c < a) a = c; }
+                if (w->dlamd[k][i] < 0) { real c = -s->lamd[k][i] / w->dlamd[k][i]; if (c < a) a = c; }
+            }
+    }
+    return a;
+}
+
+/* Mehrotra predictor-corrector primal-dual IPM in residual (Newton-step) form.
+ * returns number of IPM iterations, negative on numerical failure */
+static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWork* w, RicFactor* F)
+{
+    const int N = qp->N;
+    const int n_ineq = 8 * N + 2 * (N - 1);
+    const real thr = c->ipm_thr0, mu0 = c->ipm_mu0;
+    /* cold start (qp_solver_warm_start 0, sim_car_acados_ocp.json:885): zero step, slacks at thr */
+    memset(s, 0, sizeof *s);
+    for (int i = 0; i < NX; ++i) s->dx[0][i] = qp->dx0[i];
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) {
+            s->sl[k][j] = thr; s->su[k][j] = thr;
+            real r0[4] = { thr - qp->dlu[k][j], thr + qp->duu[k][j], thr, thr };
+            for (int i = 0; i < 4; ++i) { s->t[k][j][i] = r0[i] > thr ? r0[i] : thr; s->lam[k][j][i] = mu0 / s->t[k][j][i]; }
+        }
+        s->td[k][0] = s->td[k][1] = 1;
+        if (k >= 1) {
+            real r0[2] = { -qp->dld[k], qp->dud[k] };
+            for (int i = 0; i < 2; ++i) { s->td[k][i] = r0[i] > thr ? r0[i] : thr; s->lamd[k][i] = mu0 / s->td[k][i]; }
+        }
+    }
+    int it;
+    real rmax_prev = 0, step = 1e300;   /* step: max-norm of the last applied input step */
+    for (it = 0; it < c->ipm_iter_max; ++it) {
+        real mu = 0, cmax = 0;
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i) { real v = s->t[k][j][i] * s->lam[k][j][i]; w->rc[k][j][i] = v; mu += v; if (v > cmax) cmax = v; }
+            if (k >= 1) for (int i = 0; i < 2; ++i) { real v = s->td[k][i] * s->lamd[k][i]; w->rcd[k][i] = v; mu += v; if (v > cmax) cmax = v; }
+        }
+        mu /= n_ineq;
+        real rmax = ipm_residuals(qp, s, w);
+        if (!(mu == mu) || !(rmax == rmax)) return -1;
+        /* converged, or complementarity reached and the linear residuals sit on their rounding floor */
+        if (cmax <= c->ipm_tol_comp && step <= c->ipm_tol_step &&
+            (rmax <= c->ipm_tol_res || (it > 0 && rmax > (real)0.1 * rmax_prev))) break;
+        rmax_prev = rmax;
+
+        /* predictor (affine scaling direction) */
+        ipm_reduce(qp, s, w, 1);
+        riccati_factor(qp, (const real (*)[NU])w->Rt, w->Qt66, F);
+        riccati_solve(qp, F, (const real (*)[NX])w->gx, (const real (*)[NU])w->gu, (const real (*)[NX])w->req, w->ddu, w->ddx, w->dpi);
+        ipm_expand(qp, s, w);
+        real a_aff = ipm_max_step(qp, s, w);
+        real mu_aff = 0;
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i)
+                mu_aff += (s->t[k][j][i] + a_aff * w->dt[k][j][i]) * (s->lam[k][j][i] + a_aff * w->dlam[k][j][i]);
+            if (k >= 1) for (int i = 0; i < 2; ++i)
+                mu_aff += (s->td[k][i] + a_aff * w->dtd[k][i]) * (s->lamd[k][i] + a_aff * w->dlamd[k][i]);
+        }
+        mu_aff /= n_ineq;
+        real sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+        /* corrector: centring + second-order term */
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i)
+                w->rc[k][j][i] = s->t[k][j][i] * s->lam[k][j][i] + w->dt[k][j][i] * w->dlam[k][j][i] - sigma * mu;
+            if (k >= 1) for (int i = 0; i < 2; ++i)
+                w->rcd[k][i] = s->td[k][i] * s->lamd[k][i] + w->dtd[k][i] * w->dlamd[k][i] - sigma * mu;
+        }
+        ipm_reduce(qp, s, w, 0);
+        riccati_solve(qp, F, (const real (*)[NX])w->gx, (const real (*)[NU])w->gu, (const real (*)[NX])w->req, w->ddu, w->ddx, w->dpi);
+        ipm_expand(qp, s, w);
+        real a_max = ipm_max_step(qp, s, w);
+        real tau = 1 - mu_aff; if (tau < (real)0.995) tau = (real)0.995; if (tau > (real)0.999999) tau = (real)0.999999;
+        real alpha = tau * a_max; if (alpha > 1) alpha = 1;
+        step = 0;
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < NU; ++j) {
+                real sj = R_FABS(alpha * w->ddu[k][j]); if (sj > step) step = sj;
+                for (int i = 0; i < 4; ++i) {
+                    s->t[k][j][i] += alpha * w->dt[k][j][i]; s->lam[k][j][i] += alpha * w->dlam[k][j][i];
+                    if (s->t[k][j][i] < IPM_FLOOR) s->t[k][j][i] = IPM_FLOOR;
+                    if (s->lam[k][j][i] < IPM_FLOOR) s->lam[k][j][i] = IPM_FLOOR;
+                }
+                s->du[k][j] += alpha * w->ddu[k][j];
+                s->sl[k][j] += alpha * w->dsl[k][j];
+                s->su[k][j] += alpha * w->dsu[k][j];
+            }
+            for (int i = 0; i < NX; ++i) { s->dx[k + 1][i] += alpha * w->ddx[k + 1][i]; s->pi[k][i] += alpha * w->dpi[k][i]; }
+            if (k >= 1) for (int i = 0; i < 2; ++i) {
+                s->td[k][i] += alpha * w->dtd[k][i]; s->lamd[k][i] += alpha * w->dlamd[k][i];
+                if (s->td[k][i] < IPM_FLOOR) s->td[k][i] = IPM_FLOOR;
+                if (s->lamd[k][i] < IPM_FLOOR) s->lamd[k][i] = IPM_FLOOR;
+            }
+        }
+    }
+    return it;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* one RTI step of one instance                                                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { StageQP qp; IpmState st; IpmWork wk; RicFactor F; real dx[MAXN + 1][NX]; } Workspace;
+
+static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const double* yref, const double* yref_e,
+                    double p, double* xbar, double* ubar, int* iters)
+{
+    const int N = c->N;
+    StageQP* qp = &W->qp;
+    qp->N = N;
+    qp->rho_l = c->Ts * c->zl; qp->rho_u = c->Ts * c->zu;
+    for (int i = 0; i < NX; ++i) { qp->Qd[i] = c->Ts * c->W[i]; qp->Qe[i] = c->We[i]; }
+    for (int j = 0; j < NU; ++j) qp->Rd[j] = c->Ts * c->W[NX + j];
+    for (int k = 0; k < N; ++k) {                                           /* H1: shooting */
+        real xk[NX], uk[NU], phi[NX];
+        for (int i = 0; i < NX; ++i) xk[i] = xbar[k * NX + i];
+        for (int j = 0; j < NU; ++j) uk[j] = ubar[k * NU + j];
+        rk4_sens(c, xk, uk, (real)p, (real)c->Ts, phi, qp->A[k], qp->B[k]);
+        for (int i = 0; i < NX; ++i) qp->b[k][i] = phi[i] - (real)xbar[(k + 1) * NX + i];
+        for (int i = 0; i < NX; ++i) qp->q[k][i] = qp->Qd[i] * (xk[i] - (real)yref[k * NY + i]);      /* H2 */
+        for (int j = 0; j < NU; ++j) {
+            qp->r[k][j] = qp->Rd[j] * (uk[j] - (real)yref[k * NY + NX + j]);
+            qp->dlu[k][j] = (real)c->lbu[j] - uk[j]; qp->duu[k][j] = (real)c->ubu[j] - uk[j];          /* H3 */
+        }
+        qp->dld[k] = (real)c->lbx_delta - xk[6]; qp->dud[k] = (real)c->ubx_delta - xk[6];
+    }
+    for (int i = 0; i < NX; ++i) {
+        qp->q[N][i] = qp->Qe[i] * ((real)xbar[N * NX + i] - (real)yref_e[i]);
+        qp->dx0[i] = (real)x0[i] - (real)xbar[i];
+    }
+    int it = ipm_solve(c, qp, &W->st, &W->wk, &W->F);                       /* H4+H5 */
+    if (iters) *iters = it;
+    if (it < 0) return ADMPC_STATUS_QP_FAILURE;
+    /* H6: expand dx from du through the linearised dynamics, full step */
+    for (int i = 0; i < NX; ++i) W->dx[0][i] = qp->dx0[i];
+    for (int k = 0; k < N; ++k)
+        for (int i = 0; i < NX; ++i) {
+            real a = qp->b[k][i];
+            for (int l = 0; l < NX; ++l) a += qp->A[k][i][l] * W->dx[k][l];
+            for (int l = 0; l < NU; ++l) a += qp->B[k][i][l] * W->st.du[k][l];
+            W->dx[k + 1][i] = a;
+        }
+    int bad = 0;
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real v = (real)xbar[k * NX + i] + W->dx[k][i]; if (!(v == v) || R_FABS(v) > 1e300) bad = 1; xbar[k * NX + i] = (double)v; }
+    for (int k = 0; k < N; ++k) for (int j = 0; j < NU; ++j) { real v = (real)ubar[k * NU + j] + W->st.du[k][j]; if (!(v == v) || R_FABS(v) > 1e300) bad = 1; ubar[k * NU + j] = (double)v; }
+    return bad ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+}
+
+static double eval_cost(const AdmpcConfig* c, const double* yref, const double* yref_e, const double* xbar, const double* ubar)
+{
+    const int N = c->N;
+    real J = 0;
+    for (int k = 0; k < N; ++k) {
+        for (int i = 0; i < NX; ++i) { real e = (real)xbar[k * NX + i] - (real)yref[k * NY + i]; J += (real)0.5 * c->Ts * c->W[i] * e * e; }
+        for (int j = 0; j < NU; ++j) {
+            real u = ubar[k * NU + j];
+            real e = u - (real)yref[k * NY + NX + j]; J += (real)0.5 * c->Ts * c->W[NX + j] * e * e;
+            if (u < c->lbu[j]) J += c->Ts * c->zl * (c->lbu[j] - u);
+            if (u > c->ubu[j]) J += c->Ts * c->zu * (u - c->ubu[j]);
+        }
+    }
+    for (int i = 0; i < NX; ++i) { real e = (real)xbar[N * NX + i] - (real)yref_e[i]; J += (real)0.5 * c->We[i] * e * e; }
+    return (double)J;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* exported                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+void oracle_f(const AdmpcConfig* c, const double* x, const double* u, double p, double* xdot)
+{
+    real xr[NX], ur[NU], f[NX];
+    for (int i = 0; i < NX; ++i) xr[i] = x[i];
+    for (int j = 0; j < NU; ++j) ur[j] = u[j];
+    model_f(c, xr, ur, (real)p, f);
+    for (int i = 0; i < NX; ++i) xdot[i] = (double)f[i];
+}
+
+void oracle_jac(const AdmpcConfig* c, const double* x, const double* u, double p, double* Jx, double* Ju)
+{
+    real xr[NX], ur[NU], jx[NX][NX], ju[NX][NU];
+    for (int i = 0; i < NX; ++i) xr[i] = x[i];
+    for (int j = 0; j < NU; ++j) ur[j] = u[j];
+    model_jac(c, xr, ur, (real)p, jx, ju);
+    for (int i = 0; i < NX; ++i) { for (int j = 0; j < NX; ++j) Jx[i * NX + j] = (double)jx[i][j]; for (int j = 0; j < NU; ++j) Ju[i * NU + j] = (double)ju[i][j]; }
+}
+
+void oracle_rk4_sens(const AdmpcConfig* c, const double* x, const double* u, double p, double h, double* phi, double* A, double* B)
+{
+    real xr[NX], ur[NU], ph[NX], a[NX][NX], b[NX][NU];
+    for (int i = 0; i < NX; ++i) xr[i] = x[i];
+    for (int j = 0; j < NU; ++j) ur[j] = u[j];
+    rk4_sens(c, xr, ur, (real)p, (real)h, ph, a, b);
+    for (int i = 0; i < NX; ++i) { phi[i] = (double)ph[i]; for (int j = 0; j < NX; ++j) A[i * NX + j] = (double)a[i][j]; for (int j = 0; j < NU; ++j) B[i * NU + j] = (double)b[i][j]; }
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int oracle_solve_batch(const AdmpcConfig* c, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
+                       double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, int nthreads)
+{
+    if (!c || c->N < 2 || c->N > MAXN || B < 0) return ADMPC_EINVAL;
+    const int N = c->N;
+    const int nsqp = c->sqp_iters > 0 ? c->sqp_iters : 1;
+    (void)nthreads;
+    int err = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    {
+        Workspace* W = (Workspace*)malloc(sizeof(Workspace));
+        if (!W) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            err = 1;
+        } else {
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 8)
+#endif
+            for (int b = 0; b < B; ++b) {
+                double* xb = xbar + (size_t)b * (N + 1) * NX;
+                double* ub = ubar + (size_t)b * N * NU;
+                const double* yr = yref + (size_t)b * N * NY;
+                const double* ye = yref_e + (size_t)b * NX;
+                int st = 0, it = 0;
+                for (int s = 0; s < nsqp && st == 0; ++s) st = rti_step(c, W, x0 + (size_t)b * NX, yr, ye, p[b], xb, ub, &it);
+                if (status) status[b] = st;
+                if (iters) iters[b] = it;
+                if (cost) cost[b] = st == 0 ? eval_cost(c, yr, ye, xb, ub) : INFINITY;
+            }
+            free(W);
+        }
+    }
+    return err ? ADMPC_ENOMEM : ADMPC_OK;
+}
+
+int oracle_qp_debug(const AdmpcConfig* c, const double* x0, const double* yref, const double* yref_e, double p,
+                    const double* xbar_in, const double* ubar_in,
+                    double* du, double* dx, double* A, double* Bm, double* b,
+                    double* lam_u, double* lam_d, double* sl, double* su, int32_t* iters)
+{
+    if (!c || c->N < 2 || c->N > MAXN) return ADMPC_EINVAL;
+    const int N = c->N;
+    Workspace* W = (Workspace*)malloc(sizeof(Workspace));
+    double* xb = (double*)malloc(sizeof(double) * (N + 1) * NX);
+    double* ub = (double*)malloc(sizeof(double) * N * NU);
+    if (!W || !xb || !ub) { free(W); free(xb); free(ub); return ADMPC_ENOMEM; }
+    memcpy(xb, xbar_in, sizeof(double) * (N + 1) * NX);
+    memcpy(ub, ubar_in, sizeof(double) * N * NU);
+    int it = 0;
+    int st = rti_step(c, W, x0, yref, yref_e, p, xb, ub, &it);
+    if (iters) *iters = it;
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) {
+            du[k * NU + j] = (double)W->st.du[k][j];
+            sl[k * NU + j] = (double)W->st.sl[k][j]; su[k * NU + j] = (double)W->st.su[k][j];
+            for (int i = 0; i < 4; ++i) lam_u[(k * NU + j) * 4 + i] = (double)W->st.lam[k][j][i];
+        }
+        lam_d[k * 2 + 0] = k >= 1 ? (double)W->st.lamd[k][0] : 0; lam_d[k * 2 + 1] = k >= 1 ? (double)W->st.lamd[k][1] : 0;
+        for (int i = 0; i < NX; ++i) {
+            b[k * NX + i] = (double)W->qp.b[k][i];
+            for (int j = 0; j < NX; ++j) A[(k * NX + i) * NX + j] = (double)W->qp.A[k][i][j];
+            for (int j = 0; j < NU; ++j) Bm[(k * NX + i) * NU + j] = (double)W->qp.B[k][i][j];
+        }
+    }
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) dx[k * NX + i] = (double)W->dx[k][i];
+    free(W); free(xb); free(ub);
+    return st;
+}

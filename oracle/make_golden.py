@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the development container (needs /root/reference and oracle/_ref built by
+`make -C oracle ref`).  The fixtures are DATA (inputs and expected outputs); no reference source
+text is copied.
+
+  tests/golden/shooting.json
+      120 random (x, u, p) points -> xdot, phi, A, B computed by the REFERENCE's own compiled
+      CasADi model code (c_generated_code/sim_car_model/sim_car_expl_ode_fun.c and
+      sim_car_expl_vde_forw.c) driven as acados' ERK4 does (acados_solver_sim_car.c:655-665).
+
+  tests/golden/kat_sim_car_iterate.json
+      Known-answer test for the solver, reconstructed from the converged acados iterate that the
+      reference ships (src/ad_mpc/sim_car_iterate.json, N=40, kinematic mode p=0):
+      x0, the stage references recovered from the stored multipliers through the stationarity
+      conditions, the terminal weight scale that makes the fixture
+      consistent (1e-2, not the shipped 1e-6), and the stored X, U, pi, lam themselves.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:] = [q for q in sys.path if os.path.abspath(q or '.') != HERE]   # `oracle` must resolve to the package
+sys.path.insert(0, ROOT)
+
+from oracle.oracle import RefModel  # noqa: E402
+
+REF = os.environ.get("ADMPC_REFERENCE", "/root/reference")
+ITERATE = os.path.join(REF, "data_driven_mpc/ros_gp_mpc/src/ad_mpc/sim_car_iterate.json")
+OUT = os.path.join(ROOT, "tests", "golden")
+NX, NU = 7, 2
+TS = 0.05
+
+
+def shooting(ref):
+    rng = np.random.default_rng(20261003)
+    cases = []
+    for i in range(120):
+        p = [0.0, 0.3, 1.0][i % 3]
+        x = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-np.pi, np.pi), rng.uniform(0.5, 20),
+                      rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)])
+        u = np.array([rng.uniform(-10, 5), rng.uniform(-3, 3)])
+        if i >= 114:      # the reference's own initial iterate: all zeros (acados_solver_sim_car.c:705-731)
+            x = np.zeros(NX); u = np.zeros(NU); p = 0.0
+            if i >= 117:
+                x[0:3] = rng.uniform(-3, 3, 3); u = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1)])
+        xdot = ref.ode(x, u, p)
+        phi, A, B = ref.rk4_sens(x, u, p, TS)
+        cases.append(dict(x=x.tolist(), u=u.tolist(), p=p, h=TS, xdot=xdot.tolist(), phi=phi.tolist(),
+                          A=A.tolist(), B=B.tolist()))
+    return dict(source="reference CasADi C (sim_car_expl_ode_fun.c, sim_car_expl_vde_forw.c) via oracle/_ref",
+                cases=cases)
+
+
+def kat(ref):
+    d = json.load(open(ITERATE))
+    N = 40
+    X = np.array([d["x_%d" % k] for k in range(N + 1)])
+    U = np.array([d["u_%d" % k] for k in range(N)])
+    PI = np.array([d["pi_%d" % k] for k in range(N)])
+    LAM = [np.array(d["lam_%d" % k]) for k in range(N)]
+    q = np.array([10.0, 10.0, 100.0, 0, 0, 0, 0]); r = np.array([1.0, 100.0])
+    gaps = 0.0
+    A = np.zeros((N, NX, NX)); B = np.zeros((N, NX, NU))
+    for k in range(N):
+        phi, A[k], B[k] = ref.rk4_sens(X[k], U[k], 0.0, TS)
+        gaps = max(gaps, np.abs(phi - X[k + 1]).max())
+    # multiplier layout per stage (SURVEY 8c Pin 2 iii): k>=1: [lbu(2), lbx(1), ubu(2), ubx(1), ls(2), us(2)]
+    #                                                    k==0: [lbu(2), lbx(7), ubu(2), ubx(7), ls(2), us(2)]
+    yref = np.zeros((N, NX + NU))
+    uref_rec = np.zeros((N, NU))
+    for k in range(N):
+        lam = LAM[k]
+        nbx = 7 if k == 0 else 1
+        lbu = lam[0:2]; lbx = lam[2:2 + nbx]; ubu = lam[2 + nbx:4 + nbx]; ubx = lam[4 + nbx:4 + 2 * nbx]
+        # stationarity in u:  Ts*R*(u-uref) + B'pi - lam_lbu + lam_ubu = 0
+        uref_rec[k] = U[k] + (B[k].T @ PI[k] - lbu + ubu) / (TS * r)
+        if k >= 1:
+            g = A[k].T @ PI[k] - PI[k - 1]
+            g[6] += -lbx[0] + ubx[0]
+            # stationarity in x: Ts*Q*(x-xref) + A'pi_k - pi_{k-1} - lam_lbx + lam_ubx = 0 (weighted rows only)
+            yref[k, 0:3] = X[k, 0:3] + g[0:3] / (TS * q[0:3])
+            res_unweighted = np.abs(g[3:]).max()
+            assert res_unweighted < 1e-6, res_unweighted
+        else:
+            yref[0, 0:3] = X[0, 0:3]     # stage-0 state reference is irrelevant (x_0 is fixed); use x0
+    assert np.abs(uref_rec).max() < 1e-8, np.abs(uref_rec).max()
+    yref[:, 3] = 0.0                     # weight 0 -> value irrelevant
+    # terminal: pi_{N-1} = W_e (x_N - yref_N)  with W_e = 1e-2*q (consistent with last-row padding)
+    we_scale = 1e-2
+    We = we_scale * q
+    yref_e = np.zeros(NX)
+    yref_e[0:3] = X[N, 0:3] - PI[N - 1, 0:3] / We[0:3]
+    pad_err = np.abs(yref_e[0:2] - yref[N - 1, 0:2]).max()
+    return dict(
+        source="data_driven_mpc/ros_gp_mpc/src/ad_mpc/sim_car_iterate.json (converged acados iterate, N=40, p=0)",
+        N=N, Ts=TS, p=0.0, q=q.tolist(), r=r.tolist(), terminal_scale=we_scale,
+        x0=X[0].tolist(), yref=yref.tolist(), yref_e=yref_e.tolist(),
+        X=X.tolist(), U=U.tolist(), PI=PI.tolist(), LAM=[l.tolist() for l in LAM],
+        checks=dict(max_shooting_gap=gaps, max_abs_recovered_uref=float(np.abs(uref_rec).max()),
+                    terminal_xy_vs_last_row_padding=float(pad_err)))
+
+
+def main():
+    ref = RefModel()
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "shooting.json"), "w") as f:
+        json.dump(shooting(ref), f)
+    k = kat(ref)
+    with open(os.path.join(OUT, "kat_sim_car_iterate.json"), "w") as f:
+        json.dump(k, f)
+    print("shooting.json: 120 cases;  KAT checks:", k["checks"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+"""ctypes wrapper of oracle/liboracle.so and oracle/_ref/libsimcar_ref.so.  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package (ad_mpc_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ad_mpc_amd.config import AdmpcConfig, NX, NU, NY
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def build(omp=False, quiet=True):
+    """(Re)build the oracle library with gcc; returns the .so path."""
+    target = "liboracle_omp.so" if omp else "liboracle.so"
+    subprocess.run(["make", "-C", _HERE, target], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return os.path.join(_HERE, target)
+
+
+def _ptr(a, ty=_dp):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, omp=False):
+        path = os.path.join(_HERE, "liboracle_omp.so" if omp else "liboracle.so")
+        if not os.path.exists(path):
+            build(omp=omp)
+        self.lib = C.CDLL(path)
+        L = self.lib
+        cp = C.POINTER(AdmpcConfig)
+        L.oracle_f.argtypes = [cp, _dp, _dp, C.c_double, _dp]
+        L.oracle_jac.argtypes = [cp, _dp, _dp, C.c_double, _dp, _dp]
+        L.oracle_rk4_sens.argtypes = [cp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp]
+        L.oracle_solve_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
+        L.oracle_solve_batch.restype = C.c_int
+        L.oracle_qp_debug.argtypes = [cp, _dp, _dp, _dp, C.c_double, _dp, _dp] + [_dp] * 9 + [_ip]
+        L.oracle_qp_debug.restype = C.c_int
+        L.oracle_max_threads.restype = C.c_int
+
+    def max_threads(self):
+        return int(self.lib.oracle_max_threads())
+
+    def f(self, cfg, x, u, p):
+        x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        out = np.empty(NX)
+        self.lib.oracle_f(C.byref(cfg), _ptr(x), _ptr(u), float(p), _ptr(out))
+        return out
+
+    def jac(self, cfg, x, u, p):
+        x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        Jx = np.empty((NX, NX)); Ju = np.empty((NX, NU))
+        self.lib.oracle_jac(C.byref(cfg), _ptr(x), _ptr(u), float(p), _ptr(Jx), _ptr(Ju))
+        return Jx, Ju
+
+    def rk4_sens(self, cfg, x, u, p, h):
+        x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        phi = np.empty(NX); A = np.empty((NX, NX)); B = np.empty((NX, NU))
+        self.lib.oracle_rk4_sens(C.byref(cfg), _ptr(x), _ptr(u), float(p), float(h), _ptr(phi), _ptr(A), _ptr(B))
+        return phi, A, B
+
+    def solve_batch(self, cfg, x0, yref, yref_e, p, xbar, ubar, nthreads=1):
+        """Returns (x, u, cost, status, iters); xbar/ubar are not modified."""
+        N = cfg.N
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, NX)
+        B = x0.shape[0]
+        yref = np.ascontiguousarray(yref, dtype=np.float64).reshape(B, N, NY)
+        yref_e = np.ascontiguousarray(yref_e, dtype=np.float64).reshape(B, NX)
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(B)
+        x = np.array(xbar, dtype=np.float64).reshape(B, N + 1, NX).copy()
+        u = np.array(ubar, dtype=np.float64).reshape(B, N, NU).copy()
+        cost = np.empty(B); status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        rc = self.lib.oracle_solve_batch(C.byref(cfg), B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p),
+                                         _ptr(x), _ptr(u), _ptr(cost), _ptr(status, _ip), _ptr(iters, _ip),
+                                         int(nthreads))
+        if rc != 0:
+            raise RuntimeError("oracle_solve_batch failed: %d" % rc)
+        return x, u, cost, status, iters
+
+    def qp_debug(self, cfg, x0, yref, yref_e, p, xbar, ubar):
+        N = cfg.N
+        a = lambda v, s: np.ascontiguousarray(v, dtype=np.float64).reshape(s)
+        x0 = a(x0, (NX,)); yref = a(yref, (N, NY)); yref_e = a(yref_e, (NX,))
+        xbar = a(xbar, (N + 1, NX)); ubar = a(ubar, (N, NU))
+        out = dict(du=np.empty((N, NU)), dx=np.empty((N + 1, NX)), A=np.empty((N, NX, NX)), B=np.empty((N, NX, NU)),
+                   b=np.empty((N, NX)), lam_u=np.empty((N, NU, 4)), lam_d=np.empty((N, 2)),
+                   sl=np.empty((N, NU)), su=np.empty((N, NU)))
+        it = C.c_int32(0)
+        st = self.lib.oracle_qp_debug(C.byref(cfg), _ptr(x0), _ptr(yref), _ptr(yref_e), float(p), _ptr(xbar), _ptr(ubar),
+                                      *[_ptr(out[k]) for k in ("du", "dx", "A", "B", "b", "lam_u", "lam_d", "sl", "su")],
+                                      C.byref(it))
+        out["status"] = st; out["iters"] = it.value
+        return out
+
+
+class RefModel:
+    """The reference's own CasADi-generated model functions, compiled in place by `make -C oracle ref`
+    (c_generated_code/sim_car_model/sim_car_expl_ode_fun.c, sim_car_expl_vde_forw.c).  Calling
+    convention per SURVEY Appendix B."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "_ref", "libsimcar_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle ref` in the development container)")
+        self.lib = C.CDLL(path)
+        sig = [C.POINTER(_dp), C.POINTER(_dp), C.POINTER(C.c_longlong), _dp, C.c_int]
+        self.lib.sim_car_expl_ode_fun.argtypes = sig
+        self.lib.sim_car_expl_vde_forw.argtypes = sig
+        self._iw = (C.c_longlong * 16)()
+        self._w = (C.c_double * 512)()
+
+    def ode(self, x, u, p):
+        x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        pp = np.array([p], dtype=np.float64); out = np.empty(NX)
+        arg = (_dp * 16)(_ptr(x), _ptr(u), _ptr(pp)); res = (_dp * 16)(_ptr(out))
+        self.lib.sim_car_expl_ode_fun(arg, res, self._iw, self._w, 0)
+        return out
+
+    def vde_forw(self, x, Sx, Su, u, p):
+        """Sx [7,7], Su [7,2] (row-major numpy) -> xdot[7], dSx[7,7], dSu[7,2] (dense, zeros filled)."""
+        x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        sx = np.asfortranarray(Sx, dtype=np.float64); su = np.asfortranarray(Su, dtype=np.float64)
+        sxf = np.ascontiguousarray(sx.T.reshape(-1)); suf = np.ascontiguousarray(su.T.reshape(-1))  # column-major flat
+        pp = np.array([p], dtype=np.float64)
+        xdot = np.empty(NX); dsx = np.empty(42); dsu = np.empty(13)
+        arg = (_dp * 16)(_ptr(x), _ptr(sxf), _ptr(suf), _ptr(u), _ptr(pp)); res = (_dp * 16)(_ptr(xdot), _ptr(dsx), _ptr(dsu))
+        self.lib.sim_car_expl_vde_forw(arg, res, self._iw, self._w, 0)
+        dSx = np.zeros((NX, NX)); dSu = np.zeros((NX, NU))
+        dSx[:6, :] = dsx.reshape(7, 6).T          # 7 columns x rows 0..5
+        dSu[:6, 0] = dsu[:6]; dSu[:, 1] = dsu[6:]
+        return xdot, dSx, dSu
+
+    def rk4_sens(self, x, u, p, h):
+        """acados ERK4 (1 step) on the augmented state using the reference's VDE."""
+        x = np.asarray(x, dtype=np.float64)
+        cst = [0.0, 0.5, 0.5, 1.0]; wst = [1 / 6, 2 / 6, 2 / 6, 1 / 6]
+        kx = np.zeros(NX); kS = np.zeros((NX, NX)); kU = np.zeros((NX, NU))
+        ax = np.zeros(NX); aS = np.zeros((NX, NX)); aU = np.zeros((NX, NU))
+        for s in range(4):
+            X = x + cst[s] * h * kx; S = np.eye(NX) + cst[s] * h * kS; U = cst[s] * h * kU
+            kx, kS, kU = self.vde_forw(X, S, U, u, p)
+            ax += wst[s] * kx; aS += wst[s] * kS; aU += wst[s] * kU
+        return x + h * ax, np.eye(NX) + h * aS, h * aU
