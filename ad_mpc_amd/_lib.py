@@ -1,0 +1,53 @@
+"""Loader of the C-ABI shared library ``libadmpc.so`` (include/admpc.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the solver
+surface raises.  The CPU oracle under ``oracle/`` is test infrastructure and is never used here.
+"""
+import ctypes as C
+import os
+
+from .config import AdmpcConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadmpc.so")
+
+EXPORTS = (
+    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_solve_batch", "admpc_shoot_batch",
+    "admpc_argmin", "admpc_epilogue_batch", "admpc_last_error", "admpc_version",
+)
+
+_lib = None
+
+
+class AdmpcError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libadmpc.so and declare the prototypes of include/admpc.h (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdmpcError("%s not found: build it with `make -C ad_mpc_amd/csrc` (or __graft_entry__.build()); "
+                         "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p     # device pointers travel as integers
+    cp = C.POINTER(AdmpcConfig)
+    L.admpc_default_config.argtypes = [cp, C.c_int, C.c_double]; L.admpc_default_config.restype = C.c_int
+    L.admpc_create.argtypes = [cp, C.c_int, C.POINTER(C.c_void_p)]; L.admpc_create.restype = C.c_int
+    L.admpc_destroy.argtypes = [C.c_void_p]; L.admpc_destroy.restype = None
+    L.admpc_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
+    L.admpc_solve_batch.restype = C.c_int
+    L.admpc_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, vp]; L.admpc_shoot_batch.restype = C.c_int
+    L.admpc_argmin.argtypes = [C.c_void_p, dp, C.c_int, C.c_int64, dp, ip, vp]; L.admpc_argmin.restype = C.c_int
+    L.admpc_epilogue_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, ip, vp]; L.admpc_epilogue_batch.restype = C.c_int
+    L.admpc_last_error.restype = C.c_char_p
+    L.admpc_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise AdmpcError("libadmpc error %d: %s" % (rc, load().admpc_last_error().decode()))

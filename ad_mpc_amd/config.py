@@ -92,9 +92,9 @@ SLACK_L1 = 10.0            # ocp.cost.zl = zu = 1e1, src/ad_mpc/ad_3d_optimizer.
 IPM_ITER_MAX = 50
 IPM_MU0 = 1.0
 IPM_THR0 = 0.1
-IPM_TOL_COMP = 1e-11
+IPM_TOL_COMP = 1e-10
 IPM_TOL_RES = 1e-9
-IPM_TOL_STEP = 1e-7
+IPM_TOL_STEP = 1e-6
 
 
 def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TERMINAL_SCALE, sqp_iters=1):

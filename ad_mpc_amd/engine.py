@@ -1,0 +1,120 @@
+"""Batch solve engine: thin host wrapper over the C ABI (include/admpc.h).
+
+torch is used only as the carrier of device memory and streams; every number is produced by the
+HIP kernels in libadmpc.so.  All tensors are float64 / int32, contiguous, on the solver's device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import AdmpcConfig, NX, NU, NY, default_config
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class BatchSolver:
+    """One solver object per (config, device).  Replaces the AcadosOcpSolver object of
+    ad_3d_optimizer.py:209 for a whole batch of independent MPC instances."""
+
+    def __init__(self, cfg=None, device=0):
+        if not torch.cuda.is_available():
+            raise _lib.AdmpcError("no HIP device visible: the AD-MPC engine has no CPU fallback")
+        self.lib = _lib.load()
+        self.cfg = (cfg if cfg is not None else default_config()).copy()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p(0)
+        _lib.check(self.lib.admpc_create(C.byref(self.cfg), self.device_index, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.admpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------------------------
+    @property
+    def N(self):
+        return int(self.cfg.N)
+
+    def to_device(self, a, dtype=torch.float64):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device).contiguous()
+
+    def _chk(self, t, shape, dtype=torch.float64):
+        if t.dtype != dtype or not t.is_contiguous() or t.device != self.device or tuple(t.shape) != tuple(shape):
+            raise ValueError("expected contiguous %s tensor of shape %s on %s, got %s %s on %s"
+                             % (dtype, tuple(shape), self.device, t.dtype, tuple(t.shape), t.device))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- the hot path --------------------------------------------------------------------------
+    def solve(self, x0, yref, yref_e, p, xbar, ubar, cost=None, status=None, iters=None):
+        """One SQP-RTI step for every instance, in place on xbar/ubar (device tensors).  Asynchronous."""
+        N = self.N
+        B = x0.shape[0]
+        self._chk(x0, (B, NX)); self._chk(yref, (B, N, NY)); self._chk(yref_e, (B, NX)); self._chk(p, (B,))
+        self._chk(xbar, (B, N + 1, NX)); self._chk(ubar, (B, N, NU))
+        if cost is not None: self._chk(cost, (B,))
+        if status is not None: self._chk(status, (B,), torch.int32)
+        if iters is not None: self._chk(iters, (B,), torch.int32)
+        _lib.check(self.lib.admpc_solve_batch(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p), _ptr(xbar), _ptr(ubar),
+                                              _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
+
+    def solve_numpy(self, x0, yref, yref_e, p, xbar, ubar):
+        """Convenience for tests / the single-instance shims: host arrays in, host arrays out
+        (x, u, cost, status, iters)."""
+        d = self.to_device
+        x0 = np.asarray(x0, dtype=np.float64).reshape(-1, NX)
+        B, N = x0.shape[0], self.N
+        tx0 = d(x0); tyr = d(np.asarray(yref, dtype=np.float64).reshape(B, N, NY)); tye = d(np.asarray(yref_e, dtype=np.float64).reshape(B, NX))
+        tp = d(np.asarray(p, dtype=np.float64).reshape(B))
+        tx = d(np.asarray(xbar, dtype=np.float64).reshape(B, N + 1, NX)).clone(); tu = d(np.asarray(ubar, dtype=np.float64).reshape(B, N, NU)).clone()
+        cost = torch.empty(B, dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        iters = torch.empty(B, dtype=torch.int32, device=self.device)
+        self.solve(tx0, tyr, tye, tp, tx, tu, cost, status, iters)
+        torch.cuda.synchronize(self.device)
+        return tx.cpu().numpy(), tu.cpu().numpy(), cost.cpu().numpy(), status.cpu().numpy(), iters.cpu().numpy()
+
+    def shoot(self, xbar, ubar, p):
+        """H1 only: phi [B,N,7], A [B,N,7,7], B [B,N,7,2] (device tensors)."""
+        N = self.N
+        B = xbar.shape[0]
+        self._chk(xbar, (B, N + 1, NX)); self._chk(ubar, (B, N, NU)); self._chk(p, (B,))
+        phi = torch.empty((B, N, NX), dtype=torch.float64, device=self.device)
+        A = torch.empty((B, N, NX, NX), dtype=torch.float64, device=self.device)
+        Bm = torch.empty((B, N, NX, NU), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.admpc_shoot_batch(self._h, B, _ptr(xbar), _ptr(ubar), _ptr(p), _ptr(phi), _ptr(A), _ptr(Bm), self._stream()))
+        return phi, A, Bm
+
+    def argmin(self, cost, index_offset=0):
+        """Local arg-min over a device cost vector -> (val tensor[1], idx tensor[1] int64), ties -> lowest index."""
+        B = cost.shape[0]
+        self._chk(cost, (B,))
+        val = torch.empty(1, dtype=torch.float64, device=self.device)
+        idx = torch.empty(1, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.admpc_argmin(self._h, _ptr(cost), B, int(index_offset), _ptr(val), _ptr(idx), self._stream()))
+        return val, idx
+
+    def epilogue(self, xopt, uopt, xref_xy):
+        """Validity bit + Ackermann record per instance."""
+        N = self.N
+        B = xopt.shape[0]
+        self._chk(xopt, (B, N + 1, NX)); self._chk(uopt, (B, N, NU)); self._chk(xref_xy, (B, N + 1, 2))
+        ack = torch.empty((B, 4), dtype=torch.float32, device=self.device)
+        valid = torch.empty(B, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.admpc_epilogue_batch(self._h, B, _ptr(xopt), _ptr(uopt), _ptr(xref_xy), _ptr(ack), _ptr(valid), self._stream()))
+        return ack, valid

@@ -427,7 +427,15 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
     const real thr = c->ipm_thr0, mu0 = c->ipm_mu0;
     /* cold start (qp_solver_warm_start 0, sim_car_acados_ocp.json:885): zero step, slacks at thr */
     memset(s, 0, sizeof *s);
+    /* primal start: zero input step, states rolled out through the linearised dynamics, so every
+     * iterate satisfies dx[k+1] = A dx[k] + B du[k] + b up to rounding */
     for (int i = 0; i < NX; ++i) s->dx[0][i] = qp->dx0[i];
+    for (int k = 0; k < N; ++k)
+        for (int i = 0; i < NX; ++i) {
+            real a = qp->b[k][i];
+            for (int l = 0; l < NX; ++l) a += qp->A[k][i][l] * s->dx[k][l];
+            s->dx[k + 1][i] = a;
+        }
     for (int k = 0; k < N; ++k) {
         for (int j = 0; j < NU; ++j) {
             s->sl[k][j] = thr; s->su[k][j] = thr;
@@ -436,7 +444,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         }
         s->td[k][0] = s->td[k][1] = 1;
         if (k >= 1) {
-            real r0[2] = { -qp->dld[k], qp->dud[k] };
+            real r0[2] = { s->dx[k][6] - qp->dld[k], qp->dud[k] - s->dx[k][6] };
             for (int i = 0; i < 2; ++i) { s->td[k][i] = r0[i] > thr ? r0[i] : thr; s->lamd[k][i] = mu0 / s->td[k][i]; }
         }
     }
