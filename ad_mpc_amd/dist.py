@@ -1,0 +1,49 @@
+"""Multi-GPU layer: scenario sharding and the one collective of the path (the final arg-min).
+
+Instances are independent: rank r owns the contiguous global index range
+[r*B/W, (r+1)*B/W) and solves it locally with no data-path collective.  The only exchange is the
+16-byte (cost, global index) pair per rank, all-gathered over RCCL (backend "nccl" on ROCm) or gloo
+in the CPU tests, followed by a local scan.  Tie-break: lowest global index; NaN never wins.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous shard [lo, hi) of `total` instances for `rank` of `world` (remainder spread over the first ranks)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def pick_min(vals, idxs):
+    """arg-min over (value, index) pairs with the path's tie-break rules; returns 0-dim tensors."""
+    vals = torch.where(torch.isnan(vals), torch.full_like(vals, float("inf")), vals)
+    m = vals.min()
+    cand = torch.where(vals == m, idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
+    return m, cand.min()
+
+
+def local_argmin_torch(cost, index_offset=0):
+    """Host-side (torch) equivalent of admpc_argmin used by the gloo CPU tests of the N>1 path."""
+    idxs = torch.arange(cost.shape[0], dtype=torch.int64, device=cost.device) + int(index_offset)
+    v, i = pick_min(cost, idxs)
+    return v.reshape(1), i.reshape(1)
+
+
+def global_argmin(val, idx, group=None):
+    """Combine per-rank (val[1] f64, idx[1] i64) pairs: all-gather 16 B per rank, local scan.
+    Every rank returns the same (value, global index)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return val.reshape(()), idx.reshape(())
+    world = dist.get_world_size(group)
+    mine = torch.cat([val.reshape(1).to(torch.float64), idx.reshape(1).to(torch.int64).view(torch.float64)])
+    out = torch.empty(2 * world, dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    pairs = out.view(world, 2)
+    vals = pairs[:, 0].contiguous()
+    idxs = pairs[:, 1].contiguous().view(torch.int64)
+    return pick_min(vals, idxs)

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: MPC solves/s of the batched SQP-RTI step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (admpc_solve_batch: shooting + QP + full step for every
+instance) over one batch of synthetic scenarios that is already resident in HBM.  Every step starts
+from the same initial iterate (pre-staged copies), so all steps do identical work.  Workload at
+N=1 = BASELINE.json configs[1]: batch 4096 random (x0, curved reference) scenarios, horizon N=20,
+fp64.  With more GPUs every rank solves its own 4096-instance shard (weak scaling, no data-path
+collective) and the step ends with the RCCL arg-min over the scenario costs.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ad_mpc_amd.config import default_config, set_gp, NX, NU, NY  # noqa: E402
+from ad_mpc_amd.engine import BatchSolver  # noqa: E402
+from ad_mpc_amd.scenarios import random_scenarios, grid_gp  # noqa: E402
+from ad_mpc_amd import dist as adist  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector = matrix peak (AMD datasheet)
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_solve(N):
+    """in x0 + yref + yref_e + iterate + p ; out iterate + cost + status(4 B)."""
+    n_in = NX + (N * NY + NX) + ((N + 1) * NX + N * NU) + 1
+    n_out = (N + 1) * NX + N * NU + 1
+    return 8 * (n_in + n_out) + 4
+
+
+def algorithmic_flops_per_solve(N, mean_ipm_iters):
+    """shooting N*4360 + N*1900 per interior-point iteration (measured mean iterations)."""
+    return N * 4360.0 + N * 1900.0 * mean_ipm_iters
+
+
+def cpu_baseline(cfg, scen, target_seconds=12.0):
+    """Time the CPU oracle (OpenMP build of oracle/admpc_oracle.c) on the same workload, bounded sample."""
+    from oracle.oracle import Oracle, build
+    build(omp=True)
+    o = Oracle(omp=True)
+    nthreads = o.max_threads()
+    B = scen["x0"].shape[0]
+    # single-thread probe on 256 instances to size the sample
+    nprobe = min(256, B)
+    t = time.perf_counter()
+    o.solve_batch(cfg, scen["x0"][:nprobe], scen["yref"][:nprobe], scen["yref_e"][:nprobe], scen["p"][:nprobe],
+                  scen["xbar"][:nprobe], scen["ubar"][:nprobe], nthreads=1)
+    t1 = (time.perf_counter() - t) / nprobe
+    reps = max(1, int(round(target_seconds / (t1 * B))))       # ~target_seconds of total CPU work
+    t = time.perf_counter()
+    for _ in range(reps):
+        o.solve_batch(cfg, scen["x0"], scen["yref"], scen["yref_e"], scen["p"], scen["xbar"], scen["ubar"], nthreads=nthreads)
+    dt = time.perf_counter() - t
+    return {"value": reps * B / dt, "unit": "solves/s", "cores": nthreads, "kind": "port",
+            "sample": "%d x the same %d-instance batch (N=%d, fp64) on %d OpenMP threads; single-thread rate %.0f solves/s"
+                      % (reps, B, cfg.N, nthreads, 1.0 / t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--gp", action="store_true", help="config 3: GP residual dynamics active")
+    ap.add_argument("--dynamic", action="store_true", help="blend speeds 3/5 m/s so that the dynamic bicycle branch is active")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev_index = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+
+    N, B, K, Wm = args.horizon, args.batch_per_gpu, args.steps, args.warmup
+    cfg = default_config(N=N, Ts=0.05)
+    if args.gp:
+        set_gp(cfg, grid_gp())
+    blend = (3.0, 5.0) if args.dynamic else (100.0, 110.0)
+    scen = random_scenarios(B, N=N, Ts=0.05, seed=1234, start=rank * B, blend=blend)
+    eng = BatchSolver(cfg, device=dev_index)
+    d = eng.to_device
+    x0, yref, yref_e, p = d(scen["x0"]), d(scen["yref"]), d(scen["yref_e"]), d(scen["p"])
+    xinit, uinit = d(scen["xbar"]), d(scen["ubar"])
+    # one pre-staged iterate per step: every step starts from the same initial iterate
+    xb = [xinit.clone() for _ in range(K + Wm)]
+    ub = [uinit.clone() for _ in range(K + Wm)]
+    cost = torch.empty(B, dtype=torch.float64, device=eng.device)
+    status = torch.empty(B, dtype=torch.int32, device=eng.device)
+    iters = torch.empty(B, dtype=torch.int32, device=eng.device)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+
+    def step(i, timed_idx=None):
+        if timed_idx is not None: ev0[timed_idx].record()
+        eng.solve(x0, yref, yref_e, p, xb[i], ub[i], cost, status, iters)
+        if timed_idx is not None: ev1[timed_idx].record()
+        if world > 1:
+            v, ix = eng.argmin(cost, index_offset=rank * B)
+            return adist.global_argmin(v, ix)
+        return None
+
+    for i in range(Wm):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    best = None
+    for i in range(K):
+        best = step(Wm + i, i)
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    it_host = iters.cpu().numpy(); st_host = status.cpu().numpy()
+    mean_iters = float(it_host.mean())
+    if rank == 0:
+        total = world * B * K
+        value = total / elapsed
+        flops = algorithmic_flops_per_solve(N, mean_iters) * B
+        byts = algorithmic_bytes_per_solve(N) * B
+        ach_tf = flops / (kern_ms * 1e-3) / 1e12
+        ach_gbs = byts / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MPC solves/sec (N=%d, nx=7, nu=2, fp64)" % N, "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch %d/GPU random (x0, curved ref) scenarios, N=%d, fp64, one SQP-RTI step%s%s"
+                                   % (B, N, ", GP residual active" if args.gp else "", ", dynamic branch (blend 3/5)" if args.dynamic else ""),
+                       "batch_per_gpu": B, "horizon": N, "seed": 1234,
+                       "collective": "RCCL all-gather arg-min (16 B/rank)" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "admpc_solve_kernel", "kernel_ms": kern_ms,
+                         "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*mean_ipm_iters per solve (SURVEY 8d)"},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                             "bytes_per_solve": algorithmic_bytes_per_solve(N)},
+            "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
+        }
+        if best is not None:
+            out["argmin"] = {"cost": float(best[0].item()), "index": int(best[1].item())}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, scen)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
