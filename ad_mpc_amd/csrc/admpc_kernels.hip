@@ -688,14 +688,23 @@ __global__ __launch_bounds__(WAVE) void admpc_solve_kernel(const AdmpcConfig* __
             bool failed;
             iters = ipm_solve<UPL>(cfg, L, N, lane, U, D, Qd, Rd, Qe, rho_l, rho_u, failed);
             // ---- H6: full step
-            bool bad = failed;
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) { double v = L.xs[i] + L.dx[i]; if (!(fabs(v) <= 1e300)) bad = true; L.xs[i] = v; }
+            bool bad = failed;        // a non-finite step is a QP failure: leave the iterate untouched
+            for (int i = lane; i < (N + 1) * NX; i += WAVE) { double v = L.xs[i] + L.dx[i]; if (!(fabs(v) <= 1e300)) bad = true; }
 #pragma unroll
             for (int m = 0; m < UPL; ++m) {
                 const int sid = lane + WAVE * m;
-                if (sid < 2 * N) { double v = L.us[sid] + U[m].du; if (!(fabs(v) <= 1e300)) bad = true; L.us[sid] = v; }
+                if (sid < 2 * N) { double v = L.us[sid] + U[m].du; if (!(fabs(v) <= 1e300)) bad = true; }
             }
-            if (__any(bad)) status = ADMPC_STATUS_QP_FAILURE;
+            if (__any(bad)) {
+                status = ADMPC_STATUS_QP_FAILURE;
+            } else {
+                for (int i = lane; i < (N + 1) * NX; i += WAVE) L.xs[i] += L.dx[i];
+#pragma unroll
+                for (int m = 0; m < UPL; ++m) {
+                    const int sid = lane + WAVE * m;
+                    if (sid < 2 * N) L.us[sid] += U[m].du;
+                }
+            }
             WSYNC();
         }
         // ---- write back, cost

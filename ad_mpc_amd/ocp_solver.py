@@ -1,0 +1,126 @@
+"""``AcadosOcpSolver``-shaped adapter over the batch engine (narrow seam of SURVEY 8b).
+
+The reference stores an ``acados_template.AcadosOcpSolver`` at ad_3d_optimizer.py:209 and drives it
+with ``set(stage, field, value)`` (:330-331,:430,:438,:441-442,:450), ``solve()`` (:456) and
+``get(stage, field)`` (:462-465).  This class offers exactly those calls for ONE instance and runs
+the solve on the GPU through admpc_solve_batch (B = 1).  Like the acados object it owns a persistent
+iterate (initially all zeros, acados_solver_sim_car.c:705-731) that is never shifted or reset.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from .config import NX, NU, NY
+from .engine import BatchSolver
+
+
+class AdmpcOcpSolver:
+    def __init__(self, cfg, device=0):
+        self._eng = BatchSolver(cfg, device=device)
+        self.N = N = self._eng.N
+        self._yref = np.zeros((N, NY))
+        self._yref_e = np.zeros(NX)
+        self._lbx0 = np.zeros(NX)
+        self._ubx0 = np.zeros(NX)
+        self._p = np.zeros(N + 1)
+        self._x = np.zeros((N + 1, NX))          # persistent iterate
+        self._u = np.zeros((N, NU))
+        self._status = 0
+        self._qp_iter = 0
+        self._cost = float("nan")
+
+    # ---- acados-style setters / getters -------------------------------------------------------
+    def set(self, stage_, field_, value_):
+        value = np.asarray(value_, dtype=np.float64).reshape(-1)
+        N = self.N
+        if not isinstance(stage_, (int, np.integer)) or not (0 <= stage_ <= N):
+            raise Exception("AdmpcOcpSolver.set(): stage index must be an integer in [0, %d], got %r" % (N, stage_))
+
+        def need(n):
+            if value.shape[0] != n:
+                raise Exception("AdmpcOcpSolver.set(): mismatching dimension for field \"%s\" with dimension %d (you have %d)"
+                                % (field_, n, value.shape[0]))
+        if field_ == "yref":
+            if stage_ < N:
+                need(NY); self._yref[stage_] = value
+            else:
+                need(NX); self._yref_e[:] = value
+        elif field_ in ("lbx", "ubx"):
+            if stage_ != 0:
+                raise Exception("AdmpcOcpSolver.set(): \"%s\" is only settable at stage 0 (initial state)" % field_)
+            need(NX)
+            (self._lbx0 if field_ == "lbx" else self._ubx0)[:] = value
+        elif field_ == "p":
+            need(1); self._p[stage_] = value[0]
+        elif field_ == "x":
+            need(NX); self._x[stage_] = value
+        elif field_ == "u":
+            if stage_ >= N:
+                raise Exception("AdmpcOcpSolver.set(): no input at the terminal stage")
+            need(NU); self._u[stage_] = value
+        else:
+            raise Exception("AdmpcOcpSolver.set(): \"%s\" is not a valid argument. Possible values are "
+                            "['yref', 'lbx', 'ubx', 'p', 'x', 'u']" % field_)
+
+    def get(self, stage_, field_):
+        N = self.N
+        if not isinstance(stage_, (int, np.integer)) or not (0 <= stage_ <= N):
+            raise Exception("AdmpcOcpSolver.get(): stage index must be an integer in [0, %d], got %r" % (N, stage_))
+        if field_ == "x":
+            return self._x[stage_].copy()
+        if field_ == "u":
+            if stage_ >= N:
+                raise Exception("AdmpcOcpSolver.get(): no input at the terminal stage")
+            return self._u[stage_].copy()
+        raise Exception("AdmpcOcpSolver.get(): \"%s\" is not a valid argument. Possible values are ['x', 'u']" % field_)
+
+    def get_stats(self, field_):
+        if field_ == "qp_iter":
+            return self._qp_iter
+        if field_ == "status":
+            return self._status
+        raise Exception("AdmpcOcpSolver.get_stats(): unknown field %r" % field_)
+
+    def get_cost(self):
+        return self._cost
+
+    # ---- solve --------------------------------------------------------------------------------
+    def solve(self):
+        """One SQP_RTI step (or cfg.sqp_iters full steps); returns the acados-style status int."""
+        if not np.array_equal(self._lbx0, self._ubx0):
+            raise Exception("AdmpcOcpSolver.solve(): stage-0 lbx and ubx must both equal the measured state")
+        if not np.all(self._p == self._p[0]):
+            raise Exception("AdmpcOcpSolver.solve(): the blend parameter p must be the same on all stages")
+        x, u, cost, st, it = self._eng.solve_numpy(self._lbx0[None], self._yref[None], self._yref_e[None],
+                                                   np.array([self._p[0]]), self._x[None], self._u[None])
+        if st[0] == 0:          # acados leaves the iterate untouched only if the QP failed outright
+            self._x, self._u = x[0], u[0]
+        self._status, self._qp_iter, self._cost = int(st[0]), int(it[0]), float(cost[0])
+        return self._status
+
+    # ---- iterate snapshots (acados store_iterate / load_iterate JSON format, e.g. sim_car_iterate.json)
+    def store_iterate(self, filename="", overwrite=False):
+        if filename == "":
+            filename = "admpc_iterate.json"
+        if not overwrite and os.path.isfile(filename):
+            raise Exception("AdmpcOcpSolver.store_iterate(): file %s exists (use overwrite=True)" % filename)
+        d = {}
+        for k in range(self.N + 1):
+            d["x_%d" % k] = self._x[k].tolist()
+            d["u_%d" % k] = self._u[k].tolist() if k < self.N else []
+            for f in ("pi", "lam", "t", "sl", "su", "z"):
+                d["%s_%d" % (f, k)] = []
+        with open(filename, "w") as f:
+            json.dump(d, f, indent=4, sort_keys=True)
+
+    def load_iterate(self, filename):
+        if not os.path.isfile(filename):
+            raise Exception("AdmpcOcpSolver.load_iterate(): file %s does not exist" % filename)
+        with open(filename) as f:
+            d = json.load(f)
+        for k in range(self.N + 1):
+            self.set(k, "x", d["x_%d" % k])
+            if k < self.N:
+                self.set(k, "u", d["u_%d" % k])

@@ -559,9 +559,12 @@ static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const 
             for (int l = 0; l < NU; ++l) a += qp->B[k][i][l] * W->st.du[k][l];
             W->dx[k + 1][i] = a;
         }
-    int bad = 0;
-    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real v = (real)xbar[k * NX + i] + W->dx[k][i]; if (!(v == v) || R_FABS(v) > 1e300) bad = 1; xbar[k * NX + i] = (double)v; }
-    for (int k = 0; k < N; ++k) for (int j = 0; j < NU; ++j) { real v = (real)ubar[k * NU + j] + W->st.du[k][j]; if (!(v == v) || R_FABS(v) > 1e300) bad = 1; ubar[k * NU + j] = (double)v; }
+    int bad = 0;      /* a non-finite step is a QP failure: the iterate is left untouched (acados returns before the update) */
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real v = (real)xbar[k * NX + i] + W->dx[k][i]; if (!(R_FABS(v) <= 1e300)) bad = 1; }
+    for (int k = 0; k < N; ++k) for (int j = 0; j < NU; ++j) { real v = (real)ubar[k * NU + j] + W->st.du[k][j]; if (!(R_FABS(v) <= 1e300)) bad = 1; }
+    if (bad) return ADMPC_STATUS_QP_FAILURE;
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) xbar[k * NX + i] = (double)((real)xbar[k * NX + i] + W->dx[k][i]);
+    for (int k = 0; k < N; ++k) for (int j = 0; j < NU; ++j) ubar[k * NU + j] = (double)((real)ubar[k * NU + j] + W->st.du[k][j]);
     return bad ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
 }
 

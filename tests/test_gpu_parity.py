@@ -1,0 +1,205 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libadmpc.so), against the CPU oracle on
+identical seeded inputs, against the committed golden fixtures, and through size-independent properties
+at BASELINE's full batch size.
+
+Stated fp64 tolerance: |u - u_oracle|, |x - x_oracle| <= 1e-8 absolute (measured ~1e-12); shooting
+quantities <= 1e-11 relative.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from ad_mpc_amd.config import default_config, set_gp, AdmpcConfig  # noqa: E402
+from ad_mpc_amd.scenarios import random_scenarios, straight_scenario, assemble, grid_gp  # noqa: E402
+
+TOL = 1e-8
+
+
+def _solve_both(eng, oracle, cfg, s):
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    return g, o
+
+
+def _assert_parity(g, o, tol=TOL):
+    x, u, cost, st, it = g; xo, uo, co, so, io = o
+    np.testing.assert_array_equal(st, so)
+    ok = so == 0
+    assert np.abs(u[ok] - uo[ok]).max(initial=0.0) <= tol, np.abs(u[ok] - uo[ok]).max()
+    assert np.abs(x[ok] - xo[ok]).max(initial=0.0) <= tol, np.abs(x[ok] - xo[ok]).max()
+    np.testing.assert_allclose(cost[ok], co[ok], rtol=1e-9, atol=1e-9)
+    assert np.abs(it - io).max(initial=0) <= 1          # same algorithm: at most one borderline extra iteration
+
+
+def test_shooting_against_reference_golden_vectors(gpu_engine_factory, golden_shooting):
+    """H0/H1 on the GPU against vectors from the reference's compiled CasADi code."""
+    import torch
+    cases = golden_shooting["cases"]
+    cfg = default_config(N=2, Ts=cases[0]["h"])
+    eng = gpu_engine_factory(cfg)
+    B = len(cases)
+    xbar = np.zeros((B, 3, 7)); ubar = np.zeros((B, 2, 2)); p = np.zeros(B)
+    for b, c in enumerate(cases):
+        xbar[b, 0] = c["x"]; xbar[b, 1] = c["x"]; ubar[b, 0] = c["u"]; ubar[b, 1] = c["u"]; p[b] = c["p"]
+    phi, A, Bm = eng.shoot(eng.to_device(xbar), eng.to_device(ubar), eng.to_device(p))
+    torch.cuda.synchronize()
+    phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
+    for b, c in enumerate(cases):
+        for k in (0, 1):
+            np.testing.assert_allclose(phi[b, k], np.array(c["phi"]), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(A[b, k], np.array(c["A"]), rtol=1e-11, atol=1e-13)
+            np.testing.assert_allclose(Bm[b, k], np.array(c["B"]), rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("N,B,blend,init", [
+    (20, 256, (100.0, 110.0), "x0"), (20, 256, (3.0, 5.0), "x0"), (20, 64, (100.0, 110.0), "zeros"),
+    (40, 64, (3.0, 5.0), "x0"), (32, 16, (3.0, 5.0), "x0"), (33, 16, (3.0, 5.0), "x0"), (64, 8, (100.0, 110.0), "x0"),
+    (2, 8, (3.0, 5.0), "x0"), (5, 1, (3.0, 5.0), "x0"),
+])
+def test_solve_parity_with_oracle(gpu_engine_factory, oracle, N, B, blend, init):
+    cfg = default_config(N=N)
+    s = random_scenarios(B, N=N, seed=1234, blend=blend, init=init)
+    g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+    assert (o[3] == 0).all()
+    _assert_parity(g, o)
+
+
+def test_full_size_batch_4096(gpu_engine_factory, oracle):
+    """BASELINE configs[1] at full size: direct parity for every instance plus size-independent properties."""
+    cfg = default_config(N=20)
+    s = random_scenarios(4096, N=20, seed=1234)
+    eng = gpu_engine_factory(cfg)
+    g, o = _solve_both(eng, oracle, cfg, s)
+    assert (g[3] == 0).all()
+    _assert_parity(g, o)
+    x, u = g[0], g[1]
+    # property 1: x_0 is pinned to the measured state; steering stays inside its hard bound on stages 1..N-1
+    np.testing.assert_array_equal(x[:, 0, :], s["x0"])
+    assert np.abs(x[:, 1:20, 6]).max() <= 0.52 + 1e-8
+    # property 2: the step reduces the objective of the (already feasible) initial iterate? not guaranteed for RTI;
+    # instead: idempotence at convergence -- after 30 more full SQP steps one further RTI step is a no-op
+    cfg2 = cfg.copy(); cfg2.sqp_iters = 30
+    eng2 = gpu_engine_factory(cfg2)
+    xc, uc, cc, sc, _ = eng2.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], x, u)
+    ok = sc == 0
+    assert ok.all()
+    x1, u1, c1, s1, _ = eng.solve_numpy(s["x0"][ok], s["yref"][ok], s["yref_e"][ok], s["p"][ok], xc[ok], uc[ok])
+    conv = np.abs(u1 - uc[ok]).reshape(ok.sum(), -1).max(1)
+    assert conv.max() < 1e-6 and np.quantile(conv, 0.99) < 1e-8
+    # property 3: a converged iterate satisfies the nonlinear dynamics (multiple-shooting gaps closed)
+    import torch
+    phi, _, _ = eng.shoot(eng.to_device(x1), eng.to_device(u1), eng.to_device(s["p"][ok]))
+    torch.cuda.synchronize()
+    gaps = np.abs(phi.cpu().numpy() - x1[:, 1:, :]).reshape(ok.sum(), -1).max(1)
+    assert gaps.max() < 1e-6 and np.quantile(gaps, 0.99) < 1e-8
+
+
+def test_kat_acados_iterate_on_gpu(gpu_engine_factory, golden_kat):
+    """Solver pin on the GPU: the reference's converged acados iterate is a fixed point of one RTI step and the
+    limit of a cold-started SQP."""
+    k = golden_kat
+    N = k["N"]
+    cfg = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"])
+    X, U = np.array(k["X"]), np.array(k["U"])
+    x0, yref, ye = np.array(k["x0"]), np.array(k["yref"]), np.array(k["yref_e"])
+    eng = gpu_engine_factory(cfg)
+    x, u, cost, st, it = eng.solve_numpy(x0[None], yref[None], ye[None], np.array([0.0]), X[None], U[None])
+    assert st[0] == 0 and np.abs(u[0] - U).max() < 1e-8 and np.abs(x[0] - X).max() < 1e-8
+    assert abs(cost[0] - 11.5810534473) < 1e-8
+    cfg2 = cfg.copy(); cfg2.sqp_iters = 15
+    x, u, cost, st, it = gpu_engine_factory(cfg2).solve_numpy(x0[None], yref[None], ye[None], np.array([0.0]),
+                                                              np.zeros((1, N + 1, 7)), np.zeros((1, N, 2)))
+    assert st[0] == 0 and np.abs(u[0] - U).max() < 1e-8 and np.abs(x[0] - X).max() < 1e-8
+
+
+def test_gp_residual_config3(gpu_engine_factory, oracle):
+    cfg = default_config(N=20); set_gp(cfg, grid_gp())
+    s = random_scenarios(256, N=20, seed=1234, blend=(3.0, 5.0))
+    g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+    _assert_parity(g, o)
+    base = oracle.solve_batch(default_config(N=20), s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert np.abs(base[1] - o[1]).max() > 1e-3       # the GP really changes the answer
+
+
+def test_active_slack_and_steering_bound(gpu_engine_factory, oracle):
+    cfg = default_config()
+    x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
+    rows = []
+    for y, d0, v in [(-10.0, 0.5, 3.0), (6.0, 0.5, 14.0), (4.0, -0.5, 6.0), (-6.0, 0.5, 14.0), (0.0, 0.6, 5.0), (0.0, -0.7, 9.0)]:
+        x = x0.copy(); x[1] = y; x[6] = d0; x[3] = v; rows.append(x)
+    X0 = np.array(rows); B = len(rows)
+    s = assemble(X0, np.repeat(xref[None], B, 0), np.repeat(uref[None], B, 0))
+    g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+    _assert_parity(g, o)
+    assert (g[1][:, :, 0] > 5.0 + 1.0).any()                       # soft bound violated through the slack
+    assert np.abs(g[0][:, 1:20, 6]).max() <= 0.52 + 1e-8           # hard bound respected, even from an infeasible x0
+
+
+def test_failure_status_and_untouched_iterate(gpu_engine_factory, oracle):
+    cfg = default_config()
+    s = random_scenarios(8, seed=3, blend=(3.0, 5.0), init="zeros")
+    g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+    np.testing.assert_array_equal(g[3], o[3])
+    bad = g[3] != 0
+    assert bad.any() and (g[3][bad] == 4).all() and np.isinf(g[2][bad]).all()
+    np.testing.assert_array_equal(g[0][bad], s["xbar"][bad]); np.testing.assert_array_equal(g[1][bad], s["ubar"][bad])
+
+
+def test_empty_batch_and_argument_errors(gpu_engine_factory):
+    import torch
+    from ad_mpc_amd import _lib
+    cfg = default_config()
+    eng = gpu_engine_factory(cfg)
+    L = eng.lib
+    z = C.c_void_p(0)
+    assert L.admpc_solve_batch(eng._h, 0, z, z, z, z, z, z, z, z, z, z) == 0            # B = 0 is a no-op
+    assert L.admpc_solve_batch(eng._h, 4, z, z, z, z, z, z, z, z, z, z) == -1           # null arrays -> EINVAL
+    assert b"null" in L.admpc_last_error()
+    assert L.admpc_solve_batch(eng._h, -1, z, z, z, z, z, z, z, z, z, z) == -1
+    bad = cfg.copy(); bad.N = 1
+    h = C.c_void_p(0)
+    assert L.admpc_create(C.byref(bad), 0, C.byref(h)) == -1
+    bad = cfg.copy(); bad.n_gp = 1; bad.gp[0].out = 0; bad.gp[0].feat = 3
+    assert L.admpc_create(C.byref(bad), 0, C.byref(h)) == -1
+    assert L.admpc_create(C.byref(cfg), 99, C.byref(h)) == -2                           # no such device
+    with pytest.raises(ValueError):
+        eng.solve(torch.zeros(3, 7), torch.zeros(3, 20, 9), torch.zeros(3, 7), torch.zeros(3), torch.zeros(3, 21, 7), torch.zeros(3, 20, 2))
+
+
+def test_argmin_kernel(gpu_engine_factory):
+    import torch
+    eng = gpu_engine_factory(default_config())
+    rng = np.random.default_rng(0)
+    for B in (1, 2, 63, 64, 255, 256, 257, 4096, 8192):
+        c = rng.uniform(0, 100, B)
+        if B > 4:
+            c[B // 2] = c.min(); c[1] = np.nan; c[3] = np.inf         # tie with a later index, NaN, inf
+        v, i = eng.argmin(eng.to_device(c), index_offset=1000)
+        torch.cuda.synchronize()
+        cc = np.where(np.isnan(c), np.inf, c)
+        assert v.item() == cc.min() and i.item() == 1000 + int(np.argmin(cc))
+    v, i = eng.argmin(eng.to_device(np.array([np.inf, np.nan])), 7)
+    assert math.isinf(v.item()) and i.item() == 7
+
+
+def test_epilogue_kernel_matches_host_logic(gpu_engine_factory):
+    import torch
+    from ad_mpc_amd import host
+    cfg = default_config()
+    eng = gpu_engine_factory(cfg)
+    s = random_scenarios(64, seed=5)
+    x, u, *_ = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    x[3, :, 1] += 30.0; x[7, 4, 0] += 30.0          # make two instances invalid
+    ref = s["xref"][:, :, :2].copy()
+    ack, valid = eng.epilogue(eng.to_device(x), eng.to_device(u), eng.to_device(ref))
+    torch.cuda.synchronize()
+    ack, valid = ack.cpu().numpy(), valid.cpu().numpy()
+    for b in range(64):
+        assert bool(valid[b]) == host.is_valid_command(x[b], s["xref"][b])
+        exp = np.array(host.ackermann_fields(x[b], u[b].reshape(-1)), dtype=np.float32)
+        np.testing.assert_array_equal(ack[b], exp)
+    assert not valid[3] and not valid[7] and 0 < valid.sum() < 64

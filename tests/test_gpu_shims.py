@@ -1,0 +1,102 @@
+"""The reference's Python surface (AD3DMPC.set_reference/optimize, ROSGPMPC.optimize, the AcadosOcpSolver-shaped
+seam) running on the HIP engine; BASELINE configs[0] (single vehicle, straight path) and the quirks of SURVEY 8b."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from ad_mpc_amd.config import default_config, Q_DIAG_ROS, R_DIAG_ROS  # noqa: E402
+from ad_mpc_amd.scenarios import straight_scenario, assemble  # noqa: E402
+
+
+def _ros_cfg(N=20, T=1.0):
+    return default_config(N=N, Ts=T / N, q=Q_DIAG_ROS, r=R_DIAG_ROS)
+
+
+def test_config1_through_the_ros_surface(oracle):
+    from ad_mpc_amd.create_ros_ad_mpc import ROSGPMPC
+    mpc = ROSGPMPC(t_horizon=1.0, n_mpc_nodes=20, opt_dt=0.01)
+    x0, xref, uref = straight_scenario(N=20, Ts=0.05, v=5.0)
+    x0 = x0.copy(); x0[1] = 0.4; x0[2] = 0.05                       # small lateral / heading error
+    mpc.set_state(list(x0))
+    # the node passes N reference rows and N-1 input rows (gp_ad_mpc_node.py:180-187); padding happens inside
+    mpc.set_reference(xref[:20].copy(), uref[:19].copy())
+    msg, w_opt, x_opt, status = mpc.optimize(0)
+    assert status == 0 and w_opt.shape == (40,) and x_opt.shape == (21, 7)
+    # oracle on the same inputs: padded reference (last row repeated), zero initial iterate, p = 0
+    xr = np.vstack([xref[:20], xref[19:20]]); ur = np.vstack([uref[:19], uref[18:19]])
+    s = assemble(x0[None], xr[None], ur[None], init="zeros")
+    xo, uo, co, so, io = oracle.solve_batch(_ros_cfg(), s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert np.abs(w_opt - uo[0].reshape(-1)).max() < 1e-8 and np.abs(x_opt - xo[0]).max() < 1e-8
+    d = msg.drive
+    assert d.steering_angle == np.float32(x_opt[0, 6]) and d.steering_angle_velocity == np.float32(w_opt[1])
+    assert d.speed == np.float32(x_opt[0, 3]) and d.acceleration == np.float32(w_opt[0])
+    # second call: the solver keeps its iterate (never shifted, never reset) -> equals a second oracle step
+    msg2, w2, x2, st2 = mpc.optimize(0)
+    xo2, uo2, *_ = oracle.solve_batch(_ros_cfg(), s["x0"], s["yref"], s["yref_e"], s["p"], xo, uo)
+    assert np.abs(w2 - uo2[0].reshape(-1)).max() < 1e-8
+
+
+def test_optimizer_defaults_padding_and_fallback(oracle):
+    from ad_mpc_amd.ad_3d import AD3D
+    from ad_mpc_amd.ad_3d_mpc import AD3DMPC
+    ad = AD3D()
+    mpc = AD3DMPC(ad)                                     # optimizer-level default weights q=[10,10,50,0,0,0,1]
+    assert list(mpc.ad_opt.ocp_config.W[:]) == [10, 10, 50, 0, 0, 0, 1, 1, 100]
+    x0, xref, uref = straight_scenario()
+    ad.set_state(list(x0))
+    mpc.set_reference(xref[:5].copy(), uref[:4].copy())   # short reference -> padded to N+1 / N+... rows
+    assert mpc.ad_opt.target.shape == (21, 7)
+    w = mpc.optimize()
+    assert w.shape == (40,) and np.isfinite(w).all() and w[0] < -1.0    # the padded (stopping) reference makes the MPC brake
+    # make the prediction invalid (reference 50 m away): falls back to the previous inputs, 2N-1 long
+    far = xref.copy(); far[:, 1] += 50.0
+    mpc.set_reference(far, uref.copy())
+    w2, x2, st = mpc.optimize(return_x=True)
+    assert w2.shape == (39,)
+    np.testing.assert_array_equal(w2, np.concatenate((w[2:-1], w[-3:-1])))
+    # terminal yaw reference is fixed IN PLACE on the stored target (view semantics of the reference)
+    ad.set_state([0, 0, -3.0, 5, 0, 0, 0])
+    tgt = xref.copy(); tgt[:, 2] = 3.0
+    mpc.set_reference(tgt, uref.copy())
+    mpc.optimize()
+    assert mpc.ad_opt.target[20, 2] == pytest.approx(3.0 - 2 * np.pi) and mpc.ad_opt.target[0, 2] == 3.0
+
+
+def test_acados_shaped_seam_errors_and_iterate_io(tmp_path, golden_kat):
+    from ad_mpc_amd.ocp_solver import AdmpcOcpSolver
+    k = golden_kat
+    cfg = default_config(N=k["N"], Ts=k["Ts"], terminal_scale=k["terminal_scale"])
+    sol = AdmpcOcpSolver(cfg)
+    with pytest.raises(Exception, match="mismatching dimension"):
+        sol.set(0, "yref", np.zeros(7))
+    with pytest.raises(Exception, match="not a valid argument"):
+        sol.set(0, "foo", np.zeros(7))
+    with pytest.raises(Exception):
+        sol.get(41, "x")
+    # load the reference-format iterate (same keys as sim_car_iterate.json), solve once, store, reload
+    it = {}
+    for i in range(k["N"] + 1):
+        it["x_%d" % i] = k["X"][i]; it["u_%d" % i] = k["U"][i] if i < k["N"] else []
+    f = tmp_path / "iterate.json"; f.write_text(json.dumps(it))
+    sol.load_iterate(str(f))
+    for j in range(k["N"]):
+        sol.set(j, "yref", np.array(k["yref"][j]))
+    sol.set(k["N"], "yref", np.array(k["yref_e"]))
+    sol.set(0, "lbx", np.array(k["x0"])); sol.set(0, "ubx", np.array(k["x0"]))
+    for j in range(k["N"] + 1):
+        sol.set(j, "p", np.array([0.0]))
+    assert sol.solve() == 0
+    U = np.array([sol.get(i, "u") for i in range(k["N"])])
+    assert np.abs(U - np.array(k["U"])).max() < 1e-8
+    g = tmp_path / "out.json"
+    sol.store_iterate(str(g))
+    d = json.loads(g.read_text())
+    assert np.allclose(d["u_0"], U[0]) and "lam_0" in d and "x_40" in d
+    with pytest.raises(Exception):
+        sol.store_iterate(str(g))                        # exists, overwrite=False
+    sol.set(1, "p", np.array([0.5]))
+    with pytest.raises(Exception, match="same on all stages"):
+        sol.solve()

@@ -1,0 +1,108 @@
+"""Oracle pin 2 (solver known-answer test) and independent optimality checks of the QP solve."""
+import numpy as np
+import pytest
+
+from ad_mpc_amd.config import default_config, set_gp
+from ad_mpc_amd.scenarios import random_scenarios, straight_scenario, assemble, grid_gp
+from kkt_check import kkt_residuals
+
+KAT_TOL = 1e-8          # the fixture itself is only consistent to ~4e-10 (recovered u_ref), SURVEY 8c
+
+
+def _kat_inputs(k):
+    cfg = default_config(N=k["N"], Ts=k["Ts"], terminal_scale=k["terminal_scale"])
+    return cfg, np.array(k["x0"]), np.array(k["yref"]), np.array(k["yref_e"]), np.array(k["X"]), np.array(k["U"])
+
+
+def test_kat_fixture_is_a_fixed_point_of_one_rti_step(oracle, golden_kat):
+    """Starting ONE RTI step at the converged acados iterate of the reference must return it."""
+    cfg, x0, yref, ye, X, U = _kat_inputs(golden_kat)
+    x, u, cost, st, it = oracle.solve_batch(cfg, x0[None], yref[None], ye[None], np.array([golden_kat["p"]]), X[None], U[None])
+    assert st[0] == 0
+    assert np.abs(u[0] - U).max() < KAT_TOL
+    assert np.abs(x[0] - X).max() < KAT_TOL
+    assert abs(cost[0] - 11.5810534473) < 1e-8       # objective value found independently in SURVEY 8c
+
+
+def test_kat_cold_start_sqp_converges_to_the_acados_iterate(oracle, golden_kat):
+    cfg, x0, yref, ye, X, U = _kat_inputs(golden_kat)
+    cfg.sqp_iters = 15
+    N = cfg.N
+    x, u, cost, st, it = oracle.solve_batch(cfg, x0[None], yref[None], ye[None], np.array([0.0]), np.zeros((1, N + 1, 7)), np.zeros((1, N, 2)))
+    assert st[0] == 0
+    assert np.abs(u[0] - U).max() < KAT_TOL
+    assert np.abs(x[0] - X).max() < KAT_TOL
+    # active set of the fixture: acceleration at its upper bound on the first stages, steering interior
+    assert abs(u[0, 0, 0] - 5.0) < 1e-7 and np.abs(x[0, :, 6]).max() < 0.52
+
+
+@pytest.mark.parametrize("blend,init", [((100.0, 110.0), "x0"), ((3.0, 5.0), "x0"), ((100.0, 110.0), "zeros")])
+def test_qp_solution_satisfies_kkt_conditions(oracle, blend, init):
+    """Strictly convex QP => KKT residuals ~0 prove the returned step is THE minimiser, independently of the IPM."""
+    cfg = default_config()
+    s = random_scenarios(120, seed=99, blend=blend, init=init)
+    worst = {}
+    for i in range(120):
+        d = oracle.qp_debug(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], s["p"][i], s["xbar"][i], s["ubar"][i])
+        assert d["status"] == 0 and d["iters"] < cfg.ipm_iter_max
+        r = kkt_residuals(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], s["xbar"][i], s["ubar"][i], d)
+        for k, v in r.items():
+            worst[k] = max(worst.get(k, 0.0), float(v))
+    assert worst["x0"] == 0.0 and worst["dyn"] < 1e-12
+    assert worst["stat_u"] < 1e-8 and worst["stat_s"] < 1e-8
+    assert worst["prim"] < 1e-10 and worst["dual"] == 0.0 and worst["comp"] < 1e-9
+
+
+def test_slack_and_steering_bounds_are_exercised(oracle):
+    """Far-off reference + steering near its limit: soft input bounds are violated (slack active, multiplier = Ts*zl)
+    and the hard steering bound becomes active."""
+    cfg = default_config()
+    x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
+    x0 = x0.copy(); x0[1] = -10.0; x0[6] = 0.5; x0[3] = 3.0       # 10 m lateral error, steering almost saturated, too slow
+    s = assemble(x0[None], xref[None], uref[None])
+    d = oracle.qp_debug(cfg, s["x0"][0], s["yref"][0], s["yref_e"][0], s["p"][0], s["xbar"][0], s["ubar"][0])
+    r = kkt_residuals(cfg, s["x0"][0], s["yref"][0], s["yref_e"][0], s["xbar"][0], s["ubar"][0], d)
+    assert max(r["stat_u"], r["stat_s"], r["comp"]) < 1e-8 and r["prim"] < 1e-10
+    u_new = s["ubar"][0] + d["du"]
+    assert (u_new[:, 0] > cfg.ubu[0] + 1.0).any(), "expected a violated soft acceleration bound"
+    assert np.isclose(d["lam_u"][:, :, :2].max(), cfg.Ts * cfg.zl, atol=1e-8)       # multiplier capped at the L1 weight
+    x_new = s["xbar"][0] + d["dx"]
+    assert np.abs(x_new[1:cfg.N, 6]).max() <= 0.52 + 1e-8
+    assert d["lam_d"].max() > 1e-3, "expected an active steering bound"
+
+
+def test_config1_straight_path_is_stationary(oracle):
+    """BASELINE configs[0]: vehicle on the straight reference at reference speed -> the solver keeps u = 0."""
+    cfg = default_config()
+    x0, xref, uref = straight_scenario()
+    s = assemble(x0[None], xref[None], uref[None], init="zeros")
+    cfg.sqp_iters = 10
+    x, u, cost, st, it = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert st[0] == 0 and np.abs(u).max() < 1e-9 and cost[0] < 1e-15
+    np.testing.assert_allclose(x[0, :, 0], 5.0 * 0.05 * np.arange(21), atol=1e-9)
+
+
+def test_gp_residual_changes_the_dynamics_consistently(oracle):
+    """Config 3 mechanism: f = f_nom + B_x mu(z); Jacobian picks up dmu/dz (finite-difference check)."""
+    cfg = default_config(); set_gp(cfg, grid_gp())
+    base = default_config()
+    x = np.array([0.0, 0.0, 0.3, 7.0, 0.1, -0.05, 0.1]); u = np.array([0.5, 0.2])
+    f0, f1 = oracle.f(base, x, u, 0.0), oracle.f(cfg, x, u, 0.0)
+    assert np.abs(f1[3:6] - f0[3:6]).max() > 1e-3 and np.array_equal(f1[[0, 1, 2, 6]], f0[[0, 1, 2, 6]])
+    Jx, Ju = oracle.jac(cfg, x, u, 0.0)
+    for j in (3, 4, 5):
+        e = np.zeros(7); e[j] = 1e-6
+        fd = (oracle.f(cfg, x + e, u, 0.0) - oracle.f(cfg, x - e, u, 0.0)) / 2e-6
+        np.testing.assert_allclose(Jx[:, j], fd, rtol=1e-6, atol=1e-6)
+
+
+def test_zero_iterate_with_dynamic_branch_reports_qp_failure(oracle):
+    """v_x = 0 in the iterate and p > 0: the model divides by v_x + 1e-99 (ad_3d_optimizer.py:290-297) and the
+    linearisation overflows; the solve must flag status 4, leave the iterate untouched and return cost = +inf."""
+    cfg = default_config()
+    s = random_scenarios(4, seed=3, blend=(3.0, 5.0), init="zeros")
+    assert (s["p"] > 0).any()
+    x, u, cost, st, it = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    bad = s["p"] > 0
+    assert (st[bad] == 4).all() and np.isinf(cost[bad]).all()
+    assert np.array_equal(x[bad], s["xbar"][bad]) and np.array_equal(u[bad], s["ubar"][bad])
