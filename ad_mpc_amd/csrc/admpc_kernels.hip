@@ -142,12 +142,20 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     const int ngp = c->n_gp;
     for (int g = 0; g < ngp; ++g) {          // residual GPs: out in {3,4,5}, feat in {3..8} (validated on the host)
         const AdmpcGp& gp = c->gp[g];
-        const int feat = gp.feat, out = gp.out - 3;
-        double z = feat < NX ? x[feat] : u[feat - NX];
+        const int feat = gp.feat - 3, out = gp.out - 3;          // feat: 0..3 -> (vx,vy,r,delta), 4..5 -> (u0,u1)
+        // static indexing only: runtime-indexed private arrays would live in scratch memory
+        const double z = feat == 0 ? vx : feat == 1 ? vy : feat == 2 ? r : feat == 3 ? dl : feat == 4 ? u[0] : u[1];
         double mu, dmu;
         gp_eval(gp, z, mu, dmu);
-        e.f[3 + out] += mu;
-        if (feat < NX) e.a[out][feat - 3] += dmu; else e.bu[out][feat - NX] += dmu;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const bool so = out == o;
+            e.f[3 + o] += so ? mu : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && feat == cc) ? dmu : 0.0;
+            e.bu[o][0] += (so && feat == 4) ? dmu : 0.0;
+            e.bu[o][1] += (so && feat == 5) ? dmu : 0.0;
+        }
     }
 }
 
@@ -160,7 +168,7 @@ __device__ __forceinline__ void sens_rhs(const ModelEval& e, const double* s, in
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         double a = e.a[r][0] * s[3] + e.a[r][1] * s[4] + e.a[r][2] * s[5] + e.a[r][3] * s[6];
-        if (ucol >= 0) a += e.bu[r][ucol];
+        a += ucol == 0 ? e.bu[r][0] : (ucol == 1 ? e.bu[r][1] : 0.0);
         d[3 + r] = a;
     }
     d[6] = ucol == 1 ? 1.0 : 0.0;
