@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmpc.so")
 
 EXPORTS = (
-    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_solve_batch", "admpc_shoot_batch",
+    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_shoot_batch",
     "admpc_argmin", "admpc_epilogue_batch", "admpc_last_error", "admpc_version",
 )
 
@@ -37,6 +37,7 @@ def load():
     L.admpc_default_config.argtypes = [cp, C.c_int, C.c_double]; L.admpc_default_config.restype = C.c_int
     L.admpc_create.argtypes = [cp, C.c_int, C.POINTER(C.c_void_p)]; L.admpc_create.restype = C.c_int
     L.admpc_destroy.argtypes = [C.c_void_p]; L.admpc_destroy.restype = None
+    L.admpc_reserve.argtypes = [C.c_void_p, C.c_int]; L.admpc_reserve.restype = C.c_int
     L.admpc_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     L.admpc_solve_batch.restype = C.c_int
     L.admpc_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, vp]; L.admpc_shoot_batch.restype = C.c_int

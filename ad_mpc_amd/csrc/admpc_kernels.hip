@@ -1,7 +1,11 @@
 // admpc_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched AD-MPC solve engine.
 //
-// One MPC instance per 64-lane wavefront (workgroup = 1 wave); all per-stage data of the
-// instance lives in LDS; the per-constraint interior-point state lives in registers.
+// Two kernels per SQP step:
+//   A  admpc_linearize_kernel  one thread per (instance, stage, sensitivity-column group): ERK4 + forward
+//                              sensitivities, writes the packed stage linearisation (42+7 doubles per stage)
+//   B  admpc_qp_kernel         one MPC instance per 64-lane wavefront (workgroup = 1 wave): all per-stage data
+//                              of the instance lives in LDS (~20 KB at N=20 -> 8 instances per CU), the
+//                              per-constraint interior-point state lives in registers.
 //
 // Hot path restated (reference = data_driven_mpc/ros_gp_mpc/src/ad_mpc/...):
 //   H0/H1  model + ERK4 with forward sensitivities   ad_3d_optimizer.py:280-310, acados ERK
@@ -26,46 +30,9 @@
 #define NU ADMPC_NU
 #define NY ADMPC_NY
 #define WAVE 64
-#define GS 63            // doubles per stage of G = [A|B] (7x9 row-major); odd stride -> conflict-free stage-parallel reads
-#define PS 49            // doubles per stage of P (7x7)
-#define KS 15            // doubles per stage of K (2x7) padded to odd
 #define IPM_FLOOR 1e-40
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------
-// wave-wide reductions (xor butterfly: every lane ends with the bitwise identical result)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
-// NaN-propagating max of |v| (fmax would drop NaNs)
-__device__ __forceinline__ double absmax_nan(double acc, double v) {
-    double a = fabs(v);
-    return (a > acc || a != a) ? a : acc;
-}
-__device__ __forceinline__ double wave_max_nan(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, WAVE); v = (w > v || w != w) ? w : v; }
-    return v;
-}
-__device__ __forceinline__ double uniform(double v) {   // make a wave-uniform value provably uniform (SGPR)
-    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
 
 // ---------------------------------------------------------------------------------------------
 // model: f and the non-zero pattern of its Jacobians (ad_3d_optimizer.py:280-310)
@@ -226,402 +193,325 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS map of one instance (offsets in doubles)
+// kernel A: shooting + linearisation, one thread per (instance, stage, column group).
+// Output, instance-major and packed exactly as kernel B keeps it in LDS:
+//   GTg [B][N][7][6]  stored columns c=0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each column.
+//                     Not stored because they are structural for this model (delta' = u1, positions
+//                     do not feed back): A[:,0]=e0, A[:,1]=e1, row 6 of [A B] = [e6, 0, h].
+//   blg [B][N][7]     defect b_k = phi(xbar_k,ubar_k) - xbar_{k+1}
 // ---------------------------------------------------------------------------------------------
-struct Lds {
-    double *G, *P, *K, *Li, *bl, *q, *r, *dx, *pi, *gx, *gu, *pv, *kff, *ddx, *ddu, *Rt, *Qt, *lamd, *Ms, *Hux, *Huu;
-    double *xs, *us, *yr, *ye, *x0;
-};
-__host__ __device__ inline int lds_doubles(int N) {
-    return N * GS + (N + 1) * PS + N * KS + N * 3 + N * 7 + (N + 1) * 7 + N * 2 + (N + 1) * 7 + N * 7 + (N + 1) * 7 + N * 2 +
-           (N + 1) * 7 + N * 2 + (N + 1) * 7 + N * 2 + N * 2 + N + N * 2 + 64 + 14 + 4 +
-           (N + 1) * 7 + N * 2 + N * 9 + 7 + 7;
+#define GTS 42           // doubles per stage of the packed linearisation
+#define PKS 28           // packed symmetric 7x7
+#define KLS 17           // K0[7] K1[7] i00 i01 i11
+
+__global__ __launch_bounds__(256) void admpc_linearize_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                              const double* __restrict__ xbarg, const double* __restrict__ ubarg,
+                                                              const double* __restrict__ pg, const int32_t* __restrict__ skip,
+                                                              double* __restrict__ GTg, double* __restrict__ blg)
+{
+    const int N = cfg->N;
+    const long total = (long)B * N * 3;
+    for (long tsk = (long)blockIdx.x * blockDim.x + threadIdx.x; tsk < total; tsk += (long)gridDim.x * blockDim.x) {
+        const long sk = tsk / 3; const int g = (int)(tsk % 3);
+        const long inst = sk / N; const int k = (int)(sk % N);
+        if (skip && skip[inst] != 0) continue;
+        double x[NX], u[NU], phi[NX], col[3][NX];
+        const double* xs = xbarg + (inst * (N + 1) + k) * NX;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xs[i];
+        u[0] = ubarg[(inst * N + k) * NU]; u[1] = ubarg[(inst * N + k) * NU + 1];
+        rk4_group(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
+        double* GT = GTg + sk * GTS;
+        const int c0 = g == 0 ? 0 : (g == 1 ? 3 : 5);
+        const int nc = g == 0 ? 3 : 2;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            if (cc < nc)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) GT[(c0 + cc) * 6 + i] = col[cc][i];
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) blg[sk * NX + i] = phi[i] - xs[NX + i];
+        }
+    }
 }
-__device__ __forceinline__ void lds_carve(double* base, int N, Lds& L) {
-    double* p = base;
-    L.G = p; p += N * GS;        L.P = p; p += (N + 1) * PS;  L.K = p; p += N * KS;       L.Li = p; p += N * 3;
-    L.bl = p; p += N * 7;        L.q = p; p += (N + 1) * 7;   L.r = p; p += N * 2;        L.dx = p; p += (N + 1) * 7;
-    L.pi = p; p += N * 7;        L.gx = p; p += (N + 1) * 7;  L.gu = p; p += N * 2;       L.pv = p; p += (N + 1) * 7;
-    L.kff = p; p += N * 2;       L.ddx = p; p += (N + 1) * 7; L.ddu = p; p += N * 2;      L.Rt = p; p += N * 2;
-    L.Qt = p; p += N;            L.lamd = p; p += N * 2;      L.Ms = p; p += 64;          L.Hux = p; p += 14;
-    L.Huu = p; p += 4;
-    L.xs = p; p += (N + 1) * 7;  L.us = p; p += N * 2;        L.yr = p; p += N * 9;       L.ye = p; p += 7;  L.x0 = p; p += 7;
+
+// ---------------------------------------------------------------------------------------------
+// wave-level primitives
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rdlane(double v, int l) {        // l must be wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double ident, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+struct OpSum { static __device__ __forceinline__ double id() { return 0.0; } static __device__ __forceinline__ double f(double a, double b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ double id() { return -INFINITY; } static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); } };
+// NaN-propagating max for residual norms
+struct OpMaxNan { static __device__ __forceinline__ double id() { return -INFINITY; }
+                  static __device__ __forceinline__ double f(double a, double b) { return (b > a || b != b) ? b : a; } };
+// DPP scan: after the six steps lane 63 holds the reduction of all 64 lanes; returned wave-uniform.
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v) {
+    v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));   // row_shr:1
+    v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));   // row_shr:2
+    v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));   // row_shr:4
+    v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));   // row_shr:8   -> lane 15 of every row = row total
+    v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));   // row_bcast:15 into rows 1,3
+    v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));   // row_bcast:31 into rows 2,3
+    return rdlane(v, 63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel B: the QP of one RTI step, one instance per wavefront.
+// LDS map (doubles): see lds2_doubles(); per-stage arrays of the instance + three transients.
+// ---------------------------------------------------------------------------------------------
+struct Lds2 {
+    double *GT;    // [N][7][6]   packed linearisation
+    double *Pk;    // [N][28]     packed symmetric P_k, k = 1..N at slot k-1
+    double *KL;    // [N][17]     feedback gains + inverse of Huu
+    double *pi;    // [N][7]      multipliers of the dynamics
+    double *gx;    // [N][7]      state stationarity residual / modified gradient of stage k = 1..N at slot k-1
+    double *pv;    // [N][7]      Riccati gradient p_k, k = 1..N at slot k-1
+    double *ddx;   // [N][7]      Newton step ddx_k, k = 1..N at slot k-1 (ddx_0 = 0); also b_k during the start-up roll-out
+    double *guk;   // [N][2]      gu -> kff -> ddu (each overwrites the previous in place)
+    double *Rt;    // [N][2]
+    double *Qt;    // [N]
+    double *Pf;    // [7][8]      transient: full P_{k+1}
+    double *MT;    // [7][8]      transient: (P_{k+1} [A B])^T, stored columns
+    double *Hs;    // [81]        transient: 9x9 stage Hessian
+    double *hs;    // [10]        transient: 9 stage gradient entries
+    double *pvs;   // [8]         transient: p_{k+1}
+};
+// Hs/hs/pvs (100 doubles) are only live inside the factor sweep, when the ddx slots are dead: aliased if they fit
+__host__ __device__ inline int lds2_doubles(int N) { return N * (GTS + PKS + KLS + 7 * 4 + 2 + 2 + 1) + 56 + 56 + (N * 7 >= 100 ? 0 : 100); }
+__device__ __forceinline__ void lds2_carve(double* p, int N, Lds2& L) {
+    L.GT = p; p += N * GTS;  L.Pk = p; p += N * PKS;  L.Pf = p; p += 56;  L.MT = p; p += 56;
+    L.KL = p; p += N * KLS;  L.pi = p; p += N * 7;    L.gx = p; p += N * 7;  L.pv = p; p += N * 7;  L.ddx = p; p += N * 7;
+    L.guk = p; p += N * 2;   L.Rt = p; p += N * 2;    L.Qt = p; p += N;
+    double* tr = N * 7 >= 100 ? L.ddx : p;
+    L.Hs = tr; L.hs = tr + 82; L.pvs = tr + 92;
 }
 
 #define WSYNC() __syncthreads()
 
-// ---------------------------------------------------------------------------------------------
-// Riccati: matrices (backward), vectors (backward), roll-out (forward)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void riccati_factor(const Lds& L, int N, int lane, const double* Qd, const double* Qe)
+__device__ __forceinline__ int tri_index(int i, int j) {   // packed index of (i<=j) in a 7x7 upper triangle, row-major
+    return i * 7 - (i * (i - 1)) / 2 + (j - i);
+}
+
+// select a[i] with constant indices only (runtime-indexed private arrays would be placed in scratch memory)
+__device__ __forceinline__ double sel7(const double* a, int i) {
+    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : i == 4 ? a[4] : i == 5 ? a[5] : a[6];
+}
+
+struct Roles {       // stage-independent lane roles of the Riccati factorisation
+    int i1, c1;      // L1: M^T[c1][i1], lanes < 49
+    double r6_1;     // implicit row 6 of stored column c1
+    int r2, c2;      // L2: unique entry (r2 <= c2) of the 9x9 H, lanes < 45
+    int altoff;      // L2: offset of the copied value when r2 < 2 (relative to Pf if c2 < 2 else MT)
+    double r6_2;
+    int i3, j3;      // L3: P entry, lanes < 49
+    int pkoff;       // packed offset of (i3,j3) if i3 <= j3 else -1
+    double qd2;      // L2: constant state weight on the diagonal entry (r2 == c2 < 7)
+    double qe3;      // terminal weight of the diagonal entry (i3 == j3), else 0
+};
+
+__device__ __forceinline__ double r6_of(int c, double h) { return c == 4 ? 1.0 : (c == 6 ? h : 0.0); }
+
+__device__ __forceinline__ void make_roles(int lane, double h, const double* Qd, const double* Qe, Roles& R) {
+    R.i1 = lane / 7; R.c1 = lane % 7;
+    if (lane >= 49) { R.i1 = 0; R.c1 = 0; }
+    R.r6_1 = r6_of(R.c1, h);
+    int t = lane < 45 ? lane : 0, r = 0;
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) { const int len = 9 - rr; if (t >= len && r == rr) { t -= len; r = rr + 1; } }
+    R.r2 = r; R.c2 = r + t;
+    R.altoff = R.c2 < 2 ? R.r2 * 8 + R.c2 : (R.c2 - 2) * 8 + R.r2;
+    R.r6_2 = r6_of(R.r2 >= 2 ? R.r2 - 2 : 0, h);
+    R.i3 = R.i1; R.j3 = lane < 49 ? lane % 7 : 0;
+    R.pkoff = (lane < 49 && R.i3 <= R.j3) ? tri_index(R.i3, R.j3) : -1;
+    R.qd2 = sel7(Qd, R.r2 < 7 ? R.r2 : 0);
+    R.qe3 = R.i3 == R.j3 ? sel7(Qe, R.i3) : 0.0;
+}
+
+// Backward Riccati sweep for the matrices, fused with the backward sweep of the gradient for the
+// predictor right-hand side (gx, guk=gu).  Leaves Pk, KL, pv, kff (in guk).
+__device__ __forceinline__ void riccati_factor_fused(const Lds2& L, int N, int lane, const Roles& R)
 {
-    if (lane < PS) { int i = lane / 7, j = lane % 7; L.P[N * PS + lane] = (i == j) ? Qe[i] : 0.0; }
+    if (lane < 49) L.Pf[R.i3 * 8 + R.j3] = R.qe3;
+    if (lane < NX) L.pvs[lane] = L.gx[(N - 1) * 7 + lane];
+    if (lane < 49 && R.pkoff >= 0) L.Pk[(N - 1) * PKS + R.pkoff] = R.qe3;
+    if (lane < NX) L.pv[(N - 1) * 7 + lane] = L.gx[(N - 1) * 7 + lane];
     WSYNC();
-    const int i1 = lane / 9, j1 = lane % 9;         // L1: M = P+ * G  (7x9)
-    const int a2 = lane / 7, j2 = lane % 7;         // L2: H[a][j] = G[:,a]' M[:,j]  (9x7), L3: P entry (a2,j2) for lane<49
-    const int ua = (lane >> 1) & 1, ub = lane & 1;  // Huu entry computed redundantly
     for (int k = N - 1; k >= 0; --k) {
-        const double* G = L.G + k * GS;
-        const double* Pn = L.P + (k + 1) * PS;
-        if (lane < 63) {
-            double m = 0.0;
-#pragma unroll
-            for (int l = 0; l < NX; ++l) m += Pn[i1 * 7 + l] * G[l * 9 + j1];
-            L.Ms[lane] = m;
-        }
-        WSYNC();
-        double hxx = 0.0;
-        if (lane < 63) {
-            double hv = 0.0;
-#pragma unroll
-            for (int l = 0; l < NX; ++l) hv += G[l * 9 + a2] * L.Ms[l * 9 + j2];
-            if (a2 == j2) hv += (a2 == 6 && k >= 1) ? L.Qt[k] : Qd[a2];
-            if (a2 >= NX) L.Hux[(a2 - NX) * 7 + j2] = hv; else hxx = hv;
-        }
+        const double* GT = L.GT + k * GTS;
+        // ---- L1: M^T[c][i] = P+[i][:] . G[:,c]   (+ gradient h for the fused predictor sweep)
         {
-            double hu = 0.0;
+            const double* prow = L.Pf + R.i1 * 8;
+            const double* gcol = GT + R.c1 * 6;
+            double m = prow[6] * R.r6_1;
 #pragma unroll
-            for (int l = 0; l < NX; ++l) hu += G[l * 9 + 7 + ua] * L.Ms[l * 9 + 7 + ub];
-            if (ua == ub) hu += L.Rt[k * 2 + ua];
-            if (lane < 4) L.Huu[lane] = hu;
-        }
-        WSYNC();
-        {
-            const double h00 = L.Huu[0], h01 = L.Huu[1], h11 = L.Huu[3];
-            const double det = h00 * h11 - h01 * h01;
-            const double idet = 1.0 / det;
-            const double i00 = h11 * idet, i01 = -h01 * idet, i11 = h00 * idet;
-            if (lane < PS) {
-                const double h0i = L.Hux[a2], h1i = L.Hux[7 + a2], h0j = L.Hux[j2], h1j = L.Hux[7 + j2];
-                const double K0 = -(i00 * h0j + i01 * h1j), K1 = -(i01 * h0j + i11 * h1j);
-                L.P[k * PS + lane] = hxx + h0i * K0 + h1i * K1;
-                if (a2 == 0) { L.K[k * KS + j2] = K0; L.K[k * KS + 7 + j2] = K1; }
+            for (int l = 0; l < 6; ++l) m += prow[l] * gcol[l];
+            if (lane < 49) L.MT[R.c1 * 8 + R.i1] = m;
+            // h: lanes 0..6 -> entry c+2 (their own stored column), lanes 49,50 -> entries 0,1
+            double hv = L.pvs[6] * R.r6_1;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) hv += gcol[l] * L.pvs[l];
+            if (lane < 7) {
+                const double g = lane < 5 ? (k >= 1 ? L.gx[(k - 1) * 7 + lane + 2] : 0.0) : L.guk[k * 2 + lane - 5];
+                L.hs[lane + 2] = hv + g;
+            } else if (lane == 49 || lane == 50) {
+                const int a = lane - 49;
+                L.hs[a] = (k >= 1 ? L.gx[(k - 1) * 7 + a] : 0.0) + L.pvs[a];
             }
-            if (lane == 0) { L.Li[k * 3 + 0] = i00; L.Li[k * 3 + 1] = i01; L.Li[k * 3 + 2] = i11; }
+        }
+        WSYNC();
+        // ---- L2: unique entries of H = [A B]' M + diag
+        if (lane < 45) {
+            const int rc = R.r2 >= 2 ? R.r2 - 2 : 0, cc = R.c2 >= 2 ? R.c2 - 2 : 0;
+            const double* gcol = GT + rc * 6;
+            const double* mcol = L.MT + cc * 8;
+            double hv = mcol[6] * R.r6_2;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) hv += gcol[l] * mcol[l];
+            const double alt = (R.c2 < 2 ? L.Pf : L.MT)[R.altoff];
+            if (R.r2 < 2) hv = alt;
+            if (R.r2 == R.c2) {
+                double dg;
+                if (R.r2 < 7) dg = (R.r2 == 6 && k >= 1) ? L.Qt[k] : R.qd2;
+                else dg = L.Rt[k * 2 + R.r2 - 7];
+                hv += dg;
+            }
+            L.Hs[R.r2 * 9 + R.c2] = hv;
+            L.Hs[R.c2 * 9 + R.r2] = hv;
+        }
+        WSYNC();
+        // ---- L3: Schur complement, gains, gradient
+        {
+            const double h00 = L.Hs[70], h01 = L.Hs[71], h11 = L.Hs[80];
+            const double idet = 1.0 / (h00 * h11 - h01 * h01);
+            const double i00 = h11 * idet, i01 = -h01 * idet, i11 = h00 * idet;
+            const double hu0 = L.hs[7], hu1 = L.hs[8];
+            if (lane < 49) {
+                const double h0i = L.Hs[63 + R.i3], h1i = L.Hs[72 + R.i3], h0j = L.Hs[63 + R.j3], h1j = L.Hs[72 + R.j3];
+                // symmetric evaluation of Hxu Huu^-1 Hux (bitwise identical for (i,j) and (j,i))
+                const double cross = __dadd_rn(__dmul_rn(h0i, h1j), __dmul_rn(h1i, h0j));
+                const double s = __dadd_rn(__dadd_rn(__dmul_rn(i00, __dmul_rn(h0i, h0j)), __dmul_rn(i01, cross)), __dmul_rn(i11, __dmul_rn(h1i, h1j)));
+                const double pij = L.Hs[R.i3 * 9 + R.j3] - s;
+                L.Pf[R.i3 * 8 + R.j3] = pij;
+                if (R.pkoff >= 0 && k >= 1) L.Pk[(k - 1) * PKS + R.pkoff] = pij;
+                if (R.i3 == 0) {
+                    const double K0 = -(i00 * h0j + i01 * h1j), K1 = -(i01 * h0j + i11 * h1j);
+                    L.KL[k * KLS + R.j3] = K0; L.KL[k * KLS + 7 + R.j3] = K1;
+                    const double pvk = L.hs[R.j3] + K0 * hu0 + K1 * hu1;
+                    L.pvs[R.j3] = pvk;
+                    if (k >= 1) L.pv[(k - 1) * 7 + R.j3] = pvk;
+                }
+            }
+            if (lane == 63) {
+                L.KL[k * KLS + 14] = i00; L.KL[k * KLS + 15] = i01; L.KL[k * KLS + 16] = i11;
+                L.guk[k * 2 + 0] = -(i00 * hu0 + i01 * hu1);
+                L.guk[k * 2 + 1] = -(i01 * hu0 + i11 * hu1);
+            }
         }
         WSYNC();
     }
 }
 
-// backward sweep of the gradient (pv) and feed-forward (kff); the dynamics residual of the Newton
-// system is identically zero because every IPM iterate satisfies the linearised dynamics.
-__device__ __forceinline__ void riccati_backward(const Lds& L, int N, int lane)
+// Backward sweep of the gradient alone (corrector right-hand side); p_k travels in registers of lanes 0..6.
+__device__ __forceinline__ void riccati_backward2(const Lds2& L, int N, int lane, double h)
 {
-    if (lane < NX) L.pv[N * 7 + lane] = L.gx[N * 7 + lane];
-    WSYNC();
+    double pvv = lane < NX ? L.gx[(N - 1) * 7 + lane] : 0.0;
+    if (lane < NX) L.pv[(N - 1) * 7 + lane] = pvv;
+    const int c = lane >= 2 && lane < 9 ? lane - 2 : 0;       // lanes 2..8 own stored column c, lanes 0,1 the unit columns
+    const double r6 = r6_of(c, h);
     for (int k = N - 1; k >= 0; --k) {
-        const double* G = L.G + k * GS;
-        const double* pn = L.pv + (k + 1) * 7;
-        double h = 0.0;
-        if (lane < NY) {
-            h = lane < NX ? L.gx[k * 7 + lane] : L.gu[k * 2 + lane - NX];
-#pragma unroll
-            for (int l = 0; l < NX; ++l) h += G[l * 9 + lane] * pn[l];
+        const double* gcol = L.GT + k * GTS + c * 6;
+        double g = 0.0;
+        if (lane < 7) g = k >= 1 ? L.gx[(k - 1) * 7 + lane] : 0.0; else if (lane < 9) g = L.guk[k * 2 + lane - 7];
+        const double K0 = lane < 7 ? L.KL[k * KLS + lane] : 0.0, K1 = lane < 7 ? L.KL[k * KLS + 7 + lane] : 0.0;
+        const double i00 = L.KL[k * KLS + 14], i01 = L.KL[k * KLS + 15], i11 = L.KL[k * KLS + 16];
+        const double g0 = gcol[0], g1 = gcol[1], g2 = gcol[2], g3 = gcol[3], g4 = gcol[4], g5 = gcol[5];
+        const double p0 = rdlane(pvv, 0), p1 = rdlane(pvv, 1), p2 = rdlane(pvv, 2), p3 = rdlane(pvv, 3),
+                     p4 = rdlane(pvv, 4), p5 = rdlane(pvv, 5), p6 = rdlane(pvv, 6);
+        double hv = g + (g0 * p0 + g1 * p1) + (g2 * p2 + g3 * p3) + (g4 * p4 + g5 * p5) + r6 * p6;
+        if (lane < 2) hv = g + (lane == 0 ? p0 : p1);
+        const double hu0 = rdlane(hv, 7), hu1 = rdlane(hv, 8);
+        pvv = lane < NX ? hv + K0 * hu0 + K1 * hu1 : 0.0;
+        if (lane < NX && k >= 1) L.pv[(k - 1) * 7 + lane] = pvv;
+        if (lane == 63) {
+            L.guk[k * 2 + 0] = -(i00 * hu0 + i01 * hu1);
+            L.guk[k * 2 + 1] = -(i01 * hu0 + i11 * hu1);
         }
-        const double hu0 = __shfl(h, 7, WAVE), hu1 = __shfl(h, 8, WAVE);
-        if (lane < NX) L.pv[k * 7 + lane] = h + L.K[k * KS + lane] * hu0 + L.K[k * KS + 7 + lane] * hu1;
-        if (lane == 0) {
-            const double i00 = L.Li[k * 3], i01 = L.Li[k * 3 + 1], i11 = L.Li[k * 3 + 2];
-            L.kff[k * 2 + 0] = -(i00 * hu0 + i01 * hu1);
-            L.kff[k * 2 + 1] = -(i01 * hu0 + i11 * hu1);
-        }
-        WSYNC();
     }
 }
 
-__device__ __forceinline__ void riccati_forward(const Lds& L, int N, int lane)
+// Forward roll-out of the Newton step: ddu_k = K_k ddx_k + kff_k, ddx_{k+1} = A ddx_k + B ddu_k (+ b_k at start-up).
+// ddx travels in registers of lanes 0..6.  WITH_B: start-up roll-out with du = 0 (writes dx into pv slots).
+template <bool STARTUP>
+__device__ __forceinline__ void riccati_forward2(const Lds2& L, int N, int lane, double h, double dx0)
 {
-    if (lane < NX) L.ddx[lane] = 0.0;
-    WSYNC();
+    double dxv = STARTUP ? dx0 : 0.0;           // lanes 0..6
+    const int li = lane < 6 ? lane : 0;
     for (int k = 0; k < N; ++k) {
-        const double* G = L.G + k * GS;
-        const double* xk = L.ddx + k * 7;
-        double du = 0.0;
-        if (lane < NU) {
-            du = L.kff[k * 2 + lane];
-#pragma unroll
-            for (int l = 0; l < NX; ++l) du += L.K[k * KS + lane * 7 + l] * xk[l];
-            L.ddu[k * 2 + lane] = du;
+        const double* GT = L.GT + k * GTS;
+        const double a2 = GT[0 * 6 + li], a3 = GT[1 * 6 + li], a4 = GT[2 * 6 + li], a5 = GT[3 * 6 + li], a6 = GT[4 * 6 + li];
+        const double d0 = rdlane(dxv, 0), d1 = rdlane(dxv, 1), d2 = rdlane(dxv, 2), d3 = rdlane(dxv, 3),
+                     d4 = rdlane(dxv, 4), d5 = rdlane(dxv, 5), d6 = rdlane(dxv, 6);
+        double part = (a2 * d2 + a3 * d3) + (a4 * d4 + a5 * d5) + a6 * d6;
+        part += lane == 0 ? d0 : (lane == 1 ? d1 : 0.0);
+        if (STARTUP) {
+            const double bk = lane < NX ? L.ddx[k * 7 + lane] : 0.0;
+            dxv = lane < 6 ? part + bk : (lane == 6 ? d6 + bk : 0.0);
+            if (lane < NX) L.pv[k * 7 + lane] = dxv;            // dx_{k+1}
+        } else {
+            const double b0 = GT[5 * 6 + li], b1 = GT[6 * 6 + li];
+            double du = 0.0;
+            if (lane < 2) {
+                const double* Kr = L.KL + k * KLS + lane * 7;
+                du = L.guk[k * 2 + lane] + (Kr[0] * d0 + Kr[1] * d1) + (Kr[2] * d2 + Kr[3] * d3) + (Kr[4] * d4 + Kr[5] * d5) + Kr[6] * d6;
+            }
+            const double du0 = rdlane(du, 0), du1 = rdlane(du, 1);
+            if (lane < 2) L.guk[k * 2 + lane] = du;              // ddu_k overwrites kff_k
+            dxv = lane < 6 ? part + b0 * du0 + b1 * du1 : (lane == 6 ? d6 + h * du1 : 0.0);
+            if (lane < NX) L.ddx[k * 7 + lane] = dxv;           // ddx_{k+1}
         }
-        const double du0 = __shfl(du, 0, WAVE), du1 = __shfl(du, 1, WAVE);
-        if (lane < NX) {
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < NX; ++l) a += G[lane * 9 + l] * xk[l];
-            a += G[lane * 9 + 7] * du0 + G[lane * 9 + 8] * du1;
-            L.ddx[(k + 1) * 7 + lane] = a;
-        }
-        WSYNC();
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// per-lane interior point state
-// ---------------------------------------------------------------------------------------------
-struct USet {      // soft box on one input: 0 lower, 1 upper, 2 sl>=0, 3 su>=0
-    double t[4], lam[4], du, sl, su, dl, duu, r;      // dl = lbu-ubar, duu = ubu-ubar, r = cost gradient
+struct USet2 {     // soft box on one input: 0 lower, 1 upper, 2 sl>=0, 3 su>=0
+    double t[4], lam[4], du, sl, su, dl, duu, r;
+    double it[4], il[4], iG02, iG13;               // reciprocals, refreshed once per iteration
     double rc[4], rd[4], rsl, rsu, ru, e1, e2, dt[4], dlam[4], dsl, dsu;
 };
-struct DSet {      // hard box on delta of one stage
-    double t[2], lam[2], dl, du;
-    double rc[2], rd[2], dt[2], dlam[2];
+struct DSet2 {     // hard box on delta of one stage
+    double t[2], lam[2], dl, du, dx6, rx6;
+    double it[2], il[2], rc[2], rd[2], dt[2], dlam[2];
+};
+struct XTask {     // one state entry (k,i), k = 1..N
+    double xbar, xref, dx, w;   // w: cost weight of this entry (Ts*q_i, terminal W_e for k = N)
+    int k, i;      // k = 0 marks an unused slot
 };
 
-template <int UPL>
-__device__ __forceinline__ int ipm_solve(const AdmpcConfig* __restrict__ c, const Lds& L, int N, int lane,
-                                         USet (&U)[UPL], DSet& D, const double* Qd, const double* Rd, const double* Qe,
-                                         double rho_l, double rho_u, bool& failed)
-{
-    const double thr = c->ipm_thr0, mu0 = c->ipm_mu0;
-    const double tol_comp = c->ipm_tol_comp, tol_res = c->ipm_tol_res, tol_step = c->ipm_tol_step;
-    const int itmax = c->ipm_iter_max;
-    const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
-    const int nu_sets = 2 * N;
-    const bool dact = lane >= 1 && lane < N;            // this lane owns the delta bounds of stage `lane`
-    // ---- cold start: zero input step, states rolled out through the linearised dynamics, slacks at thr
-#pragma unroll
-    for (int m = 0; m < UPL; ++m) {
-        USet& s = U[m];
-        s.du = 0.0; s.sl = thr; s.su = thr;
-        const double r0[4] = { thr - s.dl, thr + s.duu, thr, thr };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s.t[i] = r0[i] > thr ? r0[i] : thr; s.lam[i] = mu0 / s.t[i]; }
-    }
-    // dx[0] = x0 - xbar0 ; dx[k+1] = A dx[k] + b   (du = 0)
-    if (lane < NX) L.dx[lane] = L.x0[lane] - L.xs[lane];
-    for (int i = lane; i < N * 7; i += WAVE) L.pi[i] = 0.0;
-    WSYNC();
-    for (int k = 0; k < N; ++k) {
-        if (lane < NX) {
-            double a = L.bl[k * 7 + lane];
-#pragma unroll
-            for (int l = 0; l < NX; ++l) a += L.G[k * GS + lane * 9 + l] * L.dx[k * 7 + l];
-            L.dx[(k + 1) * 7 + lane] = a;
-        }
-        WSYNC();
-    }
-    {
-        D.t[0] = D.t[1] = 1.0; D.lam[0] = D.lam[1] = 0.0;
-        if (dact) {
-            const double x6 = L.dx[lane * 7 + 6];
-            const double r0[2] = { x6 - D.dl, D.du - x6 };
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { D.t[i] = r0[i] > thr ? r0[i] : thr; D.lam[i] = mu0 / D.t[i]; }
-        }
-    }
-    failed = false;
-    double rmax_prev = 0.0, step = 1e300;
-    int it = 0;
-    for (; it < itmax; ++it) {
-        // ---- complementarity products, mu
-        double musum = 0.0, cmax = 0.0, rmax = 0.0;
-#pragma unroll
-        for (int m = 0; m < UPL; ++m) {
-            USet& s = U[m];
-            const bool act = lane + WAVE * m < nu_sets;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s.rc[i] = s.t[i] * s.lam[i]; if (act) { musum += s.rc[i]; cmax = fmax(cmax, s.rc[i]); } }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { D.rc[i] = D.t[i] * D.lam[i]; if (dact) { musum += D.rc[i]; cmax = fmax(cmax, D.rc[i]); } }
-        if (dact) { L.lamd[lane * 2] = D.lam[0]; L.lamd[lane * 2 + 1] = D.lam[1]; }
-        WSYNC();
-        // ---- linear residuals: input sets
-#pragma unroll
-        for (int m = 0; m < UPL; ++m) {
-            USet& s = U[m];
-            const int sid = lane + WAVE * m;
-            if (sid < nu_sets) {
-                const int k = sid >> 1, j = sid & 1;
-                double a = Rd[j] * s.du + s.r - s.lam[0] + s.lam[1];
-#pragma unroll
-                for (int l = 0; l < NX; ++l) a += L.G[k * GS + l * 9 + 7 + j] * L.pi[k * 7 + l];
-                s.ru = a;
-                s.rsl = rho_l - s.lam[0] - s.lam[2];
-                s.rsu = rho_u - s.lam[1] - s.lam[3];
-                s.rd[0] = s.du + s.sl - s.dl - s.t[0];
-                s.rd[1] = -s.du + s.su + s.duu - s.t[1];
-                s.rd[2] = s.sl - s.t[2];
-                s.rd[3] = s.su - s.t[3];
-                rmax = absmax_nan(rmax, s.ru); rmax = absmax_nan(rmax, s.rsl); rmax = absmax_nan(rmax, s.rsu);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rmax = absmax_nan(rmax, s.rd[i]);
-            }
-        }
-        // ---- state stationarity rows (k,i), k = 1..N
-        for (int tsk = lane; tsk < N * 7; tsk += WAVE) {
-            const int k = tsk / 7 + 1, i = tsk % 7;
-            double a;
-            if (k < N) {
-                a = Qd[i] * L.dx[k * 7 + i] + L.q[k * 7 + i] - L.pi[(k - 1) * 7 + i];
-#pragma unroll
-                for (int l = 0; l < NX; ++l) a += L.G[k * GS + l * 9 + i] * L.pi[k * 7 + l];
-                if (i == 6) a += -L.lamd[k * 2] + L.lamd[k * 2 + 1];
-            } else {
-                a = Qe[i] * L.dx[N * 7 + i] + L.q[N * 7 + i] - L.pi[(N - 1) * 7 + i];
-            }
-            L.gx[k * 7 + i] = a;
-            rmax = absmax_nan(rmax, a);
-        }
-        if (lane < NX) L.gx[lane] = 0.0;
-        if (dact) {
-            const double x6 = L.dx[lane * 7 + 6];
-            D.rd[0] = x6 - D.dl - D.t[0];
-            D.rd[1] = D.du - x6 - D.t[1];
-            rmax = absmax_nan(rmax, D.rd[0]); rmax = absmax_nan(rmax, D.rd[1]);
-        }
-        const double mu = uniform(wave_sum(musum)) * inv_nineq;
-        cmax = uniform(wave_max(cmax));
-        rmax = uniform(wave_max_nan(rmax));
-        if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
-        if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
-        rmax_prev = rmax;
-        WSYNC();
-
-        double mu_aff = 0.0, sigma = 0.0, rx6 = 0.0;
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {            // 0: predictor, 1: corrector
-            // ---- eliminate slacks / multipliers -> barrier-augmented diagonals and gradients
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                USet& s = U[m];
-                const int sid = lane + WAVE * m;
-                if (sid < nu_sets) {
-                    const double G0 = s.lam[0] / s.t[0], G1 = s.lam[1] / s.t[1], G2 = s.lam[2] / s.t[2], G3 = s.lam[3] / s.t[3];
-                    const double c0 = s.rc[0] / s.t[0], c1 = s.rc[1] / s.t[1], c2 = s.rc[2] / s.t[2], c3 = s.rc[3] / s.t[3];
-                    s.e1 = s.rsl + c0 + c2 + G0 * s.rd[0] + G2 * s.rd[2];
-                    s.e2 = s.rsu + c1 + c3 + G1 * s.rd[1] + G3 * s.rd[3];
-                    const double etal = c0 + G0 * s.rd[0] - G0 * s.e1 / (G0 + G2);
-                    const double etau = -c1 - G1 * s.rd[1] + G1 * s.e2 / (G1 + G3);
-                    if (pass == 0) L.Rt[sid] = Rd[sid & 1] + G0 * G2 / (G0 + G2) + G1 * G3 / (G1 + G3);
-                    L.gu[sid] = s.ru + etal + etau;
-                }
-            }
-            if (dact) {
-                const double G5 = D.lam[0] / D.t[0], G6 = D.lam[1] / D.t[1];
-                if (pass == 0) L.Qt[lane] = Qd[6] + G5 + G6;
-                const double ex = (D.rc[0] / D.t[0] + G5 * D.rd[0]) - (D.rc[1] / D.t[1] + G6 * D.rd[1]);
-                if (pass == 0) rx6 = L.gx[lane * 7 + 6];
-                L.gx[lane * 7 + 6] = rx6 + ex;
-            }
-            WSYNC();
-            if (pass == 0) riccati_factor(L, N, lane, Qd, Qe);
-            riccati_backward(L, N, lane);
-            riccati_forward(L, N, lane);
-            // ---- recover slack / t / lam steps, step length
-            double amax = 1.0;
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                USet& s = U[m];
-                const int sid = lane + WAVE * m;
-                if (sid < nu_sets) {
-                    const double G[4] = { s.lam[0] / s.t[0], s.lam[1] / s.t[1], s.lam[2] / s.t[2], s.lam[3] / s.t[3] };
-                    const double u = L.ddu[sid];
-                    s.dsl = -(s.e1 + G[0] * u) / (G[0] + G[2]);
-                    s.dsu = -(s.e2 - G[1] * u) / (G[1] + G[3]);
-                    s.dt[0] = u + s.dsl + s.rd[0]; s.dt[1] = -u + s.dsu + s.rd[1]; s.dt[2] = s.dsl + s.rd[2]; s.dt[3] = s.dsu + s.rd[3];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        s.dlam[i] = -s.rc[i] / s.t[i] - G[i] * s.dt[i];
-                        if (s.dt[i] < 0.0) amax = fmin(amax, -s.t[i] / s.dt[i]);
-                        if (s.dlam[i] < 0.0) amax = fmin(amax, -s.lam[i] / s.dlam[i]);
-                    }
-                }
-            }
-            if (dact) {
-                const double G5 = D.lam[0] / D.t[0], G6 = D.lam[1] / D.t[1];
-                const double x6 = L.ddx[lane * 7 + 6];
-                D.dt[0] = x6 + D.rd[0];  D.dlam[0] = -D.rc[0] / D.t[0] - G5 * D.dt[0];
-                D.dt[1] = -x6 + D.rd[1]; D.dlam[1] = -D.rc[1] / D.t[1] - G6 * D.dt[1];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (D.dt[i] < 0.0) amax = fmin(amax, -D.t[i] / D.dt[i]);
-                    if (D.dlam[i] < 0.0) amax = fmin(amax, -D.lam[i] / D.dlam[i]);
-                }
-            }
-            amax = uniform(wave_min(amax));
-            if (pass == 0) {
-                // affine step: mu_aff, sigma, corrector right-hand side
-                double s_aff = 0.0;
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) {
-                    USet& s = U[m];
-                    if (lane + WAVE * m < nu_sets)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) s_aff += (s.t[i] + amax * s.dt[i]) * (s.lam[i] + amax * s.dlam[i]);
-                }
-                if (dact)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) s_aff += (D.t[i] + amax * D.dt[i]) * (D.lam[i] + amax * D.dlam[i]);
-                mu_aff = uniform(wave_sum(s_aff)) * inv_nineq;
-                sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
-                const double smu = sigma * mu;
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) {
-                    USet& s = U[m];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s.rc[i] = s.t[i] * s.lam[i] + s.dt[i] * s.dlam[i] - smu;
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) D.rc[i] = D.t[i] * D.lam[i] + D.dt[i] * D.dlam[i] - smu;
-            } else {
-                double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
-                double alpha = fmin(tau * amax, 1.0);
-                double stp = 0.0;
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) {
-                    USet& s = U[m];
-                    const int sid = lane + WAVE * m;
-                    if (sid < nu_sets) {
-                        const double u = L.ddu[sid];
-                        stp = fmax(stp, fabs(alpha * u));
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            s.t[i] = fmax(s.t[i] + alpha * s.dt[i], IPM_FLOOR);
-                            s.lam[i] = fmax(s.lam[i] + alpha * s.dlam[i], IPM_FLOOR);
-                        }
-                        s.du += alpha * u; s.sl += alpha * s.dsl; s.su += alpha * s.dsu;
-                    }
-                }
-                if (dact)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        D.t[i] = fmax(D.t[i] + alpha * D.dt[i], IPM_FLOOR);
-                        D.lam[i] = fmax(D.lam[i] + alpha * D.dlam[i], IPM_FLOOR);
-                    }
-                // dx += alpha ddx ; pi += alpha (P ddx + pv)
-                for (int tsk = lane; tsk < N * 7; tsk += WAVE) {
-                    const int k = tsk / 7, i = tsk % 7;       // pi[k][i] and dx[k+1][i]
-                    double dp = L.pv[(k + 1) * 7 + i];
-#pragma unroll
-                    for (int l = 0; l < NX; ++l) dp += L.P[(k + 1) * PS + i * 7 + l] * L.ddx[(k + 1) * 7 + l];
-                    L.pi[k * 7 + i] += alpha * dp;
-                    L.dx[(k + 1) * 7 + i] += alpha * L.ddx[(k + 1) * 7 + i];
-                }
-                step = uniform(wave_max(stp));
-                WSYNC();
-            }
-        }
-    }
-    return it;
-}
-
-// ---------------------------------------------------------------------------------------------
-// the fused solve kernel: one instance per wave, grid-stride over instances
-// ---------------------------------------------------------------------------------------------
-template <int UPL>
-__global__ __launch_bounds__(WAVE) void admpc_solve_kernel(const AdmpcConfig* __restrict__ cfg, int B,
-                                                           const double* __restrict__ x0g, const double* __restrict__ yrefg,
-                                                           const double* __restrict__ yrefeg, const double* __restrict__ pg,
-                                                           double* __restrict__ xbarg, double* __restrict__ ubarg,
-                                                           double* __restrict__ costg, int32_t* __restrict__ statusg,
-                                                           int32_t* __restrict__ itersg)
+template <int UPL, int TPL>
+__global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                        const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                        const double* __restrict__ yrefeg,
+                                                        const double* __restrict__ GTg, const double* __restrict__ blg,
+                                                        double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                        double* __restrict__ costg, int32_t* __restrict__ statusg,
+                                                        int32_t* __restrict__ itersg, int first_pass)
 {
     extern __shared__ double lds_raw[];
     const int lane = threadIdx.x;
     const int N = cfg->N;
-    Lds L;
-    lds_carve(lds_raw, N, L);
+    Lds2 L;
+    lds2_carve(lds_raw, N, L);
     const double Ts = cfg->Ts;
     double Qd[NX], Qe[NX], Rd[NU];
 #pragma unroll
@@ -629,117 +519,342 @@ __global__ __launch_bounds__(WAVE) void admpc_solve_kernel(const AdmpcConfig* __
 #pragma unroll
     for (int j = 0; j < NU; ++j) Rd[j] = Ts * cfg->W[NX + j];
     const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
-    const int nsqp = cfg->sqp_iters > 0 ? cfg->sqp_iters : 1;
+    const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
+    const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
+    const int itmax = cfg->ipm_iter_max;
+    const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
+    const int nu_sets = 2 * N;
+    const bool dact = lane >= 1 && lane < N;
+    Roles R;
+    make_roles(lane, Ts, Qd, Qe, R);
 
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
-        // ---- stage the instance record in LDS (coalesced 8 B / lane)
+        if (!first_pass && statusg[inst] != 0) continue;          // failed in an earlier SQP step: leave untouched
+        const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
+        const double* ubg = ubarg + (size_t)inst * N * NU;
+        const double* yrg = yrefg + (size_t)inst * N * NY;
+        // ---- stage the linearisation (coalesced), defects into the ddx slots
         {
-            const double* gx = xbarg + (size_t)inst * (N + 1) * NX;
-            const double* gu = ubarg + (size_t)inst * N * NU;
-            const double* gy = yrefg + (size_t)inst * N * NY;
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) L.xs[i] = gx[i];
-            for (int i = lane; i < N * NU; i += WAVE) L.us[i] = gu[i];
-            for (int i = lane; i < N * NY; i += WAVE) L.yr[i] = gy[i];
-            if (lane < NX) { L.ye[lane] = yrefeg[(size_t)inst * NX + lane]; L.x0[lane] = x0g[(size_t)inst * NX + lane]; }
+            const double* gt = GTg + (size_t)inst * N * GTS;
+            const double* bl = blg + (size_t)inst * N * NX;
+            for (int i = lane; i < N * GTS; i += WAVE) L.GT[i] = gt[i];
+            for (int i = lane; i < N * NX; i += WAVE) L.ddx[i] = bl[i];
+            for (int i = lane; i < N * NX; i += WAVE) L.pi[i] = 0.0;
         }
-        const double p = pg[inst];
+        // ---- per-lane problem data
+        XTask T[TPL];
+#pragma unroll
+        for (int m = 0; m < TPL; ++m) {
+            const int t = lane + WAVE * m;
+            const bool on = t < N * 7;
+            const int tt = on ? t : 0;
+            const int k = tt / 7 + 1, i = tt % 7;
+            T[m].k = on ? k : 0; T[m].i = i;
+            T[m].xbar = xbg[7 + tt];
+            T[m].xref = k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i];
+            T[m].dx = 0.0;
+            T[m].w = k < N ? sel7(Qd, i) : sel7(Qe, i);
+        }
+        USet2 U[UPL];
+#pragma unroll
+        for (int m = 0; m < UPL; ++m) {
+            const int sid = lane + WAVE * m;
+            const int sc = sid < nu_sets ? sid : 0;
+            const int k = sc >> 1, j = sc & 1;
+            const double ub = ubg[sc];
+            U[m].dl = cfg->lbu[j] - ub; U[m].duu = cfg->ubu[j] - ub;
+            U[m].r = (j ? Rd[1] : Rd[0]) * (ub - yrg[k * 9 + 7 + j]);
+            U[m].du = 0.0; U[m].sl = thr; U[m].su = thr;
+            const double r0[4] = { thr - U[m].dl, thr + U[m].duu, thr, thr };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { U[m].t[i] = r0[i] > thr ? r0[i] : thr; U[m].lam[i] = mu0 / U[m].t[i]; }
+        }
+        DSet2 D;
+        {
+            const double x6 = xbg[(dact ? lane : 0) * 7 + 6];
+            D.dl = cfg->lbx_delta - x6; D.du = cfg->ubx_delta - x6;
+        }
+        const double dx0 = lane < NX ? x0g[(size_t)inst * NX + lane] - xbg[lane] : 0.0;
         WSYNC();
-        int status = ADMPC_STATUS_SUCCESS, iters = 0;
-        for (int sq = 0; sq < nsqp && status == ADMPC_STATUS_SUCCESS; ++sq) {
-            // ---- H1: shooting, task (k,g)
-            for (int tsk = lane; tsk < 3 * N; tsk += WAVE) {
-                const int k = tsk / 3, g = tsk % 3;
-                double x[NX], u[NU], phi[NX], col[3][NX];
+        // ---- start-up: du = 0, states rolled out through the linearised dynamics (dx_{k+1} into pv slots)
+        riccati_forward2<true>(L, N, lane, Ts, dx0);
+        WSYNC();
 #pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = L.xs[k * 7 + i];
-                u[0] = L.us[k * 2]; u[1] = L.us[k * 2 + 1];
-                rk4_group(cfg, x, u, p, Ts, g, phi, col);
-                double* G = L.G + k * GS;
-                if (g == 0) {
+        for (int m = 0; m < TPL; ++m) if (T[m].k) T[m].dx = L.pv[(T[m].k - 1) * 7 + T[m].i];
+        {
+            D.dx6 = dact ? L.pv[(lane - 1) * 7 + 6] : 0.0;
+            D.t[0] = D.t[1] = 1.0; D.lam[0] = D.lam[1] = 0.0; D.rx6 = 0.0;
+            if (dact) {
+                const double r0[2] = { D.dx6 - D.dl, D.du - D.dx6 };
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        G[i * 9 + 0] = i == 0 ? 1.0 : 0.0; G[i * 9 + 1] = i == 1 ? 1.0 : 0.0;
-                        G[i * 9 + 2] = col[0][i]; G[i * 9 + 3] = col[1][i]; G[i * 9 + 4] = col[2][i];
-                        L.bl[k * 7 + i] = phi[i] - L.xs[(k + 1) * 7 + i];
-                    }
-                } else if (g == 1) {
+                for (int i = 0; i < 2; ++i) { D.t[i] = r0[i] > thr ? r0[i] : thr; D.lam[i] = mu0 / D.t[i]; }
+            }
+        }
+        WSYNC();
+
+        bool failed = false;
+        double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
+        int it = 0;
+        for (; it < itmax; ++it) {
+            // ---- reciprocals, complementarity, residuals of the input sets
+            double musum = 0.0, cmax = 0.0, rmax = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { G[i * 9 + 5] = col[0][i]; G[i * 9 + 6] = col[1][i]; }
-                } else {
+            for (int m = 0; m < UPL; ++m) {
+                USet2& s = U[m];
+                const int sid = lane + WAVE * m;
+                const bool act = sid < nu_sets;
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { G[i * 9 + 7] = col[0][i]; G[i * 9 + 8] = col[1][i]; }
+                for (int i = 0; i < 4; ++i) {
+                    s.it[i] = 1.0 / s.t[i]; s.il[i] = 1.0 / s.lam[i];
+                    s.rc[i] = s.t[i] * s.lam[i];
+                    if (act) { musum += s.rc[i]; cmax = fmax(cmax, s.rc[i]); }
+                }
+                s.iG02 = 1.0 / (s.lam[0] * s.it[0] + s.lam[2] * s.it[2]);
+                s.iG13 = 1.0 / (s.lam[1] * s.it[1] + s.lam[3] * s.it[3]);
+                if (act) {
+                    const int k = sid >> 1, j = sid & 1;
+                    const double* bcol = L.GT + k * GTS + (5 + j) * 6;
+                    const double* pik = L.pi + k * 7;
+                    double a = (j ? Rd[1] : Rd[0]) * s.du + s.r - s.lam[0] + s.lam[1] + (j == 1 ? Ts * pik[6] : 0.0);
+#pragma unroll
+                    for (int l = 0; l < 6; ++l) a += bcol[l] * pik[l];
+                    s.ru = a;
+                    s.rsl = rho_l - s.lam[0] - s.lam[2];
+                    s.rsu = rho_u - s.lam[1] - s.lam[3];
+                    s.rd[0] = s.du + s.sl - s.dl - s.t[0];
+                    s.rd[1] = -s.du + s.su + s.duu - s.t[1];
+                    s.rd[2] = s.sl - s.t[2];
+                    s.rd[3] = s.su - s.t[3];
+                    rmax = OpMaxNan::f(rmax, fabs(s.ru)); rmax = OpMaxNan::f(rmax, fabs(s.rsl)); rmax = OpMaxNan::f(rmax, fabs(s.rsu));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rmax = OpMaxNan::f(rmax, fabs(s.rd[i]));
                 }
             }
-            // ---- H2: gradients of the Gauss-Newton model
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) {
-                const int k = i / 7, ii = i % 7;
-                L.q[i] = k < N ? Qd[ii] * (L.xs[i] - L.yr[k * 9 + ii]) : Qe[ii] * (L.xs[i] - L.ye[ii]);
-            }
-            // ---- H3: bounds in step form
-            USet U[UPL];
-            DSet D;
 #pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                const int sid = lane + WAVE * m;
-                const int sc = sid < 2 * N ? sid : 0;
-                const int k = sc >> 1, j = sc & 1;
-                const double ub = L.us[sc];
-                U[m].dl = cfg->lbu[j] - ub; U[m].duu = cfg->ubu[j] - ub;
-                U[m].r = Rd[j] * (ub - L.yr[k * 9 + 7 + j]);
+            for (int i = 0; i < 2; ++i) {
+                D.it[i] = 1.0 / D.t[i]; D.il[i] = 1.0 / D.lam[i];
+                D.rc[i] = D.t[i] * D.lam[i];
+                if (dact) { musum += D.rc[i]; cmax = fmax(cmax, D.rc[i]); }
             }
-            {
-                const int k = lane < N ? lane : 0;
-                D.dl = cfg->lbx_delta - L.xs[k * 7 + 6]; D.du = cfg->ubx_delta - L.xs[k * 7 + 6];
+            // ---- state stationarity rows (k,i), k = 1..N (the delta-bound multipliers are added by the owner lane)
+#pragma unroll
+            for (int m = 0; m < TPL; ++m) {
+                const XTask& tk = T[m];
+                if (tk.k) {
+                    const int k = tk.k, i = tk.i;
+                    double a;
+                    if (k < N) {
+                        a = tk.w * (tk.dx + (tk.xbar - tk.xref)) - L.pi[(k - 1) * 7 + i];
+                        const double* pik = L.pi + k * 7;
+                        if (i < 2) a += pik[i];
+                        else {
+                            const double* acol = L.GT + k * GTS + (i - 2) * 6;
+#pragma unroll
+                            for (int l = 0; l < 6; ++l) a += acol[l] * pik[l];
+                            if (i == 6) a += pik[6];
+                        }
+                    } else {
+                        a = tk.w * (tk.dx + (tk.xbar - tk.xref)) - L.pi[(N - 1) * 7 + i];
+                    }
+                    L.gx[(k - 1) * 7 + i] = a;
+                    if (!(k < N && i == 6)) rmax = OpMaxNan::f(rmax, fabs(a));
+                }
             }
             WSYNC();
-            // ---- H4/H5: QP
-            bool failed;
-            iters = ipm_solve<UPL>(cfg, L, N, lane, U, D, Qd, Rd, Qe, rho_l, rho_u, failed);
-            // ---- H6: full step
-            bool bad = failed;        // a non-finite step is a QP failure: leave the iterate untouched
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) { double v = L.xs[i] + L.dx[i]; if (!(fabs(v) <= 1e300)) bad = true; }
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                const int sid = lane + WAVE * m;
-                if (sid < 2 * N) { double v = L.us[sid] + U[m].du; if (!(fabs(v) <= 1e300)) bad = true; }
+            if (dact) {
+                D.rx6 = L.gx[(lane - 1) * 7 + 6] - D.lam[0] + D.lam[1];
+                D.rd[0] = D.dx6 - D.dl - D.t[0];
+                D.rd[1] = D.du - D.dx6 - D.t[1];
+                rmax = OpMaxNan::f(rmax, fabs(D.rx6)); rmax = OpMaxNan::f(rmax, fabs(D.rd[0])); rmax = OpMaxNan::f(rmax, fabs(D.rd[1]));
             }
-            if (__any(bad)) {
-                status = ADMPC_STATUS_QP_FAILURE;
-            } else {
-                for (int i = lane; i < (N + 1) * NX; i += WAVE) L.xs[i] += L.dx[i];
+            const double mu = wave_reduce<OpSum>(musum) * inv_nineq;
+            cmax = wave_reduce<OpMax>(cmax);
+            rmax = wave_reduce<OpMaxNan>(rmax);
+            step = wave_reduce<OpMax>(stp_local);
+            if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
+            if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
+            rmax_prev = rmax;
+
+            double mu_aff = 0.0;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {            // 0: predictor, 1: corrector
+                // ---- eliminate slacks / multipliers
 #pragma unroll
                 for (int m = 0; m < UPL; ++m) {
+                    USet2& s = U[m];
                     const int sid = lane + WAVE * m;
-                    if (sid < 2 * N) L.us[sid] += U[m].du;
+                    if (sid < nu_sets) {
+                        const double G0 = s.lam[0] * s.it[0], G1 = s.lam[1] * s.it[1], G2 = s.lam[2] * s.it[2], G3 = s.lam[3] * s.it[3];
+                        const double c0 = s.rc[0] * s.it[0], c1 = s.rc[1] * s.it[1], c2 = s.rc[2] * s.it[2], c3 = s.rc[3] * s.it[3];
+                        s.e1 = s.rsl + c0 + c2 + G0 * s.rd[0] + G2 * s.rd[2];
+                        s.e2 = s.rsu + c1 + c3 + G1 * s.rd[1] + G3 * s.rd[3];
+                        const double etal = c0 + G0 * s.rd[0] - G0 * s.e1 * s.iG02;
+                        const double etau = -c1 - G1 * s.rd[1] + G1 * s.e2 * s.iG13;
+                        if (pass == 0) L.Rt[sid] = ((sid & 1) ? Rd[1] : Rd[0]) + G0 * G2 * s.iG02 + G1 * G3 * s.iG13;
+                        L.guk[sid] = s.ru + etal + etau;
+                    }
+                }
+                if (dact) {
+                    const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
+                    if (pass == 0) L.Qt[lane] = Qd[6] + G5 + G6;
+                    L.gx[(lane - 1) * 7 + 6] = D.rx6 + (D.rc[0] * D.it[0] + G5 * D.rd[0]) - (D.rc[1] * D.it[1] + G6 * D.rd[1]);
+                }
+                WSYNC();
+                if (pass == 0) riccati_factor_fused(L, N, lane, R);
+                else { riccati_backward2(L, N, lane, Ts); WSYNC(); }
+                riccati_forward2<false>(L, N, lane, Ts, 0.0);
+                WSYNC();
+                // ---- recover slack / t / lam steps; largest step to the boundary via max(-d/v)
+                double rr = 0.0;
+#pragma unroll
+                for (int m = 0; m < UPL; ++m) {
+                    USet2& s = U[m];
+                    const int sid = lane + WAVE * m;
+                    if (sid < nu_sets) {
+                        const double G[4] = { s.lam[0] * s.it[0], s.lam[1] * s.it[1], s.lam[2] * s.it[2], s.lam[3] * s.it[3] };
+                        const double u = L.guk[sid];
+                        s.dsl = -(s.e1 + G[0] * u) * s.iG02;
+                        s.dsu = -(s.e2 - G[1] * u) * s.iG13;
+                        s.dt[0] = u + s.dsl + s.rd[0]; s.dt[1] = -u + s.dsu + s.rd[1]; s.dt[2] = s.dsl + s.rd[2]; s.dt[3] = s.dsu + s.rd[3];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            s.dlam[i] = -s.rc[i] * s.it[i] - G[i] * s.dt[i];
+                            rr = fmax(rr, fmax(-s.dt[i] * s.it[i], -s.dlam[i] * s.il[i]));
+                        }
+                    }
+                }
+                if (dact) {
+                    const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
+                    const double x6 = L.ddx[(lane - 1) * 7 + 6];
+                    D.dt[0] = x6 + D.rd[0];  D.dlam[0] = -D.rc[0] * D.it[0] - G5 * D.dt[0];
+                    D.dt[1] = -x6 + D.rd[1]; D.dlam[1] = -D.rc[1] * D.it[1] - G6 * D.dt[1];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) rr = fmax(rr, fmax(-D.dt[i] * D.it[i], -D.dlam[i] * D.il[i]));
+                }
+                rr = wave_reduce<OpMax>(rr);
+                const double amax = rr > 1.0 ? 1.0 / rr : 1.0;
+                if (pass == 0) {
+                    double s_aff = 0.0;
+#pragma unroll
+                    for (int m = 0; m < UPL; ++m) {
+                        USet2& s = U[m];
+                        if (lane + WAVE * m < nu_sets)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) s_aff += (s.t[i] + amax * s.dt[i]) * (s.lam[i] + amax * s.dlam[i]);
+                    }
+                    if (dact)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) s_aff += (D.t[i] + amax * D.dt[i]) * (D.lam[i] + amax * D.dlam[i]);
+                    mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
+                    double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+                    const double smu = sigma * mu;
+#pragma unroll
+                    for (int m = 0; m < UPL; ++m) {
+                        USet2& s = U[m];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s.rc[i] = s.t[i] * s.lam[i] + s.dt[i] * s.dlam[i] - smu;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) D.rc[i] = D.t[i] * D.lam[i] + D.dt[i] * D.dlam[i] - smu;
+                } else {
+                    double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+                    const double alpha = fmin(tau * amax, 1.0);
+                    stp_local = 0.0;
+#pragma unroll
+                    for (int m = 0; m < UPL; ++m) {
+                        USet2& s = U[m];
+                        const int sid = lane + WAVE * m;
+                        if (sid < nu_sets) {
+                            const double u = L.guk[sid];
+                            stp_local = fmax(stp_local, fabs(alpha * u));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                s.t[i] = fmax(s.t[i] + alpha * s.dt[i], IPM_FLOOR);
+                                s.lam[i] = fmax(s.lam[i] + alpha * s.dlam[i], IPM_FLOOR);
+                            }
+                            s.du += alpha * u; s.sl += alpha * s.dsl; s.su += alpha * s.dsu;
+                        }
+                    }
+                    if (dact) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            D.t[i] = fmax(D.t[i] + alpha * D.dt[i], IPM_FLOOR);
+                            D.lam[i] = fmax(D.lam[i] + alpha * D.dlam[i], IPM_FLOOR);
+                        }
+                        D.dx6 += alpha * L.ddx[(lane - 1) * 7 + 6];
+                    }
+                    // dx += alpha ddx ; pi[k-1] += alpha (P_k ddx_k + p_k)   for the entries (k,i) this lane owns
+                    double dpi[TPL];
+#pragma unroll
+                    for (int m = 0; m < TPL; ++m) {
+                        dpi[m] = 0.0;
+                        if (T[m].k) {
+                            const int k = T[m].k, i = T[m].i;
+                            const double* dk = L.ddx + (k - 1) * 7;
+                            const double* Pp = L.Pk + (k - 1) * PKS;
+                            double dp = L.pv[(k - 1) * 7 + i];
+#pragma unroll
+                            for (int l = 0; l < NX; ++l) {
+                                const int lo = l < i ? l : i, hi = l < i ? i : l;
+                                dp += Pp[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)] * dk[l];
+                            }
+                            dpi[m] = dp;
+                            T[m].dx += alpha * dk[i];
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < TPL; ++m) if (T[m].k) L.pi[(T[m].k - 1) * 7 + T[m].i] += alpha * dpi[m];
+                    WSYNC();
                 }
             }
-            WSYNC();
         }
-        // ---- write back, cost
-        {
-            double* gx = xbarg + (size_t)inst * (N + 1) * NX;
-            double* gu = ubarg + (size_t)inst * N * NU;
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) gx[i] = L.xs[i];
-            for (int i = lane; i < N * NU; i += WAVE) gu[i] = L.us[i];
-            double J = 0.0;
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) {
-                const int k = i / 7, ii = i % 7;
-                if (k < N) { double e = L.xs[i] - L.yr[k * 9 + ii]; J += 0.5 * Ts * cfg->W[ii] * e * e; }
-                else { double e = L.xs[i] - L.ye[ii]; J += 0.5 * cfg->We[ii] * e * e; }
+        // ---- H6: full step, outputs
+        bool bad = failed;
+#pragma unroll
+        for (int m = 0; m < TPL; ++m) if (T[m].k) { const double v = T[m].xbar + T[m].dx; if (!(fabs(v) <= 1e300)) bad = true; }
+#pragma unroll
+        for (int m = 0; m < UPL; ++m) {
+            const int sid = lane + WAVE * m;
+            if (sid < nu_sets) { const double v = ubg[sid] + U[m].du; if (!(fabs(v) <= 1e300)) bad = true; }
+        }
+        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+        double J = 0.0;
+        if (status == ADMPC_STATUS_SUCCESS) {
+            double* xo = xbarg + (size_t)inst * (N + 1) * NX;
+            double* uo = ubarg + (size_t)inst * N * NU;
+            if (lane < NX) {
+                const double x0v = xbg[lane] + dx0;
+                const double e = x0v - yrg[lane];
+                J += 0.5 * sel7(Qd, lane) * e * e;
+                xo[lane] = x0v;
             }
-            for (int i = lane; i < N * NU; i += WAVE) {
-                const int k = i >> 1, j = i & 1;
-                const double u = L.us[i];
-                double e = u - L.yr[k * 9 + 7 + j]; J += 0.5 * Ts * cfg->W[NX + j] * e * e;
-                if (u < cfg->lbu[j]) J += Ts * cfg->zl * (cfg->lbu[j] - u);
-                if (u > cfg->ubu[j]) J += Ts * cfg->zu * (u - cfg->ubu[j]);
+#pragma unroll
+            for (int m = 0; m < TPL; ++m) if (T[m].k) {
+                const double v = T[m].xbar + T[m].dx, e = v - T[m].xref;
+                J += 0.5 * T[m].w * e * e;
+                xo[7 + lane + WAVE * m] = v;
             }
-            J = wave_sum(J);
-            if (lane == 0) {
-                if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? J : INFINITY;
-                if (statusg) statusg[inst] = status;
-                if (itersg) itersg[inst] = iters;
+#pragma unroll
+            for (int m = 0; m < UPL; ++m) {
+                const int sid = lane + WAVE * m;
+                if (sid < nu_sets) {
+                    const int j = sid & 1;
+                    const double ub = ubg[sid];
+                    const double v = ub + U[m].du;
+                    const double rdj = j ? Rd[1] : Rd[0];
+                    const double e = U[m].du + U[m].r / rdj;                   // u - uref
+                    J += 0.5 * rdj * e * e;
+                    if (v < cfg->lbu[j]) J += rho_l * (cfg->lbu[j] - v);
+                    if (v > cfg->ubu[j]) J += rho_u * (v - cfg->ubu[j]);
+                    uo[sid] = v;
+                }
             }
+        }
+        J = wave_reduce<OpSum>(J);
+        if (lane == 0) {
+            if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? J : INFINITY;
+            statusg[inst] = status;
+            if (itersg) itersg[inst] = it;
         }
         WSYNC();
     }
@@ -846,6 +961,11 @@ struct AdmpcSolver {
     int num_cu;
     int lds_bytes;
     int blocks_per_cu;
+    // workspace of the linearisation (kernel A -> kernel B), grown on demand by admpc_reserve
+    int cap;                 // instances
+    double* d_GT;            // [cap][N][42]
+    double* d_bl;            // [cap][N][7]
+    int32_t* d_status;       // [cap] used when the caller passes status == NULL
 };
 
 static thread_local std::string g_err;
@@ -904,18 +1024,21 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     AdmpcSolver* s = new (std::nothrow) AdmpcSolver();
     if (!s) return fail(ADMPC_ENOMEM, "out of host memory");
     s->cfg = *cfg; s->device = device; s->num_cu = prop.multiProcessorCount;
-    s->lds_bytes = lds_doubles(cfg->N) * (int)sizeof(double);
+    if (cfg->N > 64) { delete s; return fail(ADMPC_EINVAL, "N > 64 is not supported by this build of the QP kernel"); }
+    s->lds_bytes = lds2_doubles(cfg->N) * (int)sizeof(double);
     if (s->lds_bytes > 160 * 1024) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     s->blocks_per_cu = (160 * 1024) / s->lds_bytes;
     if (s->blocks_per_cu > 16) s->blocks_per_cu = 16;
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
+    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr;
     hipError_t e = hipMalloc((void**)&s->d_cfg, sizeof(AdmpcConfig));
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcConfig), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_cfg); delete s; return fail(ADMPC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     // opt in to > 64 KB of dynamic LDS
-    const void* kerns[3] = { (const void*)admpc_solve_kernel<1>, (const void*)admpc_solve_kernel<2>, (const void*)admpc_solve_kernel<4> };
-    for (int i = 0; i < 3; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* kerns[4] = { (const void*)admpc_qp_kernel<1, 3>, (const void*)admpc_qp_kernel<1, 4>,
+                             (const void*)admpc_qp_kernel<2, 5>, (const void*)admpc_qp_kernel<2, 7> };
+    for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
 }
@@ -925,7 +1048,28 @@ void admpc_destroy(AdmpcSolver* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_cfg);
+    if (s->d_GT) (void)hipFree(s->d_GT);
+    if (s->d_bl) (void)hipFree(s->d_bl);
+    if (s->d_status) (void)hipFree(s->d_status);
     delete s;
+}
+
+int admpc_reserve(AdmpcSolver* s, int B)
+{
+    if (!s || B < 0) return fail(ADMPC_EINVAL, "admpc_reserve: bad argument");
+    if (B <= s->cap) return ADMPC_OK;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());                  // nothing may still be using the old workspace
+    if (s->d_GT) (void)hipFree(s->d_GT);
+    if (s->d_bl) (void)hipFree(s->d_bl);
+    if (s->d_status) (void)hipFree(s->d_status);
+    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->cap = 0;
+    const size_t N = (size_t)s->cfg.N;
+    HIPCHK(hipMalloc((void**)&s->d_GT, (size_t)B * N * GTS * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&s->d_bl, (size_t)B * N * NX * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&s->d_status, (size_t)B * sizeof(int32_t)));
+    s->cap = B;
+    return ADMPC_OK;
 }
 
 int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
@@ -936,13 +1080,28 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     if (B == 0) return ADMPC_OK;
     if (!x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
     HIPCHK(hipSetDevice(s->device));
+    if (B > s->cap) { int rc = admpc_reserve(s, B); if (rc) return rc; }   // allocates: call admpc_reserve up front to keep this call allocation-free
     const int N = s->cfg.N;
-    int grid = s->num_cu * s->blocks_per_cu;
-    if (grid > B) grid = B;
     hipStream_t st = (hipStream_t)stream;
-    if (2 * N <= 64) hipLaunchKernelGGL(admpc_solve_kernel<1>, dim3(grid), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, status, iters);
-    else if (2 * N <= 128) hipLaunchKernelGGL(admpc_solve_kernel<2>, dim3(grid), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, status, iters);
-    else return fail(ADMPC_EINVAL, "N > 64 not supported by this build");
+    int32_t* stat = status ? status : s->d_status;
+    int gridB = s->num_cu * s->blocks_per_cu;
+    if (gridB > B) gridB = B;
+    const long totalA = (long)B * N * 3;
+    int gridA = (int)((totalA + 255) / 256);
+    if (gridA > s->num_cu * 16) gridA = s->num_cu * 16;
+    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
+    for (int sq = 0; sq < nsqp; ++sq) {
+        const int first = sq == 0 ? 1 : 0;
+        hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(256), 0, st, s->d_cfg, B, xbar, ubar, p,
+                           first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl);
+#define LAUNCH_QP(U_, T_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
+                           (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
+        if (N <= 27) LAUNCH_QP(1, 3);
+        else if (N <= 32) LAUNCH_QP(1, 4);
+        else if (N <= 45) LAUNCH_QP(2, 5);
+        else LAUNCH_QP(2, 7);
+#undef LAUNCH_QP
+    }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

@@ -109,6 +109,11 @@ int admpc_default_config(AdmpcConfig* cfg, int N, double Ts);
 int  admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out);
 void admpc_destroy(AdmpcSolver* s);
 
+/* Pre-allocate the internal linearisation workspace (49 doubles per stage and instance) for batches of
+ * up to B instances.  admpc_solve_batch grows it on demand (which allocates and synchronises); calling
+ * this once up front keeps every later solve allocation-free and stream-capture safe. */
+int admpc_reserve(AdmpcSolver* s, int B);
+
 /* One SQP real-time iteration (or cfg.sqp_iters full steps) for B independent instances.
  *   x0     [B][7]        measured state             (solver.set(0,'lbx'/'ubx',x0), py:441-442)
  *   yref   [B][N][9]     stage references [x;u]     (solver.set(j,'yref',ref),     py:430)
