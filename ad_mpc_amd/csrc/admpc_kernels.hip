@@ -499,7 +499,7 @@ struct XTask {     // one state entry (k,i), k = 1..N
 };
 
 template <int UPL, int TPL>
-__global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+__global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                         const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                         const double* __restrict__ yrefeg,
                                                         const double* __restrict__ GTg, const double* __restrict__ blg,
