@@ -298,7 +298,10 @@ __device__ __forceinline__ void lds2_carve(double* p, int N, Lds2& L) {
     L.Hs = tr; L.hs = tr + 82; L.pvs = tr + 92;
 }
 
-#define WSYNC() __syncthreads()
+// A workgroup is ONE wavefront: its LDS instructions are issued and completed in program order, so a
+// cross-lane exchange through LDS needs no s_barrier -- only a fence that keeps the compiler from
+// reordering the LDS accesses (wavefront scope: emits no instruction).
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 __device__ __forceinline__ int tri_index(int i, int j) {   // packed index of (i<=j) in a 7x7 upper triangle, row-major
     return i * 7 - (i * (i - 1)) / 2 + (j - i);
@@ -348,6 +351,7 @@ __device__ __forceinline__ void riccati_factor_fused(const Lds2& L, int N, int l
     if (lane < 49 && R.pkoff >= 0) L.Pk[(N - 1) * PKS + R.pkoff] = R.qe3;
     if (lane < NX) L.pv[(N - 1) * 7 + lane] = L.gx[(N - 1) * 7 + lane];
     WSYNC();
+#pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
         const double* GT = L.GT + k * GTS;
         // ---- L1: M^T[c][i] = P+[i][:] . G[:,c]   (+ gradient h for the fused predictor sweep)
@@ -430,6 +434,7 @@ __device__ __forceinline__ void riccati_backward2(const Lds2& L, int N, int lane
     if (lane < NX) L.pv[(N - 1) * 7 + lane] = pvv;
     const int c = lane >= 2 && lane < 9 ? lane - 2 : 0;       // lanes 2..8 own stored column c, lanes 0,1 the unit columns
     const double r6 = r6_of(c, h);
+#pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
         const double* gcol = L.GT + k * GTS + c * 6;
         double g = 0.0;
@@ -458,6 +463,7 @@ __device__ __forceinline__ void riccati_forward2(const Lds2& L, int N, int lane,
 {
     double dxv = STARTUP ? dx0 : 0.0;           // lanes 0..6
     const int li = lane < 6 ? lane : 0;
+#pragma unroll 1
     for (int k = 0; k < N; ++k) {
         const double* GT = L.GT + k * GTS;
         const double a2 = GT[0 * 6 + li], a3 = GT[1 * 6 + li], a4 = GT[2 * 6 + li], a5 = GT[3 * 6 + li], a6 = GT[4 * 6 + li];
@@ -487,19 +493,26 @@ __device__ __forceinline__ void riccati_forward2(const Lds2& L, int N, int lane,
 struct USet2 {     // soft box on one input: 0 lower, 1 upper, 2 sl>=0, 3 su>=0
     double t[4], lam[4], du, sl, su, dl, duu, r;
     double it[4], il[4], iG02, iG13;               // reciprocals, refreshed once per iteration
-    double rc[4], rd[4], rsl, rsu, ru, e1, e2, dt[4], dlam[4], dsl, dsu;
+    double rc[4], ru, dt[4], dlam[4], dsl, dsu;
+    // primal residuals of the four inequalities and of the slack stationarity are cheap: recomputed where needed
+    __device__ __forceinline__ double rd0() const { return du + sl - dl - t[0]; }
+    __device__ __forceinline__ double rd1() const { return -du + su + duu - t[1]; }
+    __device__ __forceinline__ double rd2() const { return sl - t[2]; }
+    __device__ __forceinline__ double rd3() const { return su - t[3]; }
 };
 struct DSet2 {     // hard box on delta of one stage
     double t[2], lam[2], dl, du, dx6, rx6;
-    double it[2], il[2], rc[2], rd[2], dt[2], dlam[2];
+    double it[2], il[2], rc[2], dt[2], dlam[2];
+    __device__ __forceinline__ double rd0() const { return dx6 - dl - t[0]; }
+    __device__ __forceinline__ double rd1() const { return du - dx6 - t[1]; }
 };
 struct XTask {     // one state entry (k,i), k = 1..N
-    double xbar, xref, dx, w;   // w: cost weight of this entry (Ts*q_i, terminal W_e for k = N)
-    int k, i;      // k = 0 marks an unused slot
+    double q0, dx, w;   // q0 = w*(xbar - xref): gradient of the GN model at the iterate; w: Ts*q_i (terminal W_e for k = N)
+    int k, i;           // k = 0 marks an unused slot
 };
 
-template <int UPL, int TPL>
-__global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+template <int UPL, int TPL, int NT>     // NT > 0: horizon known at compile time (all LDS offsets fold to constants)
+__global__ __launch_bounds__(WAVE, (NT > 0 ? 2 : 1)) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                         const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                         const double* __restrict__ yrefeg,
                                                         const double* __restrict__ GTg, const double* __restrict__ blg,
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
 {
     extern __shared__ double lds_raw[];
     const int lane = threadIdx.x;
-    const int N = cfg->N;
+    const int N = NT > 0 ? NT : cfg->N;
     Lds2 L;
     lds2_carve(lds_raw, N, L);
     const double Ts = cfg->Ts;
@@ -550,10 +563,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
             const int tt = on ? t : 0;
             const int k = tt / 7 + 1, i = tt % 7;
             T[m].k = on ? k : 0; T[m].i = i;
-            T[m].xbar = xbg[7 + tt];
-            T[m].xref = k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i];
-            T[m].dx = 0.0;
             T[m].w = k < N ? sel7(Qd, i) : sel7(Qe, i);
+            T[m].q0 = T[m].w * (xbg[7 + tt] - (k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i]));
+            T[m].dx = 0.0;
         }
         USet2 U[UPL];
 #pragma unroll
@@ -619,15 +631,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
 #pragma unroll
                     for (int l = 0; l < 6; ++l) a += bcol[l] * pik[l];
                     s.ru = a;
-                    s.rsl = rho_l - s.lam[0] - s.lam[2];
-                    s.rsu = rho_u - s.lam[1] - s.lam[3];
-                    s.rd[0] = s.du + s.sl - s.dl - s.t[0];
-                    s.rd[1] = -s.du + s.su + s.duu - s.t[1];
-                    s.rd[2] = s.sl - s.t[2];
-                    s.rd[3] = s.su - s.t[3];
-                    rmax = OpMaxNan::f(rmax, fabs(s.ru)); rmax = OpMaxNan::f(rmax, fabs(s.rsl)); rmax = OpMaxNan::f(rmax, fabs(s.rsu));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) rmax = OpMaxNan::f(rmax, fabs(s.rd[i]));
+                    rmax = OpMaxNan::f(rmax, fabs(s.ru));
+                    rmax = OpMaxNan::f(rmax, fabs(rho_l - s.lam[0] - s.lam[2])); rmax = OpMaxNan::f(rmax, fabs(rho_u - s.lam[1] - s.lam[3]));
+                    rmax = OpMaxNan::f(rmax, fabs(s.rd0())); rmax = OpMaxNan::f(rmax, fabs(s.rd1()));
+                    rmax = OpMaxNan::f(rmax, fabs(s.rd2())); rmax = OpMaxNan::f(rmax, fabs(s.rd3()));
                 }
             }
 #pragma unroll
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
                     const int k = tk.k, i = tk.i;
                     double a;
                     if (k < N) {
-                        a = tk.w * (tk.dx + (tk.xbar - tk.xref)) - L.pi[(k - 1) * 7 + i];
+                        a = tk.w * tk.dx + tk.q0 - L.pi[(k - 1) * 7 + i];
                         const double* pik = L.pi + k * 7;
                         if (i < 2) a += pik[i];
                         else {
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
                             if (i == 6) a += pik[6];
                         }
                     } else {
-                        a = tk.w * (tk.dx + (tk.xbar - tk.xref)) - L.pi[(N - 1) * 7 + i];
+                        a = tk.w * tk.dx + tk.q0 - L.pi[(N - 1) * 7 + i];
                     }
                     L.gx[(k - 1) * 7 + i] = a;
                     if (!(k < N && i == 6)) rmax = OpMaxNan::f(rmax, fabs(a));
@@ -663,9 +670,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
             WSYNC();
             if (dact) {
                 D.rx6 = L.gx[(lane - 1) * 7 + 6] - D.lam[0] + D.lam[1];
-                D.rd[0] = D.dx6 - D.dl - D.t[0];
-                D.rd[1] = D.du - D.dx6 - D.t[1];
-                rmax = OpMaxNan::f(rmax, fabs(D.rx6)); rmax = OpMaxNan::f(rmax, fabs(D.rd[0])); rmax = OpMaxNan::f(rmax, fabs(D.rd[1]));
+                rmax = OpMaxNan::f(rmax, fabs(D.rx6)); rmax = OpMaxNan::f(rmax, fabs(D.rd0())); rmax = OpMaxNan::f(rmax, fabs(D.rd1()));
             }
             const double mu = wave_reduce<OpSum>(musum) * inv_nineq;
             cmax = wave_reduce<OpMax>(cmax);
@@ -686,10 +691,11 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
                     if (sid < nu_sets) {
                         const double G0 = s.lam[0] * s.it[0], G1 = s.lam[1] * s.it[1], G2 = s.lam[2] * s.it[2], G3 = s.lam[3] * s.it[3];
                         const double c0 = s.rc[0] * s.it[0], c1 = s.rc[1] * s.it[1], c2 = s.rc[2] * s.it[2], c3 = s.rc[3] * s.it[3];
-                        s.e1 = s.rsl + c0 + c2 + G0 * s.rd[0] + G2 * s.rd[2];
-                        s.e2 = s.rsu + c1 + c3 + G1 * s.rd[1] + G3 * s.rd[3];
-                        const double etal = c0 + G0 * s.rd[0] - G0 * s.e1 * s.iG02;
-                        const double etau = -c1 - G1 * s.rd[1] + G1 * s.e2 * s.iG13;
+                        const double rd0 = s.rd0(), rd1 = s.rd1();
+                        const double e1 = (rho_l - s.lam[0] - s.lam[2]) + c0 + c2 + G0 * rd0 + G2 * s.rd2();
+                        const double e2 = (rho_u - s.lam[1] - s.lam[3]) + c1 + c3 + G1 * rd1 + G3 * s.rd3();
+                        const double etal = c0 + G0 * rd0 - G0 * e1 * s.iG02;
+                        const double etau = -c1 - G1 * rd1 + G1 * e2 * s.iG13;
                         if (pass == 0) L.Rt[sid] = ((sid & 1) ? Rd[1] : Rd[0]) + G0 * G2 * s.iG02 + G1 * G3 * s.iG13;
                         L.guk[sid] = s.ru + etal + etau;
                     }
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
                 if (dact) {
                     const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
                     if (pass == 0) L.Qt[lane] = Qd[6] + G5 + G6;
-                    L.gx[(lane - 1) * 7 + 6] = D.rx6 + (D.rc[0] * D.it[0] + G5 * D.rd[0]) - (D.rc[1] * D.it[1] + G6 * D.rd[1]);
+                    L.gx[(lane - 1) * 7 + 6] = D.rx6 + (D.rc[0] * D.it[0] + G5 * D.rd0()) - (D.rc[1] * D.it[1] + G6 * D.rd1());
                 }
                 WSYNC();
                 if (pass == 0) riccati_factor_fused(L, N, lane, R);
@@ -713,9 +719,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
                     if (sid < nu_sets) {
                         const double G[4] = { s.lam[0] * s.it[0], s.lam[1] * s.it[1], s.lam[2] * s.it[2], s.lam[3] * s.it[3] };
                         const double u = L.guk[sid];
-                        s.dsl = -(s.e1 + G[0] * u) * s.iG02;
-                        s.dsu = -(s.e2 - G[1] * u) * s.iG13;
-                        s.dt[0] = u + s.dsl + s.rd[0]; s.dt[1] = -u + s.dsu + s.rd[1]; s.dt[2] = s.dsl + s.rd[2]; s.dt[3] = s.dsu + s.rd[3];
+                        const double rd0 = s.rd0(), rd1 = s.rd1(), rd2 = s.rd2(), rd3 = s.rd3();
+                        const double e1 = (rho_l - s.lam[0] - s.lam[2]) + s.rc[0] * s.it[0] + s.rc[2] * s.it[2] + G[0] * rd0 + G[2] * rd2;
+                        const double e2 = (rho_u - s.lam[1] - s.lam[3]) + s.rc[1] * s.it[1] + s.rc[3] * s.it[3] + G[1] * rd1 + G[3] * rd3;
+                        s.dsl = -(e1 + G[0] * u) * s.iG02;
+                        s.dsu = -(e2 - G[1] * u) * s.iG13;
+                        s.dt[0] = u + s.dsl + rd0; s.dt[1] = -u + s.dsu + rd1; s.dt[2] = s.dsl + rd2; s.dt[3] = s.dsu + rd3;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             s.dlam[i] = -s.rc[i] * s.it[i] - G[i] * s.dt[i];
@@ -726,8 +735,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
                 if (dact) {
                     const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
                     const double x6 = L.ddx[(lane - 1) * 7 + 6];
-                    D.dt[0] = x6 + D.rd[0];  D.dlam[0] = -D.rc[0] * D.it[0] - G5 * D.dt[0];
-                    D.dt[1] = -x6 + D.rd[1]; D.dlam[1] = -D.rc[1] * D.it[1] - G6 * D.dt[1];
+                    D.dt[0] = x6 + D.rd0();  D.dlam[0] = -D.rc[0] * D.it[0] - G5 * D.dt[0];
+                    D.dt[1] = -x6 + D.rd1(); D.dlam[1] = -D.rc[1] * D.it[1] - G6 * D.dt[1];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) rr = fmax(rr, fmax(-D.dt[i] * D.it[i], -D.dlam[i] * D.il[i]));
                 }
@@ -810,8 +819,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
         }
         // ---- H6: full step, outputs
         bool bad = failed;
+        double xnew[TPL];
 #pragma unroll
-        for (int m = 0; m < TPL; ++m) if (T[m].k) { const double v = T[m].xbar + T[m].dx; if (!(fabs(v) <= 1e300)) bad = true; }
+        for (int m = 0; m < TPL; ++m) {
+            xnew[m] = 0.0;
+            if (T[m].k) { xnew[m] = xbg[7 + lane + WAVE * m] + T[m].dx; if (!(fabs(xnew[m]) <= 1e300)) bad = true; }
+        }
 #pragma unroll
         for (int m = 0; m < UPL; ++m) {
             const int sid = lane + WAVE * m;
@@ -830,9 +843,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_kernel(const AdmpcConfig* __
             }
 #pragma unroll
             for (int m = 0; m < TPL; ++m) if (T[m].k) {
-                const double v = T[m].xbar + T[m].dx, e = v - T[m].xref;
+                const int k = T[m].k, i = T[m].i;
+                const double e = xnew[m] - (k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i]);
                 J += 0.5 * T[m].w * e * e;
-                xo[7 + lane + WAVE * m] = v;
+                xo[7 + lane + WAVE * m] = xnew[m];
             }
 #pragma unroll
             for (int m = 0; m < UPL; ++m) {
@@ -1036,9 +1050,10 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     e = hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcConfig), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_cfg); delete s; return fail(ADMPC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     // opt in to > 64 KB of dynamic LDS
-    const void* kerns[4] = { (const void*)admpc_qp_kernel<1, 3>, (const void*)admpc_qp_kernel<1, 4>,
-                             (const void*)admpc_qp_kernel<2, 5>, (const void*)admpc_qp_kernel<2, 7> };
-    for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 0>, (const void*)admpc_qp_kernel<1, 4, 0>,
+                             (const void*)admpc_qp_kernel<2, 5, 0>, (const void*)admpc_qp_kernel<2, 7, 0>,
+                             (const void*)admpc_qp_kernel<1, 3, 20>, (const void*)admpc_qp_kernel<2, 5, 40> };
+    for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
 }
@@ -1094,12 +1109,14 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
         const int first = sq == 0 ? 1 : 0;
         hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(256), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl);
-#define LAUNCH_QP(U_, T_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
+#define LAUNCH_QP(U_, T_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
-        if (N <= 27) LAUNCH_QP(1, 3);
-        else if (N <= 32) LAUNCH_QP(1, 4);
-        else if (N <= 45) LAUNCH_QP(2, 5);
-        else LAUNCH_QP(2, 7);
+        if (N == 20) LAUNCH_QP(1, 3, 20);          // the reference's Python default (ad_3d_mpc.py:23)
+        else if (N == 40) LAUNCH_QP(2, 5, 40);     // the reference's launch file (gp_ad_mpc.launch:6-7)
+        else if (N <= 27) LAUNCH_QP(1, 3, 0);
+        else if (N <= 32) LAUNCH_QP(1, 4, 0);
+        else if (N <= 45) LAUNCH_QP(2, 5, 0);
+        else LAUNCH_QP(2, 7, 0);
 #undef LAUNCH_QP
     }
     HIPCHK(hipGetLastError());
