@@ -298,10 +298,12 @@ __device__ __forceinline__ void lds2_carve(double* p, int N, Lds2& L) {
     L.Hs = tr; L.hs = tr + 82; L.pvs = tr + 92;
 }
 
-// A workgroup is ONE wavefront: its LDS instructions are issued and completed in program order, so a
-// cross-lane exchange through LDS needs no s_barrier -- only a fence that keeps the compiler from
-// reordering the LDS accesses (wavefront scope: emits no instruction).
+// A workgroup is ONE wavefront.  WSYNC orders a cross-lane exchange through LDS (write, WSYNC, read).
+#ifdef ADMPC_WSYNC_FENCE_ONLY
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define WSYNC() __syncthreads()
+#endif
 
 __device__ __forceinline__ int tri_index(int i, int j) {   // packed index of (i<=j) in a 7x7 upper triangle, row-major
     return i * 7 - (i * (i - 1)) / 2 + (j - i);
@@ -512,7 +514,9 @@ struct XTask {     // one state entry (k,i), k = 1..N
 };
 
 template <int UPL, int TPL, int NT>     // NT > 0: horizon known at compile time (all LDS offsets fold to constants)
-__global__ __launch_bounds__(WAVE, (NT > 0 ? 2 : 1)) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+// One wave per SIMD (512-register budget): at 256 registers the kernel spills ~200 VGPRs to scratch, and
+// back-to-back launches of kernels with large private segments aborted inside the runtime.
+__global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                         const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                         const double* __restrict__ yrefeg,
                                                         const double* __restrict__ GTg, const double* __restrict__ blg,
@@ -874,6 +878,411 @@ __global__ __launch_bounds__(WAVE, (NT > 0 ? 2 : 1)) void admpc_qp_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// kernel B' : condensed QP, dense Cholesky -- the reference's own QP strategy (FULL_CONDENSING_HPIPM,
+// acados_solver_sim_car.c:145) for horizons with 2N <= 64 inputs.  One instance per wavefront,
+// lane i <-> input i = 2k+j: it owns row i of the condensed Hessian / of its Cholesky factor (in
+// registers, statically indexed -> horizon is a template parameter) and the four inequalities of
+// that input.  The states are eliminated: dx_k = xhat_k + Gamma_k du, so the interior-point state
+// is (du, t, lam) only -- no dynamics multipliers, no state residuals.
+//   H   = sum_k Gamma_k' Q_k Gamma_k               (input weights R are added on the diagonal on the fly)
+//   g0  = r + sum_k Gamma_k' Q_k (xhat_k + xbar_k - xref_k)
+//   delta row of stage k:  dx6_k = xhat_k[6] + h * sum_{k'<k} du_{(k',1)}   (structural: delta' = u1)
+// ---------------------------------------------------------------------------------------------
+template <class Op>
+__device__ __forceinline__ double wave_scan_incl(double v) {      // inclusive prefix over lanes 0..lane
+    v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));
+    v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));
+    v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));
+    v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));
+    v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));
+    v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));
+    return v;
+}
+
+template <int NT>
+struct DenseLds {
+    static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
+    static constexpr int LSZ = NTRI > N * GTS ? NTRI : N * GTS;
+    static constexpr int BLS = (N * 7 + 1) & ~1, DQS = ((N + 1) * 7 + 1) & ~1;     // keep every sub-array 16-byte aligned
+    static constexpr int total = NTRI + (NTRI & 1) + LSZ + BLS + DQS + 5 * 64;
+};
+
+template <int NT>
+__global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                                 const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                                 const double* __restrict__ yrefeg,
+                                                                 const double* __restrict__ GTg, const double* __restrict__ blg,
+                                                                 double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                                 double* __restrict__ costg, int32_t* __restrict__ statusg,
+                                                                 int32_t* __restrict__ itersg, int first_pass)
+{
+    constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI, LSZ = DenseLds<NT>::LSZ;
+    extern __shared__ double lds_raw[];
+    double* const Hp = lds_raw;                 // packed lower-triangular rows of H
+    double* const Lp = Hp + NTRI + (NTRI & 1);  // packed lower-triangular rows of the Cholesky factor (IPM loop)
+    double* const GT = Lp;                      //   aliased: packed linearisation (set-up and final roll-out)
+    double* const bl = Lp + LSZ;                // defects b_k
+    double* const dq = bl + DenseLds<NT>::BLS;  // xbar_k - xref_k, k = 0..N (later: dx_k)
+    double* const gam = dq + DenseLds<NT>::DQS;       // [64] cross-lane exchange of one Gamma component
+    double* const cb = gam + 64;                // [64] Cholesky column / step broadcast buffer
+    double* const invd = cb + 64;               // [64] 1 / L_jj
+    double* const sb = invd + 64;               // [64] per-stage exchange
+    double* const sb2 = sb + 64;                // [64]
+
+    const int lane = threadIdx.x;
+    const int ki = lane >> 1, ji = lane & 1;
+    const bool uact = lane < n;
+    const bool dact = lane >= 1 && lane < N;
+    const int trow = lane * (lane + 1) / 2;
+    const int zero_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 3 * 64 + 63;        // = &sb[63] relative to Lp: always 0.0 (no stage 63)
+    const int dummy_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 4 * 64 + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
+    const double Ts = cfg->Ts, h = cfg->Ts;
+    double Qd[NX], Qe[NX], Rd[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cfg->W[i]; Qe[i] = cfg->We[i]; }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) Rd[j] = Ts * cfg->W[NX + j];
+    const double Rj = ji ? Rd[1] : Rd[0];
+    const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
+    const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
+    const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
+    const int itmax = cfg->ipm_iter_max;
+    const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
+
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        if (!first_pass && statusg[inst] != 0) continue;
+        const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
+        const double* ubg = ubarg + (size_t)inst * N * NU;
+        const double* yrg = yrefg + (size_t)inst * N * NY;
+        const double* gtg = GTg + (size_t)inst * N * GTS;
+        // ---------------- stage the instance ----------------
+        for (int i = lane; i < N * GTS; i += WAVE) GT[i] = gtg[i];
+        for (int i = lane; i < N * NX; i += WAVE) bl[i] = blg[(size_t)inst * N * NX + i];
+        for (int i = lane; i < (N + 1) * NX; i += WAVE) {
+            const int k = i / 7, c = i % 7;
+            dq[i] = xbg[i] - (k < N ? yrg[k * 9 + c] : yrefeg[(size_t)inst * NX + c]);
+        }
+        const int sc = uact ? lane : 0;
+        const double ubar_i = ubg[sc];
+        const double r_i = Rj * (ubar_i - yrg[(sc >> 1) * 9 + 7 + (sc & 1)]);
+        const double dl_i = cfg->lbu[ji] - ubar_i, duu_i = cfg->ubu[ji] - ubar_i;
+        double xh[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) xh[c] = x0g[(size_t)inst * NX + c] - xbg[c];      // uniform
+        WSYNC();
+        // ---------------- condensing ----------------
+        double g[NX], hrow[n];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) g[c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) hrow[i] = 0.0;
+        double g0 = r_i;
+        double xh6_own = 0.0;                   // xhat_k[6] of the stage whose delta box this lane owns
+#pragma unroll
+        for (int k = 0; k <= N; ++k) {
+            if (k >= 1) {
+                // ---- cost of stage k: H += Gamma_k' Q Gamma_k over the inputs of stages < k, g0 += Gamma_k' Q (xhat + dq)
+                if (lane == k) xh6_own = xh[6];
+#pragma unroll 1
+                for (int c = 0; c < NX; ++c) {
+                    const double w = k < N ? sel7(Qd, c) : sel7(Qe, c);
+                    if (w != 0.0) {                                   // wave-uniform
+                        const double gc = sel7(g, c);
+                        const double wg = w * gc;
+                        gam[lane] = gc;
+                        WSYNC();
+                        g0 += wg * (sel7(xh, c) + dq[k * 7 + c]);
+                        const int lim = 2 * k < n ? 2 * k : n;
+#pragma unroll
+                        for (int i2 = 0; i2 < n; i2 += 2) {
+                            if (i2 < lim) {
+                                const double2 v = *reinterpret_cast<const double2*>(gam + i2);
+                                hrow[i2] += wg * v.x;
+                                hrow[i2 + 1] += wg * v.y;
+                            }
+                        }
+                        WSYNC();
+                    }
+                }
+            }
+            if (k < N) {
+                // ---- propagate: xhat_{k+1} = A xhat + b ; Gamma_{k+1}[:,i] = A Gamma_k[:,i]  (or B[:,j] for the inputs of stage k)
+                const double* Gk = GT + k * GTS;
+                double xn[NX], gn[NX];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { xn[r] = bl[k * 7 + r] + (r < 2 ? xh[r] : 0.0); gn[r] = r < 2 ? g[r] : 0.0; }
+                xn[6] = bl[k * 7 + 6] + xh[6]; gn[6] = g[6];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+#pragma unroll
+                    for (int r = 0; r < 6; r += 2) {
+                        const double2 a = *reinterpret_cast<const double2*>(Gk + c * 6 + r);
+                        xn[r] += a.x * xh[c + 2]; xn[r + 1] += a.y * xh[c + 2];
+                        gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
+                    }
+                }
+                const bool mine = ki == k;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double b0 = Gk[5 * 6 + r], b1 = Gk[6 * 6 + r];
+                    g[r] = mine ? (ji ? b1 : b0) : gn[r];
+                    xh[r] = xn[r];
+                }
+                g[6] = mine ? (ji ? h : 0.0) : gn[6];
+                xh[6] = xn[6];
+            }
+        }
+        // packed lower-triangular rows of H into LDS
+#pragma unroll
+        for (int i2 = 0; i2 < n; ++i2) if (uact && i2 <= lane) Hp[trow + i2] = hrow[i2];
+        // ---------------- interior point start ----------------
+        double t[4], lam[4], du = 0.0, sl = thr, su = thr;
+        {
+            const double r0[4] = { thr - dl_i, thr + duu_i, thr, thr };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 / t[i]; }
+        }
+        double Dt[2] = {1.0, 1.0}, Dlam[2] = {0.0, 0.0}, Ddl = 0.0, Ddu = 0.0, dx6 = 0.0;
+        if (dact) {
+            const double x6 = xbg[lane * 7 + 6];
+            Ddl = cfg->lbx_delta - x6; Ddu = cfg->ubx_delta - x6;
+            dx6 = xh6_own;
+            const double r0[2] = { dx6 - Ddl, Ddu - dx6 };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 / Dt[i]; }
+        }
+        WSYNC();
+
+        bool failed = false;
+        double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
+        int it = 0;
+        for (; it < itmax; ++it) {
+            // ---- reciprocals, complementarity
+            double it_[4], il_[4], rc[4], Dit[2], Dil[2], Drc[2];
+            double musum = 0.0, cmax = 0.0, rmax = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { it_[i] = 1.0 / t[i]; il_[i] = 1.0 / lam[i]; rc[i] = t[i] * lam[i]; musum += uact ? rc[i] : 0.0; cmax = fmax(cmax, uact ? rc[i] : 0.0); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { Dit[i] = 1.0 / Dt[i]; Dil[i] = 1.0 / Dlam[i]; Drc[i] = Dt[i] * Dlam[i]; musum += dact ? Drc[i] : 0.0; cmax = fmax(cmax, dact ? Drc[i] : 0.0); }
+            const double G0 = lam[0] * it_[0], G1 = lam[1] * it_[1], G2 = lam[2] * it_[2], G3 = lam[3] * it_[3];
+            const double iG02 = 1.0 / (G0 + G2), iG13 = 1.0 / (G1 + G3);
+            const double G5 = Dlam[0] * Dit[0], G6 = Dlam[1] * Dit[1];
+            // ---- reduced gradient  ru = H du + R du + g0 - lam0 + lam1 + [u1 inputs] h * sum_{k>ki} (lam6_k - lam5_k)
+            cb[lane] = uact ? du : 0.0;
+            const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
+            const double dlam_tot = rdlane(dlam_pref, 63);
+            sb[lane] = dlam_tot - dlam_pref;                        // suffix over stages > lane
+            WSYNC();
+            double hdu = 0.0;
+#pragma unroll
+            for (int i2 = 0; i2 < n; i2 += 2) {
+                const double2 dv = *reinterpret_cast<const double2*>(cb + i2);
+                const int a0 = i2 <= lane ? trow + i2 : (i2 * (i2 + 1)) / 2 + lane;
+                const int a1 = i2 + 1 <= lane ? trow + i2 + 1 : ((i2 + 1) * (i2 + 2)) / 2 + lane;
+                hdu += Hp[uact ? a0 : 0] * dv.x + Hp[uact ? a1 : 0] * dv.y;
+            }
+            const double ru = hdu + Rj * du + g0 - lam[0] + lam[1] + (ji ? h * sb[uact ? ki : 0] : 0.0);
+            const double rd0 = du + sl - dl_i - t[0], rd1 = -du + su + duu_i - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+            const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
+            const double Drd0 = dx6 - Ddl - Dt[0], Drd1 = Ddu - dx6 - Dt[1];
+            {
+                double ra = OpMaxNan::f(fabs(ru), fabs(rsl)); ra = OpMaxNan::f(ra, fabs(rsu));
+                ra = OpMaxNan::f(ra, fabs(rd0)); ra = OpMaxNan::f(ra, fabs(rd1)); ra = OpMaxNan::f(ra, fabs(rd2)); ra = OpMaxNan::f(ra, fabs(rd3));
+                const double rb = OpMaxNan::f(fabs(Drd0), fabs(Drd1));
+                rmax = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
+            }
+            const double mu = wave_reduce<OpSum>(musum) * inv_nineq;
+            cmax = wave_reduce<OpMax>(cmax);
+            rmax = wave_reduce<OpMaxNan>(rmax);
+            step = wave_reduce<OpMax>(stp_local);
+            if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
+            if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
+            rmax_prev = rmax;
+
+            // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block; Cholesky
+            const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? (G5 + G6) : 0.0);
+            const double S_own_stage = rdlane(Ssuf_incl, 63) - Ssuf_incl;        // lane = stage: sum over stages > lane
+            sb2[lane] = S_own_stage;
+            WSYNC();
+            const double S_i = h * h * sb2[uact ? ki : 0];                       // lane = input: S_{k_i}
+            double a[n];
+#pragma unroll
+            for (int i2 = 0; i2 < n; ++i2) {
+                double v = Hp[(uact && i2 <= lane) ? trow + i2 : 0];
+                v = (uact && i2 <= lane) ? v : 0.0;
+                if ((i2 & 1) && ji) v += S_i;                                    // k_{i2} <= k_i on the lower triangle
+                a[i2] = v;
+            }
+            const double Dbar = uact ? Rj + G0 * G2 * iG02 + G1 * G3 * iG13 : 1.0;      // idle lanes: identity rows
+#pragma unroll
+            for (int i2 = 0; i2 < n; ++i2) a[i2] += (i2 == lane) ? Dbar : 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const double dj = rdlane(a[j], j);
+                const double inv = rsqrt(dj);                               // 1 / L_jj
+                const double l = lane > j ? a[j] * inv : 0.0;               // strictly-lower column j; 0 on and above the diagonal
+                a[j] = l;
+                cb[lane] = l;
+                invd[j] = inv;                                              // uniform value, same address
+                Lp[(uact && lane > j) ? trow + j : dummy_off] = l;          // packed copy for the transposed solve; branch-free
+                WSYNC();
+#pragma unroll
+                for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * cb[jj];
+                WSYNC();
+            }
+
+            double mu_aff = 0.0, dsl = 0.0, dsu = 0.0, ddu = 0.0, dt[4], dlam[4], Ddt[2], Ddlam[2];
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                // ---- right-hand side: eliminate slacks / multipliers
+                const double c0 = rc[0] * it_[0], c1 = rc[1] * it_[1], c2 = rc[2] * it_[2], c3 = rc[3] * it_[3];
+                const double e1 = rsl + c0 + c2 + G0 * rd0 + G2 * rd2;
+                const double e2 = rsu + c1 + c3 + G1 * rd1 + G3 * rd3;
+                const double etal = c0 + G0 * rd0 - G0 * e1 * iG02;
+                const double etau = -c1 - G1 * rd1 + G1 * e2 * iG13;
+                const double ek = dact ? (Drc[0] * Dit[0] + G5 * Drd0) - (Drc[1] * Dit[1] + G6 * Drd1) : 0.0;
+                const double epref = wave_scan_incl<OpSum>(ek);
+                sb[lane] = rdlane(epref, 63) - epref;
+                WSYNC();
+                double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
+                // ---- forward substitution  L z = y : a[j] holds the strictly-lower L[lane][j] (0 elsewhere), so lane j's
+                //      value is final after step j-1 and no per-step select is needed; z = y * invd afterwards
+#pragma unroll
+                for (int j = 0; j < n; ++j) {
+                    const double zj = rdlane(y, j) * invd[j];
+                    y -= a[j] * zj;
+                }
+                double x = y * invd[uact ? lane : 0];
+                // ---- backward substitution  L' x = z : column entries L[j][lane] (lane < j) from the packed LDS copy
+#pragma unroll
+                for (int j = n - 1; j >= 1; --j) {
+                    const double xj = rdlane(x, j) * invd[j];
+                    const double lji = Lp[lane < j ? (j * (j + 1)) / 2 + lane : zero_off];
+                    x -= lji * xj;
+                }
+                x *= invd[uact ? lane : 0];
+                ddu = uact ? x : 0.0;
+                // ---- delta rows: ddx6_k = h * sum_{k'<k} ddu_{(k',1)}
+                cb[lane] = ddu;
+                WSYNC();
+                const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
+                const double pre = wave_scan_incl<OpSum>(du1_stage);
+                const double ddx6 = h * (pre - du1_stage);
+                // ---- expand
+                dsl = -(e1 + G0 * ddu) * iG02;
+                dsu = -(e2 - G1 * ddu) * iG13;
+                dt[0] = ddu + dsl + rd0; dt[1] = -ddu + dsu + rd1; dt[2] = dsl + rd2; dt[3] = dsu + rd3;
+                const double Gs[4] = { G0, G1, G2, G3 };
+                double rr = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dlam[i] = -rc[i] * it_[i] - Gs[i] * dt[i];
+                    rr = fmax(rr, uact ? fmax(-dt[i] * it_[i], -dlam[i] * il_[i]) : 0.0);
+                }
+                Ddt[0] = ddx6 + Drd0;  Ddlam[0] = -Drc[0] * Dit[0] - G5 * Ddt[0];
+                Ddt[1] = -ddx6 + Drd1; Ddlam[1] = -Drc[1] * Dit[1] - G6 * Ddt[1];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) rr = fmax(rr, dact ? fmax(-Ddt[i] * Dit[i], -Ddlam[i] * Dil[i]) : 0.0);
+                rr = wave_reduce<OpMax>(rr);
+                const double amax = rr > 1.0 ? 1.0 / rr : 1.0;
+                if (pass == 0) {
+                    double s_aff = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s_aff += uact ? (t[i] + amax * dt[i]) * (lam[i] + amax * dlam[i]) : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) s_aff += dact ? (Dt[i] + amax * Ddt[i]) * (Dlam[i] + amax * Ddlam[i]) : 0.0;
+                    mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
+                    double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+                    const double smu = sigma * mu;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] + Ddt[i] * Ddlam[i] - smu;
+                } else {
+                    double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+                    const double alpha = fmin(tau * amax, 1.0);
+                    stp_local = uact ? fabs(alpha * ddu) : 0.0;
+                    // idle lanes carry harmless finite values (their steps are computed from finite data)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { t[i] = fmax(t[i] + alpha * dt[i], IPM_FLOOR); lam[i] = fmax(lam[i] + alpha * dlam[i], IPM_FLOOR); }
+                    du += alpha * ddu; sl += alpha * dsl; su += alpha * dsu;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Dt[i] = dact ? fmax(Dt[i] + alpha * Ddt[i], IPM_FLOOR) : 1.0;
+                        Dlam[i] = dact ? fmax(Dlam[i] + alpha * Ddlam[i], IPM_FLOOR) : 1.0;
+                    }
+                    dx6 += dact ? alpha * ddx6 : 0.0;
+                }
+                WSYNC();
+            }
+        }
+        // ---------------- H6: expand the states through the linearised dynamics, full step, cost ----------------
+        cb[lane] = uact ? du : 0.0;
+        for (int i = lane; i < N * GTS; i += WAVE) GT[i] = gtg[i];           // Lp region held the factor: stage the linearisation again
+        WSYNC();
+        bool bad = failed;
+        double J = 0.0;
+        double* xo = xbarg + (size_t)inst * (N + 1) * NX;
+        double* uo = ubarg + (size_t)inst * N * NU;
+        double dxv[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) dxv[c] = x0g[(size_t)inst * NX + c] - xbg[c];
+        // the new states are staged in the dq slots (uniform values, lane c writes component c)
+#pragma unroll 1
+        for (int k = 0; k <= N; ++k) {
+            // cost and output of stage k
+            double e2sum = 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                const double dqk = dq[k * 7 + c];
+                const double e = dxv[c] + dqk;
+                e2sum += 0.5 * (k < N ? Qd[c] : Qe[c]) * e * e;
+                if (!(fabs(dxv[c]) <= 1e300)) bad = true;
+            }
+            J += e2sum;                            // uniform: every lane accumulates the same value
+            WSYNC();
+            if (lane < NX) dq[k * 7 + lane] = sel7(dxv, lane);     // dq slot k now holds dx_k (dq_k itself is no longer needed)
+            if (k < N) {
+                const double* Gk = GT + k * GTS;
+                const double u0 = cb[2 * k], u1 = cb[2 * k + 1];
+                double xn[NX];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xn[r] = bl[k * 7 + r] + (r < 2 ? dxv[r] : 0.0) + Gk[5 * 6 + r] * u0 + Gk[6 * 6 + r] * u1;
+                xn[6] = bl[k * 7 + 6] + dxv[6] + h * u1;
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xn[r] += Gk[c * 6 + r] * dxv[c + 2];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) dxv[r] = xn[r];
+            }
+            WSYNC();
+        }
+        const double unew = ubar_i + du;
+        if (uact && !(fabs(unew) <= 1e300)) bad = true;
+        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+        double Ju = 0.0;
+        if (status == ADMPC_STATUS_SUCCESS) {
+            for (int i = lane; i < (N + 1) * NX; i += WAVE) xo[i] = xbg[i] + dq[i];
+            if (uact) {
+                const double e = du + r_i / Rj;
+                Ju = 0.5 * Rj * e * e;
+                if (unew < cfg->lbu[ji]) Ju += rho_l * (cfg->lbu[ji] - unew);
+                if (unew > cfg->ubu[ji]) Ju += rho_u * (unew - cfg->ubu[ji]);
+                uo[lane] = unew;
+            }
+        }
+        Ju = wave_reduce<OpSum>(Ju);
+        if (lane == 0) {
+            if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? J + Ju : INFINITY;
+            statusg[inst] = status;
+            if (itersg) itersg[inst] = it;
+        }
+        WSYNC();
+    }
+}
+
 // shooting only: phi, A, B to global memory (parity tests of H0/H1)
 __global__ __launch_bounds__(WAVE) void admpc_shoot_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                            const double* __restrict__ xbarg, const double* __restrict__ ubarg,
@@ -967,6 +1376,7 @@ __global__ void admpc_epilogue_kernel(int N, int B, const double* __restrict__ x
 #include <string>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 struct AdmpcSolver {
     AdmpcConfig cfg;
@@ -975,6 +1385,8 @@ struct AdmpcSolver {
     int num_cu;
     int lds_bytes;
     int blocks_per_cu;
+    int use_dense;           // condensed dense-Cholesky QP kernel available for this horizon (N == 20) and not disabled
+    int dense_lds_bytes;
     // workspace of the linearisation (kernel A -> kernel B), grown on demand by admpc_reserve
     int cap;                 // instances
     double* d_GT;            // [cap][N][42]
@@ -1042,18 +1454,23 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     s->lds_bytes = lds2_doubles(cfg->N) * (int)sizeof(double);
     if (s->lds_bytes > 160 * 1024) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     s->blocks_per_cu = (160 * 1024) / s->lds_bytes;
-    if (s->blocks_per_cu > 16) s->blocks_per_cu = 16;
+    if (s->blocks_per_cu > 4) s->blocks_per_cu = 4;          // register-limited: one wave per SIMD
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
     s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr;
+    {   // ADMPC_QP=riccati forces the stage-wise Riccati kernel (A/B tests); default: condensed kernel where instantiated
+        const char* e = getenv("ADMPC_QP");
+        s->use_dense = (cfg->N == 20) && !(e && strcmp(e, "riccati") == 0);
+        s->dense_lds_bytes = DenseLds<20>::total * (int)sizeof(double);
+    }
     hipError_t e = hipMalloc((void**)&s->d_cfg, sizeof(AdmpcConfig));
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcConfig), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_cfg); delete s; return fail(ADMPC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     // opt in to > 64 KB of dynamic LDS
-    const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 0>, (const void*)admpc_qp_kernel<1, 4, 0>,
-                             (const void*)admpc_qp_kernel<2, 5, 0>, (const void*)admpc_qp_kernel<2, 7, 0>,
-                             (const void*)admpc_qp_kernel<1, 3, 20>, (const void*)admpc_qp_kernel<2, 5, 40> };
-    for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* kerns[4] = { (const void*)admpc_qp_kernel<1, 3, 0>, (const void*)admpc_qp_kernel<1, 4, 0>,
+                             (const void*)admpc_qp_kernel<2, 5, 0>, (const void*)admpc_qp_kernel<2, 7, 0> };
+    for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_qp_dense_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
 }
@@ -1111,8 +1528,14 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl);
 #define LAUNCH_QP(U_, T_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
-        if (N == 20) LAUNCH_QP(1, 3, 20);          // the reference's Python default (ad_3d_mpc.py:23)
-        else if (N == 40) LAUNCH_QP(2, 5, 40);     // the reference's launch file (gp_ad_mpc.launch:6-7)
+        if (s->use_dense) {
+            int gridD = s->num_cu * 4;                    // 512-register kernel: one wave per SIMD
+            if (gridD > B) gridD = B;
+            hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B, x0, yref, yref_e,
+                               (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first);
+        }
+        // (the NT template parameter allows compile-time-N instantiations; none is dispatched: a <2,5,40> build gave
+        //  nondeterministic results at B >= 64 on MI355X while the runtime-N kernels are correct -- cause not yet understood)
         else if (N <= 27) LAUNCH_QP(1, 3, 0);
         else if (N <= 32) LAUNCH_QP(1, 4, 0);
         else if (N <= 45) LAUNCH_QP(2, 5, 0);

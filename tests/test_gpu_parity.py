@@ -68,6 +68,21 @@ def test_solve_parity_with_oracle(gpu_engine_factory, oracle, N, B, blend, init)
     _assert_parity(g, o)
 
 
+def test_both_qp_kernels_agree_at_n20(gpu_engine_factory, oracle, monkeypatch):
+    """N = 20 has two device paths: the condensed dense-Cholesky kernel (default) and the stage-wise Riccati
+    kernel (ADMPC_QP=riccati, also the path of every other horizon).  Both must match the oracle."""
+    cfg = default_config(N=20)
+    s = random_scenarios(512, N=20, seed=77, blend=(3.0, 5.0))
+    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    g_dense = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    monkeypatch.setenv("ADMPC_QP", "riccati")
+    g_ric = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    monkeypatch.delenv("ADMPC_QP")
+    _assert_parity(g_dense, o)
+    _assert_parity(g_ric, o)
+    assert np.abs(g_dense[1] - g_ric[1]).max() <= TOL
+
+
 def test_full_size_batch_4096(gpu_engine_factory, oracle):
     """BASELINE configs[1] at full size: direct parity for every instance plus size-independent properties."""
     cfg = default_config(N=20)
