@@ -161,7 +161,7 @@ def main():
                        "collective": "RCCL all-gather arg-min (16 B/rank)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "admpc_solve_kernel", "kernel_ms": kern_ms,
+                         "kernel": "admpc_linearize_kernel + admpc_qp_dense_kernel<20> (one launch pair = one step)", "kernel_ms": kern_ms,
                          "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*mean_ipm_iters per solve (SURVEY 8d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N)},
