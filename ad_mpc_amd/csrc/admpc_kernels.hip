@@ -513,7 +513,7 @@ struct XTask {     // one state entry (k,i), k = 1..N
     int k, i;           // k = 0 marks an unused slot
 };
 
-template <int UPL, int TPL, int NT>     // NT > 0: horizon known at compile time (all LDS offsets fold to constants)
+template <int UPL, int TPL, int DPL, int NT>     // DPL: delta-box stages per lane; NT > 0: horizon known at compile time (all LDS offsets fold to constants)
 // One wave per SIMD (512-register budget): at 256 registers the kernel spills ~200 VGPRs to scratch, and
 // back-to-back launches of kernels with large private segments aborted inside the runtime.
 __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
@@ -541,7 +541,6 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
     const int itmax = cfg->ipm_iter_max;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
     const int nu_sets = 2 * N;
-    const bool dact = lane >= 1 && lane < N;
     Roles R;
     make_roles(lane, Ts, Qd, Qe, R);
 
@@ -585,9 +584,12 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
 #pragma unroll
             for (int i = 0; i < 4; ++i) { U[m].t[i] = r0[i] > thr ? r0[i] : thr; U[m].lam[i] = mu0 / U[m].t[i]; }
         }
-        DSet2 D;
-        {
-            const double x6 = xbg[(dact ? lane : 0) * 7 + 6];
+        DSet2 Dv[DPL];
+#define DSET_LOOP _Pragma("unroll") for (int md = 0; md < DPL; ++md)
+#define DSET_BIND DSet2& D = Dv[md]; const int dk = lane + WAVE * md; const bool dact = dk >= 1 && dk < N; (void)dact; (void)dk;
+        DSET_LOOP {
+            DSET_BIND
+            const double x6 = xbg[(dact ? dk : 0) * 7 + 6];
             D.dl = cfg->lbx_delta - x6; D.du = cfg->ubx_delta - x6;
         }
         const double dx0 = lane < NX ? x0g[(size_t)inst * NX + lane] - xbg[lane] : 0.0;
@@ -597,8 +599,9 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
         WSYNC();
 #pragma unroll
         for (int m = 0; m < TPL; ++m) if (T[m].k) T[m].dx = L.pv[(T[m].k - 1) * 7 + T[m].i];
-        {
-            D.dx6 = dact ? L.pv[(lane - 1) * 7 + 6] : 0.0;
+        DSET_LOOP {
+            DSET_BIND
+            D.dx6 = dact ? L.pv[(dk - 1) * 7 + 6] : 0.0;
             D.t[0] = D.t[1] = 1.0; D.lam[0] = D.lam[1] = 0.0; D.rx6 = 0.0;
             if (dact) {
                 const double r0[2] = { D.dx6 - D.dl, D.du - D.dx6 };
@@ -641,11 +644,14 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                     rmax = OpMaxNan::f(rmax, fabs(s.rd2())); rmax = OpMaxNan::f(rmax, fabs(s.rd3()));
                 }
             }
+            DSET_LOOP {
+                DSET_BIND
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                D.it[i] = 1.0 / D.t[i]; D.il[i] = 1.0 / D.lam[i];
-                D.rc[i] = D.t[i] * D.lam[i];
-                if (dact) { musum += D.rc[i]; cmax = fmax(cmax, D.rc[i]); }
+                for (int i = 0; i < 2; ++i) {
+                    D.it[i] = 1.0 / D.t[i]; D.il[i] = 1.0 / D.lam[i];
+                    D.rc[i] = D.t[i] * D.lam[i];
+                    if (dact) { musum += D.rc[i]; cmax = fmax(cmax, D.rc[i]); }
+                }
             }
             // ---- state stationarity rows (k,i), k = 1..N (the delta-bound multipliers are added by the owner lane)
 #pragma unroll
@@ -672,8 +678,10 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                 }
             }
             WSYNC();
-            if (dact) {
-                D.rx6 = L.gx[(lane - 1) * 7 + 6] - D.lam[0] + D.lam[1];
+            DSET_LOOP {
+                DSET_BIND
+                if (!dact) continue;
+                D.rx6 = L.gx[(dk - 1) * 7 + 6] - D.lam[0] + D.lam[1];
                 rmax = OpMaxNan::f(rmax, fabs(D.rx6)); rmax = OpMaxNan::f(rmax, fabs(D.rd0())); rmax = OpMaxNan::f(rmax, fabs(D.rd1()));
             }
             const double mu = wave_reduce<OpSum>(musum) * inv_nineq;
@@ -704,10 +712,12 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                         L.guk[sid] = s.ru + etal + etau;
                     }
                 }
-                if (dact) {
+                DSET_LOOP {
+                    DSET_BIND
+                    if (!dact) continue;
                     const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
-                    if (pass == 0) L.Qt[lane] = Qd[6] + G5 + G6;
-                    L.gx[(lane - 1) * 7 + 6] = D.rx6 + (D.rc[0] * D.it[0] + G5 * D.rd0()) - (D.rc[1] * D.it[1] + G6 * D.rd1());
+                    if (pass == 0) L.Qt[dk] = Qd[6] + G5 + G6;
+                    L.gx[(dk - 1) * 7 + 6] = D.rx6 + (D.rc[0] * D.it[0] + G5 * D.rd0()) - (D.rc[1] * D.it[1] + G6 * D.rd1());
                 }
                 WSYNC();
                 if (pass == 0) riccati_factor_fused(L, N, lane, R);
@@ -736,9 +746,11 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                         }
                     }
                 }
-                if (dact) {
+                DSET_LOOP {
+                    DSET_BIND
+                    if (!dact) continue;
                     const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
-                    const double x6 = L.ddx[(lane - 1) * 7 + 6];
+                    const double x6 = L.ddx[(dk - 1) * 7 + 6];
                     D.dt[0] = x6 + D.rd0();  D.dlam[0] = -D.rc[0] * D.it[0] - G5 * D.dt[0];
                     D.dt[1] = -x6 + D.rd1(); D.dlam[1] = -D.rc[1] * D.it[1] - G6 * D.dt[1];
 #pragma unroll
@@ -755,9 +767,12 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
 #pragma unroll
                             for (int i = 0; i < 4; ++i) s_aff += (s.t[i] + amax * s.dt[i]) * (s.lam[i] + amax * s.dlam[i]);
                     }
-                    if (dact)
+                    DSET_LOOP {
+                        DSET_BIND
+                        if (dact)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) s_aff += (D.t[i] + amax * D.dt[i]) * (D.lam[i] + amax * D.dlam[i]);
+                            for (int i = 0; i < 2; ++i) s_aff += (D.t[i] + amax * D.dt[i]) * (D.lam[i] + amax * D.dlam[i]);
+                    }
                     mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
                     double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
                     const double smu = sigma * mu;
@@ -767,8 +782,11 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
 #pragma unroll
                         for (int i = 0; i < 4; ++i) s.rc[i] = s.t[i] * s.lam[i] + s.dt[i] * s.dlam[i] - smu;
                     }
+                    DSET_LOOP {
+                        DSET_BIND
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) D.rc[i] = D.t[i] * D.lam[i] + D.dt[i] * D.dlam[i] - smu;
+                        for (int i = 0; i < 2; ++i) D.rc[i] = D.t[i] * D.lam[i] + D.dt[i] * D.dlam[i] - smu;
+                    }
                 } else {
                     double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
                     const double alpha = fmin(tau * amax, 1.0);
@@ -788,13 +806,15 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                             s.du += alpha * u; s.sl += alpha * s.dsl; s.su += alpha * s.dsu;
                         }
                     }
-                    if (dact) {
+                    DSET_LOOP {
+                        DSET_BIND
+                        if (!dact) continue;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             D.t[i] = fmax(D.t[i] + alpha * D.dt[i], IPM_FLOOR);
                             D.lam[i] = fmax(D.lam[i] + alpha * D.dlam[i], IPM_FLOOR);
                         }
-                        D.dx6 += alpha * L.ddx[(lane - 1) * 7 + 6];
+                        D.dx6 += alpha * L.ddx[(dk - 1) * 7 + 6];
                     }
                     // dx += alpha ddx ; pi[k-1] += alpha (P_k ddx_k + p_k)   for the entries (k,i) this lane owns
                     double dpi[TPL];
@@ -1450,7 +1470,6 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     AdmpcSolver* s = new (std::nothrow) AdmpcSolver();
     if (!s) return fail(ADMPC_ENOMEM, "out of host memory");
     s->cfg = *cfg; s->device = device; s->num_cu = prop.multiProcessorCount;
-    if (cfg->N > 64) { delete s; return fail(ADMPC_EINVAL, "N > 64 is not supported by this build of the QP kernel"); }
     s->lds_bytes = lds2_doubles(cfg->N) * (int)sizeof(double);
     if (s->lds_bytes > 160 * 1024) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     s->blocks_per_cu = (160 * 1024) / s->lds_bytes;
@@ -1467,9 +1486,10 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     e = hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcConfig), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_cfg); delete s; return fail(ADMPC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     // opt in to > 64 KB of dynamic LDS
-    const void* kerns[4] = { (const void*)admpc_qp_kernel<1, 3, 0>, (const void*)admpc_qp_kernel<1, 4, 0>,
-                             (const void*)admpc_qp_kernel<2, 5, 0>, (const void*)admpc_qp_kernel<2, 7, 0> };
-    for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
+                             (const void*)admpc_qp_kernel<2, 5, 1, 0>, (const void*)admpc_qp_kernel<2, 7, 1, 0>,
+                             (const void*)admpc_qp_kernel<3, 11, 2, 0>, (const void*)admpc_qp_kernel<4, 14, 2, 0> };
+    for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_qp_dense_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
@@ -1526,7 +1546,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
         const int first = sq == 0 ? 1 : 0;
         hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(256), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl);
-#define LAUNCH_QP(U_, T_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
+#define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
         if (s->use_dense) {
             int gridD = s->num_cu * 4;                    // 512-register kernel: one wave per SIMD
@@ -1536,10 +1556,12 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
         }
         // (the NT template parameter allows compile-time-N instantiations; none is dispatched: a <2,5,40> build gave
         //  nondeterministic results at B >= 64 on MI355X while the runtime-N kernels are correct -- cause not yet understood)
-        else if (N <= 27) LAUNCH_QP(1, 3, 0);
-        else if (N <= 32) LAUNCH_QP(1, 4, 0);
-        else if (N <= 45) LAUNCH_QP(2, 5, 0);
-        else LAUNCH_QP(2, 7, 0);
+        else if (N <= 27) LAUNCH_QP(1, 3, 1, 0);
+        else if (N <= 32) LAUNCH_QP(1, 4, 1, 0);
+        else if (N <= 45) LAUNCH_QP(2, 5, 1, 0);
+        else if (N <= 64) LAUNCH_QP(2, 7, 1, 0);
+        else if (N <= 96) LAUNCH_QP(3, 11, 2, 0);      // 7N <= 704, 2N <= 192
+        else LAUNCH_QP(4, 14, 2, 0);                   // N <= 128
 #undef LAUNCH_QP
     }
     HIPCHK(hipGetLastError());

@@ -218,3 +218,35 @@ def test_epilogue_kernel_matches_host_logic(gpu_engine_factory):
         exp = np.array(host.ackermann_fields(x[b], u[b].reshape(-1)), dtype=np.float32)
         np.testing.assert_array_equal(ack[b], exp)
     assert not valid[3] and not valid[7] and 0 < valid.sum() < 64
+
+
+_LONG_CHILD = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from ad_mpc_amd.config import default_config
+from ad_mpc_amd.engine import BatchSolver
+from ad_mpc_amd.scenarios import random_scenarios
+from oracle.oracle import Oracle
+out = []
+for N, B in [(80, 32), (128, 4)]:
+    cfg = default_config(N=N)                       # Ts = 0.05 -> T = 4 s at N = 80 (BASELINE configs[4] horizon)
+    s = random_scenarios(B, N=N, seed=1234, blend=(3.0, 5.0))
+    x, u, c, st, it = BatchSolver(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    xo, uo, co, so, io = Oracle().solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    out.append(dict(N=N, status_equal=bool((st == so).all()), ok=int((so == 0).sum()), du=float(np.abs(u - uo).max()), dx=float(np.abs(x - xo).max()),
+                    diters=int(np.abs(it - io).max())))
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_long_horizons_fp64_in_child_process():
+    """Horizon of BASELINE configs[4] (N = 80, T = 4 s) and the maximum N = 128, in fp64.  Run in a process of its own:
+    these builds of the Riccati kernel carry a large private segment (see the scratch note in DESIGN.md 4)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LONG_CHILD % root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    for rec in json.loads(line[7:]):
+        assert rec["status_equal"] and rec["ok"] > 0, rec
+        assert rec["du"] <= TOL and rec["dx"] <= TOL and rec["diters"] <= 1, rec
