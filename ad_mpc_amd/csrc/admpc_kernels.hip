@@ -1303,6 +1303,129 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// local reference generator: batched RefTrajectory.get_waypoints (src/ad_mpc/ref_traj.py:89-171).
+// One wavefront per vehicle pose; the global trajectory (M waypoints: vel, x, y, psi, unwrapped psi, cdist, curv)
+// is shared.  Lane h < H owns horizon slot h.  Reproduces the reference's arithmetic, including that the
+// interpolation abscissae start at the beginning of the path (start_dist is computed but unused, :125-134).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bound_pi(double a) {            // (a + pi) % (2 pi) - pi with Python's modulo (ref_traj.py:29-30)
+    const double twopi = 2.0 * M_PI;
+    double r = fmod(a + M_PI, twopi);
+    if (r != 0.0 && r < 0.0) r += twopi;
+    return r - M_PI;
+}
+__device__ __forceinline__ double interp_np(const double* __restrict__ xp, const double* __restrict__ fp, int M, double x) {   // numpy.interp
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[M - 1]) return fp[M - 1];
+    int lo = 0, hi = M - 1;                                       // xp[lo] <= x < xp[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
+    const double slope = __ddiv_rn(__dsub_rn(fp[lo + 1], fp[lo]), __dsub_rn(xp[lo + 1], xp[lo]));
+    return __dadd_rn(__dmul_rn(slope, __dsub_rn(x, xp[lo])), fp[lo]);
+}
+
+__global__ __launch_bounds__(WAVE) void admpc_waypoints_kernel(int M, int H, double dt, int B,
+        const double* __restrict__ vel, const double* __restrict__ tx, const double* __restrict__ ty,
+        const double* __restrict__ tpsi, const double* __restrict__ tpsi_unw, const double* __restrict__ cdist, const double* __restrict__ curv,
+        const double* __restrict__ Xi, const double* __restrict__ Yi, const double* __restrict__ Pi,
+        double* __restrict__ out_ref /*[B][6][H]: x,y,psi,v,cdist,curv*/, double* __restrict__ out_err /*[B][3]: s0,e_y0,e_psi0*/,
+        int32_t* __restrict__ out_stop)
+{
+    __shared__ double sh[WAVE];
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const double X0 = Xi[b], Y0 = Yi[b];
+        const double psi0 = bound_pi(Pi[b]);
+        // (1) closest waypoint: first index of the minimum of sqrt(dx^2 + dy^2)
+        double best = INFINITY; int bi = 0x7fffffff;
+        for (int m = lane; m < M; m += WAVE) {
+            const double dx = __dsub_rn(tx[m], X0), dy = __dsub_rn(ty[m], Y0);
+            const double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+            if (d < best) { best = d; bi = m; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE);
+            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int ci = bi;
+        // (2) Frenet errors at the closest waypoint
+        if (lane == 0) {
+            const double pw = tpsi[ci];
+            const double ex = __dsub_rn(X0, tx[ci]), ey = __dsub_rn(Y0, ty[ci]);
+            out_err[b * 3 + 0] = cdist[ci];
+            out_err[b * 3 + 1] = __dadd_rn(__dmul_rn(-sin(pw), ex), __dmul_rn(cos(pw), ey));
+            out_err[b * 3 + 2] = bound_pi(psi0 - pw);
+        }
+        // (3) abscissae: cumulative dt * vel over the horizon (velocities padded with 0.01), lane h -> s_h
+        double s_h = 0.0;
+        {
+            double acc = 0.0;
+            for (int h = 0; h < H; ++h) {                 // serial, identical rounding to the reference's running sum
+                const double v = h < M ? vel[h] : 0.01;
+                acc = h == 0 ? __dmul_rn(dt, v) : __dadd_rn(acc, __dmul_rn(dt, v));
+                if (h == lane) s_h = acc;
+            }
+        }
+        const bool on = lane < H;
+        const double xr = on ? interp_np(cdist, tx, M, s_h) : 0.0;
+        const double yr = on ? interp_np(cdist, ty, M, s_h) : 0.0;
+        const double cr = on ? interp_np(cdist, cdist, M, s_h) : 0.0;
+        const double kr = on ? interp_np(cdist, curv, M, s_h) : 0.0;
+        const double pr = on ? interp_np(cdist, tpsi_unw, M, s_h) : 0.0;
+        // psi: fix_angle_reference (bound, unwrap, add back) then bound (ref_traj.py:32-37,146-148)
+        const double d0 = bound_pi(pr - psi0);
+        sh[lane] = d0;
+        __syncthreads();
+        double corr = 0.0;
+        if (on && lane >= 1) {
+            const double dd = __dsub_rn(d0, sh[lane - 1]);
+            double ddmod = fmod(dd + M_PI, 2.0 * M_PI);
+            if (ddmod < 0.0) ddmod += 2.0 * M_PI;
+            ddmod -= M_PI;
+            if (ddmod == -M_PI && dd > 0.0) ddmod = M_PI;
+            corr = fabs(dd) < M_PI ? 0.0 : __dsub_rn(ddmod, dd);
+        }
+        __syncthreads();
+        // cumulative sum of the corrections (serial order as numpy.cumsum)
+        sh[lane] = corr;
+        __syncthreads();
+        double cum = 0.0;
+        for (int h = 1; h <= lane && h < H; ++h) cum = __dadd_rn(cum, sh[h]);
+        const double psi_fixed = bound_pi(__dadd_rn(psi0, lane >= 1 ? __dadd_rn(d0, cum) : d0));
+        __syncthreads();
+        // v_ref = diff(cdist_ref) / dt, last value repeated
+        sh[lane] = cr;
+        __syncthreads();
+        double vr = 0.0;
+        if (on) {
+            const int h1 = lane < H - 1 ? lane : H - 2;
+            vr = __ddiv_rn(__dsub_rn(sh[h1 + 1], sh[h1]), dt);
+        }
+        if (lane == 0) out_stop[b] = (sh[H - 1] == cdist[M - 1]) ? 1 : 0;
+        __syncthreads();
+        // splice: three points from the current pose to the second waypoint, then waypoints 2..H-2 (ref_traj.py:158-170)
+        double* o = out_ref + (size_t)b * 6 * H;
+        sh[lane] = xr; __syncthreads();
+        const double x1 = sh[1];
+        double xo = 0.0;
+        if (on) { if (lane < 3) { const double st = __ddiv_rn(__dsub_rn(x1, X0), 2.0); xo = lane == 2 ? x1 : __dadd_rn(X0, __dmul_rn((double)lane, st)); } else xo = sh[lane - 1]; }
+        __syncthreads();
+        sh[lane] = yr; __syncthreads();
+        const double y1 = sh[1];
+        double yo = 0.0;
+        if (on) { if (lane < 3) { const double st = __ddiv_rn(__dsub_rn(y1, Y0), 2.0); yo = lane == 2 ? y1 : __dadd_rn(Y0, __dmul_rn((double)lane, st)); } else yo = sh[lane - 1]; }
+        __syncthreads();
+        sh[lane] = psi_fixed; __syncthreads();
+        const double po = on ? (lane < 3 ? sh[0] : sh[lane - 1]) : 0.0;
+        __syncthreads();
+        sh[lane] = vr; __syncthreads();
+        const double vo = on ? (lane < 3 ? sh[2] : sh[lane - 1]) : 0.0;
+        __syncthreads();
+        if (on) { o[0 * H + lane] = xo; o[1 * H + lane] = yo; o[2 * H + lane] = po; o[3 * H + lane] = vo; o[4 * H + lane] = cr; o[5 * H + lane] = kr; }
+    }
+}
+
 // shooting only: phi, A, B to global memory (parity tests of H0/H1)
 __global__ __launch_bounds__(WAVE) void admpc_shoot_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                            const double* __restrict__ xbarg, const double* __restrict__ ubarg,
@@ -1599,6 +1722,24 @@ int admpc_epilogue_batch(AdmpcSolver* s, int B, const double* xopt, const double
     if (!xopt || !uopt || !xref_xy || !ack || !valid) return fail(ADMPC_EINVAL, "null array argument");
     HIPCHK(hipSetDevice(s->device));
     hipLaunchKernelGGL(admpc_epilogue_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->cfg.N, B, xopt, uopt, xref_xy, ack, valid);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_waypoints_batch(int device, int M, int H, double dt, int B,
+                          const double* vel, const double* x, const double* y, const double* psi, const double* psi_unwrapped,
+                          const double* cdist, const double* curv,
+                          const double* X_init, const double* Y_init, const double* psi_init,
+                          double* out_ref, double* out_err, int32_t* out_stop, void* stream)
+{
+    if (M < 2 || H < 3 || H > WAVE || B < 0 || !(dt > 0)) return fail(ADMPC_EINVAL, "admpc_waypoints_batch: need M >= 2, 3 <= H <= 64, dt > 0");
+    if (B == 0) return ADMPC_OK;
+    if (!vel || !x || !y || !psi || !psi_unwrapped || !cdist || !curv || !X_init || !Y_init || !psi_init || !out_ref || !out_err || !out_stop)
+        return fail(ADMPC_EINVAL, "null array argument");
+    HIPCHK(hipSetDevice(device));
+    int grid = B < 4096 ? B : 4096;
+    hipLaunchKernelGGL(admpc_waypoints_kernel, dim3(grid), dim3(WAVE), 0, (hipStream_t)stream, M, H, dt, B, vel, x, y, psi, psi_unwrapped, cdist, curv,
+                       X_init, Y_init, psi_init, out_ref, out_err, out_stop);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

@@ -153,6 +153,18 @@ int admpc_epilogue_batch(AdmpcSolver* s, int B,
                          const double* xopt, const double* uopt, const double* xref_xy,
                          float* ack, int32_t* valid, void* stream);
 
+/* Local reference generator: batched RefTrajectory.get_waypoints (src/ad_mpc/ref_traj.py:89-171) for B vehicle
+ * poses against ONE global trajectory of M waypoints (columns as built by RefTrajectory.set_traj, ref_traj.py:67-86, plus the
+ * unwrapped yaw).  H = traj_horizon (3..64), dt = traj_dt.  All arrays are device pointers.
+ *   out_ref  [B][6][H]  x_ref, y_ref, psi_ref, v_ref (after the "three points from the current pose" splice, :158-170),
+ *                       cdist_ref, curv_ref
+ *   out_err  [B][3]     s0, e_y0, e_psi0          out_stop [B]  1 if the horizon reaches the end of the path (:153-155) */
+int admpc_waypoints_batch(int device, int M, int H, double dt, int B,
+                          const double* vel, const double* x, const double* y, const double* psi, const double* psi_unwrapped,
+                          const double* cdist, const double* curv,
+                          const double* X_init, const double* Y_init, const double* psi_init,
+                          double* out_ref, double* out_err, int32_t* out_stop, void* stream);
+
 const char* admpc_last_error(void);
 const char* admpc_version(void);
 

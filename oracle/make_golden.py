@@ -106,6 +106,40 @@ def kat(ref):
                     terminal_xy_vs_last_row_padding=float(pad_err)))
 
 
+def ref_traj_golden():
+    """Golden vectors of RefTrajectory.set_traj/get_waypoints produced by the reference module itself.  ref_traj.py imports
+    rosbag and rospy at module level without using them in these two functions; empty placeholder modules let it import."""
+    import importlib.util
+    import types
+    for name in ("rosbag", "rospy"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    path = os.path.join(REF, "data_driven_mpc/ros_gp_mpc/src/ad_mpc/ref_traj.py")
+    spec = importlib.util.spec_from_file_location("reference_ref_traj", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(7)
+    cases = []
+    for M, H, dt in [(400, 20, 0.05), (400, 40, 0.05), (60, 10, 0.2), (40, 45, 0.2)]:
+        # a smooth path: varying curvature, yaw crossing +-pi, speeds 2..12 m/s
+        s = np.linspace(0.0, 0.5 * M, M)
+        psi = 2.8 + 0.9 * np.sin(s / 35.0) + 0.004 * s
+        x = np.concatenate(([0.0], np.cumsum(np.cos(psi[:-1]) * np.diff(s)))) + 10.0
+        y = np.concatenate(([0.0], np.cumsum(np.sin(psi[:-1]) * np.diff(s)))) - 5.0
+        psi_w = (psi + np.pi) % (2 * np.pi) - np.pi
+        vel = 7.0 + 5.0 * np.sin(s / 20.0)
+        rt = mod.RefTrajectory(traj_horizon=H, traj_dt=dt)
+        rt.set_traj(x, y, psi_w, vel)
+        poses = []
+        for _ in range(6):
+            i = int(rng.integers(0, M))
+            X0 = x[i] + rng.normal(0, 0.8); Y0 = y[i] + rng.normal(0, 0.8); P0 = psi_w[i] + rng.normal(0, 0.3) + rng.choice([0, 2 * np.pi, -2 * np.pi])
+            w = rt.get_waypoints(X0, Y0, P0)
+            poses.append(dict(X=X0, Y=Y0, psi=P0, out={k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in w.items()}))
+        cases.append(dict(M=M, H=H, dt=dt, x=x.tolist(), y=y.tolist(), psi=psi_w.tolist(), vel=vel.tolist(),
+                          table=rt.trajectory.tolist(), poses=poses))
+    return dict(source="data_driven_mpc/ros_gp_mpc/src/ad_mpc/ref_traj.py imported in the development container", cases=cases)
+
+
 def main():
     ref = RefModel()
     os.makedirs(OUT, exist_ok=True)
@@ -114,7 +148,9 @@ def main():
     k = kat(ref)
     with open(os.path.join(OUT, "kat_sim_car_iterate.json"), "w") as f:
         json.dump(k, f)
-    print("shooting.json: 120 cases;  KAT checks:", k["checks"])
+    with open(os.path.join(OUT, "ref_traj.json"), "w") as f:
+        json.dump(ref_traj_golden(), f)
+    print("shooting.json: 120 cases;  KAT checks:", k["checks"], "; ref_traj.json written")
 
 
 if __name__ == "__main__":
