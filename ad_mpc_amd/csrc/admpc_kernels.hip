@@ -929,7 +929,7 @@ struct DenseLds {
 };
 
 template <int NT>
-__global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+__global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                                  const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                                  const double* __restrict__ yrefeg,
                                                                  const double* __restrict__ GTg, const double* __restrict__ blg,
@@ -949,6 +949,12 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
     double* const invd = cb + 64;               // [64] 1 / L_jj
     double* const sb = invd + 64;               // [64] per-stage exchange
     double* const sb2 = sb + 64;                // [64]
+    double* const park = bl;                    // [5][64] per-lane constants during the IPM loop (bl, dq, gam are dead then)
+#define PK_DL   park[0 * 64 + lane]
+#define PK_DUU  park[1 * 64 + lane]
+#define PK_G0   park[2 * 64 + lane]
+#define PK_DDL  park[3 * 64 + lane]
+#define PK_DDU  park[4 * 64 + lane]
 
     const int lane = threadIdx.x;
     const int ki = lane >> 1, ji = lane & 1;
@@ -1054,8 +1060,12 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
             }
         }
         // packed lower-triangular rows of H into LDS
+        {
+            int lw = lane; asm volatile("" : "+v"(lw));
+            const int trw = lw * (lw + 1) / 2;
 #pragma unroll
-        for (int i2 = 0; i2 < n; ++i2) if (uact && i2 <= lane) Hp[trow + i2] = hrow[i2];
+            for (int i2 = 0; i2 < n; ++i2) Hp[(lw < n && i2 <= lw) ? trw + i2 : NTRI + (NTRI & 1) + lw] = hrow[i2];    // predicated-off lanes: scratch slots in the (not yet used) Lp area
+        }
         // ---------------- interior point start ----------------
         double t[4], lam[4], du = 0.0, sl = thr, su = thr;
         {
@@ -1073,84 +1083,109 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
             for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 / Dt[i]; }
         }
         WSYNC();
+        PK_DL = dl_i; PK_DUU = duu_i; PK_G0 = g0; PK_DDL = Ddl; PK_DDU = Ddu;      // parked in LDS: registers are the scarce resource
+        WSYNC();
 
         bool failed = false;
         double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
         int it = 0;
         for (; it < itmax; ++it) {
-            // ---- reciprocals, complementarity
+            int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
+            asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops (hipcc parked ~200 of them in scratch)
+            const int trz = lz * (lz + 1) / 2;
+            const bool uz = lz < n;
+            // ---- phase A: complementarity, reduced gradient, convergence test, Newton matrix, Cholesky.
+            // Everything derived from (t, lam) in this phase dies before the factorisation ends: the 40-double factor row
+            // and the interior-point state must not be live at the same time (256-register budget, two waves per SIMD).
+            double ru, mu, Dbar, S_i;
+            {
+                double musum = 0.0, cmax = 0.0, rmax = 0.0;
+                double G0, G1, G2, G3;
+                {
+                    const double i0 = 1.0 / t[0], i1 = 1.0 / t[1], i2_ = 1.0 / t[2], i3 = 1.0 / t[3];
+                    G0 = lam[0] * i0; G1 = lam[1] * i1; G2 = lam[2] * i2_; G3 = lam[3] * i3;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const double rci = t[i] * lam[i]; musum += uact ? rci : 0.0; cmax = fmax(cmax, uact ? rci : 0.0); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { const double rci = Dt[i] * Dlam[i]; musum += dact ? rci : 0.0; cmax = fmax(cmax, dact ? rci : 0.0); }
+                const double G56 = Dlam[0] / Dt[0] + Dlam[1] / Dt[1];
+                Dbar = uact ? Rj + G0 * G2 / (G0 + G2) + G1 * G3 / (G1 + G3) : 1.0;       // idle lanes: identity rows
+                // reduced gradient  ru = H du + R du + g0 - lam0 + lam1 + [u1 inputs] h * sum_{k>ki} (lam6_k - lam5_k)
+                cb[lane] = uact ? du : 0.0;
+                const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
+                sb[lane] = rdlane(dlam_pref, 63) - dlam_pref;           // suffix over stages > lane
+                const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? G56 : 0.0);
+                sb2[lane] = rdlane(Ssuf_incl, 63) - Ssuf_incl;          // lane = stage: sum over stages > lane
+                WSYNC();
+                double hdu = 0.0;
+#pragma unroll
+                for (int i2 = 0; i2 < n; i2 += 2) {
+                    const double2 dv = *reinterpret_cast<const double2*>(cb + i2);
+                    const int a0 = i2 <= lz ? trz + i2 : (i2 * (i2 + 1)) / 2 + lz;
+                    const int a1 = i2 + 1 <= lz ? trz + i2 + 1 : ((i2 + 1) * (i2 + 2)) / 2 + lz;
+                    hdu += Hp[uz ? a0 : 0] * dv.x + Hp[uz ? a1 : 0] * dv.y;
+                }
+                ru = hdu + Rj * du + PK_G0 - lam[0] + lam[1] + (ji ? h * sb[uact ? ki : 0] : 0.0);
+                S_i = h * h * sb2[uact ? ki : 0];                        // lane = input: S_{k_i}
+                {
+                    const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+                    const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
+                    const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
+                    double ra = OpMaxNan::f(fabs(ru), fabs(rsl)); ra = OpMaxNan::f(ra, fabs(rsu));
+                    ra = OpMaxNan::f(ra, fabs(rd0)); ra = OpMaxNan::f(ra, fabs(rd1)); ra = OpMaxNan::f(ra, fabs(rd2)); ra = OpMaxNan::f(ra, fabs(rd3));
+                    const double rb = OpMaxNan::f(fabs(Drd0), fabs(Drd1));
+                    rmax = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
+                }
+                mu = wave_reduce<OpSum>(musum) * inv_nineq;
+                cmax = wave_reduce<OpMax>(cmax);
+                rmax = wave_reduce<OpMaxNan>(rmax);
+                step = wave_reduce<OpMax>(stp_local);
+                if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
+                if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
+                rmax_prev = rmax;
+            }
+            // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block; right-looking Cholesky
+            {
+                double a[n];
+#pragma unroll
+                for (int i2 = 0; i2 < n; ++i2) {
+                    double v = Hp[trz + i2];                                      // in-bounds for every lane; masked below
+                    v = (uz && i2 <= lz) ? v : 0.0;
+                    if ((i2 & 1) && ji) v += S_i;                                // k_{i2} <= k_i on the lower triangle
+                    a[i2] = v + ((i2 == lz) ? Dbar : 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < n; ++j) {
+                    const double dj = rdlane(a[j], j);
+                    const double inv = rsqrt(dj);                               // 1 / L_jj
+                    const double l = lz > j ? a[j] * inv : 0.0;                 // strictly-lower column j; 0 on and above the diagonal
+                    cb[lane] = l;
+                    invd[j] = inv;                                              // uniform value, same address
+                    Lp[(uz && lz > j) ? trz + j : dummy_off] = l;               // packed strictly-lower factor; branch-free
+                    WSYNC();
+#pragma unroll
+                    for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * cb[jj];
+                    WSYNC();
+                }
+            }
+            // ---- phase C: re-derive the barrier quantities from (t, lam).  The asm statements make the compiler forget what
+            //      it computed in phase A so that nothing but the state itself stays live across the factorisation.
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(t[i]), "+v"(lam[i]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(Dt[i]), "+v"(Dlam[i]));
             double it_[4], il_[4], rc[4], Dit[2], Dil[2], Drc[2];
-            double musum = 0.0, cmax = 0.0, rmax = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { it_[i] = 1.0 / t[i]; il_[i] = 1.0 / lam[i]; rc[i] = t[i] * lam[i]; musum += uact ? rc[i] : 0.0; cmax = fmax(cmax, uact ? rc[i] : 0.0); }
+            for (int i = 0; i < 4; ++i) { it_[i] = 1.0 / t[i]; il_[i] = 1.0 / lam[i]; rc[i] = t[i] * lam[i]; }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { Dit[i] = 1.0 / Dt[i]; Dil[i] = 1.0 / Dlam[i]; Drc[i] = Dt[i] * Dlam[i]; musum += dact ? Drc[i] : 0.0; cmax = fmax(cmax, dact ? Drc[i] : 0.0); }
+            for (int i = 0; i < 2; ++i) { Dit[i] = 1.0 / Dt[i]; Dil[i] = 1.0 / Dlam[i]; Drc[i] = Dt[i] * Dlam[i]; }
             const double G0 = lam[0] * it_[0], G1 = lam[1] * it_[1], G2 = lam[2] * it_[2], G3 = lam[3] * it_[3];
             const double iG02 = 1.0 / (G0 + G2), iG13 = 1.0 / (G1 + G3);
             const double G5 = Dlam[0] * Dit[0], G6 = Dlam[1] * Dit[1];
-            // ---- reduced gradient  ru = H du + R du + g0 - lam0 + lam1 + [u1 inputs] h * sum_{k>ki} (lam6_k - lam5_k)
-            cb[lane] = uact ? du : 0.0;
-            const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
-            const double dlam_tot = rdlane(dlam_pref, 63);
-            sb[lane] = dlam_tot - dlam_pref;                        // suffix over stages > lane
-            WSYNC();
-            double hdu = 0.0;
-#pragma unroll
-            for (int i2 = 0; i2 < n; i2 += 2) {
-                const double2 dv = *reinterpret_cast<const double2*>(cb + i2);
-                const int a0 = i2 <= lane ? trow + i2 : (i2 * (i2 + 1)) / 2 + lane;
-                const int a1 = i2 + 1 <= lane ? trow + i2 + 1 : ((i2 + 1) * (i2 + 2)) / 2 + lane;
-                hdu += Hp[uact ? a0 : 0] * dv.x + Hp[uact ? a1 : 0] * dv.y;
-            }
-            const double ru = hdu + Rj * du + g0 - lam[0] + lam[1] + (ji ? h * sb[uact ? ki : 0] : 0.0);
-            const double rd0 = du + sl - dl_i - t[0], rd1 = -du + su + duu_i - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+            const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
             const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
-            const double Drd0 = dx6 - Ddl - Dt[0], Drd1 = Ddu - dx6 - Dt[1];
-            {
-                double ra = OpMaxNan::f(fabs(ru), fabs(rsl)); ra = OpMaxNan::f(ra, fabs(rsu));
-                ra = OpMaxNan::f(ra, fabs(rd0)); ra = OpMaxNan::f(ra, fabs(rd1)); ra = OpMaxNan::f(ra, fabs(rd2)); ra = OpMaxNan::f(ra, fabs(rd3));
-                const double rb = OpMaxNan::f(fabs(Drd0), fabs(Drd1));
-                rmax = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
-            }
-            const double mu = wave_reduce<OpSum>(musum) * inv_nineq;
-            cmax = wave_reduce<OpMax>(cmax);
-            rmax = wave_reduce<OpMaxNan>(rmax);
-            step = wave_reduce<OpMax>(stp_local);
-            if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
-            if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
-            rmax_prev = rmax;
-
-            // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block; Cholesky
-            const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? (G5 + G6) : 0.0);
-            const double S_own_stage = rdlane(Ssuf_incl, 63) - Ssuf_incl;        // lane = stage: sum over stages > lane
-            sb2[lane] = S_own_stage;
-            WSYNC();
-            const double S_i = h * h * sb2[uact ? ki : 0];                       // lane = input: S_{k_i}
-            double a[n];
-#pragma unroll
-            for (int i2 = 0; i2 < n; ++i2) {
-                double v = Hp[(uact && i2 <= lane) ? trow + i2 : 0];
-                v = (uact && i2 <= lane) ? v : 0.0;
-                if ((i2 & 1) && ji) v += S_i;                                    // k_{i2} <= k_i on the lower triangle
-                a[i2] = v;
-            }
-            const double Dbar = uact ? Rj + G0 * G2 * iG02 + G1 * G3 * iG13 : 1.0;      // idle lanes: identity rows
-#pragma unroll
-            for (int i2 = 0; i2 < n; ++i2) a[i2] += (i2 == lane) ? Dbar : 0.0;
-#pragma unroll
-            for (int j = 0; j < n; ++j) {
-                const double dj = rdlane(a[j], j);
-                const double inv = rsqrt(dj);                               // 1 / L_jj
-                const double l = lane > j ? a[j] * inv : 0.0;               // strictly-lower column j; 0 on and above the diagonal
-                a[j] = l;
-                cb[lane] = l;
-                invd[j] = inv;                                              // uniform value, same address
-                Lp[(uact && lane > j) ? trow + j : dummy_off] = l;          // packed copy for the transposed solve; branch-free
-                WSYNC();
-#pragma unroll
-                for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * cb[jj];
-                WSYNC();
-            }
+            const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
 
             double mu_aff = 0.0, dsl = 0.0, dsu = 0.0, ddu = 0.0, dt[4], dlam[4], Ddt[2], Ddlam[2];
 #pragma unroll 1
@@ -1166,19 +1201,20 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
                 sb[lane] = rdlane(epref, 63) - epref;
                 WSYNC();
                 double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
-                // ---- forward substitution  L z = y : a[j] holds the strictly-lower L[lane][j] (0 elsewhere), so lane j's
-                //      value is final after step j-1 and no per-step select is needed; z = y * invd afterwards
+                // ---- forward substitution  L z = y : strictly-lower L[lane][j] from the packed LDS factor (0 for lanes <= j), so
+                //      lane j's value is final after step j-1 and no per-step select is needed; z = y * invd afterwards
 #pragma unroll
-                for (int j = 0; j < n; ++j) {
+                for (int j = 0; j < n - 1; ++j) {
                     const double zj = rdlane(y, j) * invd[j];
-                    y -= a[j] * zj;
+                    const double lij = Lp[(uz && lz > j) ? trz + j : zero_off];
+                    y -= lij * zj;
                 }
                 double x = y * invd[uact ? lane : 0];
                 // ---- backward substitution  L' x = z : column entries L[j][lane] (lane < j) from the packed LDS copy
 #pragma unroll
                 for (int j = n - 1; j >= 1; --j) {
                     const double xj = rdlane(x, j) * invd[j];
-                    const double lji = Lp[lane < j ? (j * (j + 1)) / 2 + lane : zero_off];
+                    const double lji = Lp[lz < j ? (j * (j + 1)) / 2 + lz : zero_off];
                     x -= lji * xj;
                 }
                 x *= invd[uact ? lane : 0];
@@ -1240,6 +1276,11 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
         // ---------------- H6: expand the states through the linearised dynamics, full step, cost ----------------
         cb[lane] = uact ? du : 0.0;
         for (int i = lane; i < N * GTS; i += WAVE) GT[i] = gtg[i];           // Lp region held the factor: stage the linearisation again
+        for (int i = lane; i < N * NX; i += WAVE) bl[i] = blg[(size_t)inst * N * NX + i];     // bl / dq held the parked constants
+        for (int i = lane; i < (N + 1) * NX; i += WAVE) {
+            const int k = i / 7, c = i % 7;
+            dq[i] = xbg[i] - (k < N ? yrg[k * 9 + c] : yrefeg[(size_t)inst * NX + c]);
+        }
         WSYNC();
         bool bad = failed;
         double J = 0.0;
@@ -1279,14 +1320,15 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_dense_kernel(const AdmpcConfig*
             }
             WSYNC();
         }
-        const double unew = ubar_i + du;
+        const double ubar_f = ubg[sc];
+        const double unew = ubar_f + du;
         if (uact && !(fabs(unew) <= 1e300)) bad = true;
         const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
         double Ju = 0.0;
         if (status == ADMPC_STATUS_SUCCESS) {
             for (int i = lane; i < (N + 1) * NX; i += WAVE) xo[i] = xbg[i] + dq[i];
             if (uact) {
-                const double e = du + r_i / Rj;
+                const double e = unew - yrg[(sc >> 1) * 9 + 7 + (sc & 1)];
                 Ju = 0.5 * Rj * e * e;
                 if (unew < cfg->lbu[ji]) Ju += rho_l * (cfg->lbu[ji] - unew);
                 if (unew > cfg->ubu[ji]) Ju += rho_u * (unew - cfg->ubu[ji]);
@@ -1672,7 +1714,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
 #define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
         if (s->use_dense) {
-            int gridD = s->num_cu * 4;                    // 512-register kernel: one wave per SIMD
+            int gridD = s->num_cu * ((160 * 1024) / s->dense_lds_bytes < 8 ? (160 * 1024) / s->dense_lds_bytes : 8);   // two waves per SIMD
             if (gridD > B) gridD = B;
             hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first);
