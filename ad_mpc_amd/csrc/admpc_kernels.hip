@@ -920,6 +920,16 @@ __device__ __forceinline__ double wave_scan_incl(double v) {      // inclusive p
     return v;
 }
 
+// 1/sqrt(d) for well-scaled positive d: hardware estimate + two Newton steps (full double accuracy for the pivots seen here,
+// 1e-3 .. 1e15; ocml's rsqrt adds range scaling that the pivot chain does not need)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    e = fma(-d * r, r, 1.0);
+    return fma(0.5 * r, e, r);
+}
+
 template <int NT>
 struct DenseLds {
     static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
@@ -1155,19 +1165,28 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     if ((i2 & 1) && ji) v += S_i;                                // k_{i2} <= k_i on the lower triangle
                     a[i2] = v + ((i2 == lz) ? Dbar : 0.0);
                 }
+#ifdef ADMPC_DUP_CHOL
+              for (int dup_ = 0; dup_ < 2; ++dup_) {
+                if (dup_ == 1) {
+#pragma unroll
+                    for (int i2 = 0; i2 < n; ++i2) { double v = Hp[trz + i2]; v = (uz && i2 <= lz) ? v : 0.0; if ((i2 & 1) && ji) v += S_i; a[i2] = v + ((i2 == lz) ? Dbar : 0.0); }
+                }
+#endif
 #pragma unroll
                 for (int j = 0; j < n; ++j) {
                     const double dj = rdlane(a[j], j);
-                    const double inv = rsqrt(dj);                               // 1 / L_jj
+                    const double inv = rsqrt_nr(dj);                            // 1 / L_jj
                     const double l = lz > j ? a[j] * inv : 0.0;                 // strictly-lower column j; 0 on and above the diagonal
-                    cb[lane] = l;
                     invd[j] = inv;                                              // uniform value, same address
                     Lp[(uz && lz > j) ? trz + j : dummy_off] = l;               // packed strictly-lower factor; branch-free
-                    WSYNC();
+                    // column broadcast by v_readlane: no LDS round trip (and no wait) on the critical path of the factorisation
 #pragma unroll
-                    for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * cb[jj];
-                    WSYNC();
+                    for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * rdlane(l, jj);
                 }
+                WSYNC();
+#ifdef ADMPC_DUP_CHOL
+              }
+#endif
             }
             // ---- phase C: re-derive the barrier quantities from (t, lam).  The asm statements make the compiler forget what
             //      it computed in phase A so that nothing but the state itself stays live across the factorisation.
@@ -1201,6 +1220,11 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 sb[lane] = rdlane(epref, 63) - epref;
                 WSYNC();
                 double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
+#ifdef ADMPC_DUP_SUBST
+                double y_keep = y; double x = 0.0;
+              for (int dup_ = 0; dup_ < 2; ++dup_) {
+                y = y_keep; asm volatile("" : "+v"(y));
+#endif
                 // ---- forward substitution  L z = y : strictly-lower L[lane][j] from the packed LDS factor (0 for lanes <= j), so
                 //      lane j's value is final after step j-1 and no per-step select is needed; z = y * invd afterwards
 #pragma unroll
@@ -1209,7 +1233,11 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     const double lij = Lp[(uz && lz > j) ? trz + j : zero_off];
                     y -= lij * zj;
                 }
+#ifdef ADMPC_DUP_SUBST
+                x = y * invd[uact ? lane : 0];
+#else
                 double x = y * invd[uact ? lane : 0];
+#endif
                 // ---- backward substitution  L' x = z : column entries L[j][lane] (lane < j) from the packed LDS copy
 #pragma unroll
                 for (int j = n - 1; j >= 1; --j) {
@@ -1218,6 +1246,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     x -= lji * xj;
                 }
                 x *= invd[uact ? lane : 0];
+#ifdef ADMPC_DUP_SUBST
+              }
+#endif
                 ddu = uact ? x : 0.0;
                 // ---- delta rows: ddx6_k = h * sum_{k'<k} ddu_{(k',1)}
                 cb[lane] = ddu;
