@@ -935,57 +935,37 @@ struct DenseLds {
     static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
     static constexpr int LSZ = NTRI > N * GTS ? NTRI : N * GTS;
     static constexpr int BLS = (N * 7 + 1) & ~1, DQS = ((N + 1) * 7 + 1) & ~1;     // keep every sub-array 16-byte aligned
-    static constexpr int total = NTRI + (NTRI & 1) + LSZ + BLS + DQS + 5 * 64;
+    static constexpr int total = NTRI + (NTRI & 1) + LSZ + BLS + DQS + 5 * 64 + 196;       // + panel buffer [48][4] (+4 spare)
 };
 
+// kernel C (N = 20 path): condensing.  One instance per wavefront, lane i <-> input i.  Writes, per instance, the packed
+// lower-triangular Hessian rows H[NTRI] and aux[128] = { g0[64] (reduced gradient at du = 0, per input), xhat6[64] (free
+// response of delta per stage) } for the interior-point kernel.  A kernel of its own so that its 40-double Hessian row and
+// the IPM state never compete for registers (and so that the IPM kernel's code stays small).
 template <int NT>
-__global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
-                                                                 const double* __restrict__ x0g, const double* __restrict__ yrefg,
-                                                                 const double* __restrict__ yrefeg,
-                                                                 const double* __restrict__ GTg, const double* __restrict__ blg,
-                                                                 double* __restrict__ xbarg, double* __restrict__ ubarg,
-                                                                 double* __restrict__ costg, int32_t* __restrict__ statusg,
-                                                                 int32_t* __restrict__ itersg, int first_pass)
+__global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                              const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                              const double* __restrict__ yrefeg,
+                                                              const double* __restrict__ GTg, const double* __restrict__ blg,
+                                                              const double* __restrict__ xbarg, const double* __restrict__ ubarg,
+                                                              const int32_t* __restrict__ statusg, int first_pass,
+                                                              double* __restrict__ Hg, double* __restrict__ auxg)
 {
-    constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI, LSZ = DenseLds<NT>::LSZ;
+    constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI;
     extern __shared__ double lds_raw[];
-    double* const Hp = lds_raw;                 // packed lower-triangular rows of H
-    double* const Lp = Hp + NTRI + (NTRI & 1);  // packed lower-triangular rows of the Cholesky factor (IPM loop)
-    double* const GT = Lp;                      //   aliased: packed linearisation (set-up and final roll-out)
-    double* const bl = Lp + LSZ;                // defects b_k
-    double* const dq = bl + DenseLds<NT>::BLS;  // xbar_k - xref_k, k = 0..N (later: dx_k)
-    double* const gam = dq + DenseLds<NT>::DQS;       // [64] cross-lane exchange of one Gamma component
-    double* const cb = gam + 64;                // [64] Cholesky column / step broadcast buffer
-    double* const invd = cb + 64;               // [64] 1 / L_jj
-    double* const sb = invd + 64;               // [64] per-stage exchange
-    double* const sb2 = sb + 64;                // [64]
-    double* const park = bl;                    // [5][64] per-lane constants during the IPM loop (bl, dq, gam are dead then)
-#define PK_DL   park[0 * 64 + lane]
-#define PK_DUU  park[1 * 64 + lane]
-#define PK_G0   park[2 * 64 + lane]
-#define PK_DDL  park[3 * 64 + lane]
-#define PK_DDU  park[4 * 64 + lane]
-
+    double* const Hp = lds_raw;
+    double* const GT = Hp + NTRI + (NTRI & 1);
+    double* const bl = GT + N * GTS;
+    double* const dq = bl + DenseLds<NT>::BLS;
+    double* const gam = dq + DenseLds<NT>::DQS;
     const int lane = threadIdx.x;
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
-    const bool dact = lane >= 1 && lane < N;
-    const int trow = lane * (lane + 1) / 2;
-    const int zero_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 3 * 64 + 63;        // = &sb[63] relative to Lp: always 0.0 (no stage 63)
-    const int dummy_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 4 * 64 + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
     const double Ts = cfg->Ts, h = cfg->Ts;
-    double Qd[NX], Qe[NX], Rd[NU];
+    double Qd[NX], Qe[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cfg->W[i]; Qe[i] = cfg->We[i]; }
-#pragma unroll
-    for (int j = 0; j < NU; ++j) Rd[j] = Ts * cfg->W[NX + j];
-    const double Rj = ji ? Rd[1] : Rd[0];
-    const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
-    const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
-    const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
-    const int itmax = cfg->ipm_iter_max;
-    const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
-
+    const double Rj = Ts * cfg->W[NX + ji];
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
         if (!first_pass && statusg[inst] != 0) continue;
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
@@ -1002,7 +982,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         const int sc = uact ? lane : 0;
         const double ubar_i = ubg[sc];
         const double r_i = Rj * (ubar_i - yrg[(sc >> 1) * 9 + 7 + (sc & 1)]);
-        const double dl_i = cfg->lbu[ji] - ubar_i, duu_i = cfg->ubu[ji] - ubar_i;
         double xh[NX];
 #pragma unroll
         for (int c = 0; c < NX; ++c) xh[c] = x0g[(size_t)inst * NX + c] - xbg[c];      // uniform
@@ -1074,8 +1053,79 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             int lw = lane; asm volatile("" : "+v"(lw));
             const int trw = lw * (lw + 1) / 2;
 #pragma unroll
-            for (int i2 = 0; i2 < n; ++i2) Hp[(lw < n && i2 <= lw) ? trw + i2 : NTRI + (NTRI & 1) + lw] = hrow[i2];    // predicated-off lanes: scratch slots in the (not yet used) Lp area
+            for (int i2 = 0; i2 < n; ++i2) Hp[(lw < n && i2 <= lw) ? trw + i2 : NTRI + (NTRI & 1) + lw] = hrow[i2];    // predicated-off lanes: dummy slots in the GT area (dead by now)
         }
+        WSYNC();
+        for (int i = lane; i < NTRI; i += WAVE) Hg[(size_t)inst * NTRI + i] = Hp[i];
+        auxg[(size_t)inst * 128 + lane] = g0;
+        auxg[(size_t)inst * 128 + 64 + lane] = xh6_own;
+        WSYNC();
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                                 const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                                 const double* __restrict__ yrefeg,
+                                                                 const double* __restrict__ GTg, const double* __restrict__ blg,
+                                                                 double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                                 double* __restrict__ costg, int32_t* __restrict__ statusg,
+                                                                 int32_t* __restrict__ itersg, int first_pass,
+                                                                 const double* __restrict__ Hg, const double* __restrict__ auxg)
+{
+    constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI, LSZ = DenseLds<NT>::LSZ;
+    extern __shared__ double lds_raw[];
+    double* const Hp = lds_raw;                 // packed lower-triangular rows of H
+    double* const Lp = Hp + NTRI + (NTRI & 1);  // packed lower-triangular rows of the Cholesky factor (IPM loop)
+    double* const GT = Lp;                      //   aliased: packed linearisation (set-up and final roll-out)
+    double* const bl = Lp + LSZ;                // defects b_k
+    double* const dq = bl + DenseLds<NT>::BLS;  // xbar_k - xref_k, k = 0..N (later: dx_k)
+    double* const gam = dq + DenseLds<NT>::DQS;       // [64] cross-lane exchange of one Gamma component
+    double* const cb = gam + 64;                // [64] Cholesky column / step broadcast buffer
+    double* const invd = cb + 64;               // [64] 1 / L_jj
+    double* const sb = invd + 64;               // [64] per-stage exchange
+    double* const sb2 = sb + 64;                // [64]
+    double* const pan = sb2 + 64;               // [48][4] Cholesky panel exchange (+4 spare doubles for predicated-off stores)
+    double* const park = bl;                    // [5][64] per-lane constants during the IPM loop (bl, dq, gam are dead then)
+#define PK_DL   park[0 * 64 + lane]
+#define PK_DUU  park[1 * 64 + lane]
+#define PK_G0   park[2 * 64 + lane]
+#define PK_DDL  park[3 * 64 + lane]
+#define PK_DDU  park[4 * 64 + lane]
+
+    const int lane = threadIdx.x;
+    const int ki = lane >> 1, ji = lane & 1;
+    const bool uact = lane < n;
+    const bool dact = lane >= 1 && lane < N;
+    const int trow = lane * (lane + 1) / 2;
+    const int zero_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 3 * 64 + 63;        // = &sb[63] relative to Lp: always 0.0 (no stage 63)
+    const int dummy_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 4 * 64 + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
+    const double Ts = cfg->Ts, h = cfg->Ts;
+    double Qd[NX], Qe[NX], Rd[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cfg->W[i]; Qe[i] = cfg->We[i]; }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) Rd[j] = Ts * cfg->W[NX + j];
+    const double Rj = ji ? Rd[1] : Rd[0];
+    const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
+    const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
+    const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
+    const int itmax = cfg->ipm_iter_max;
+    const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
+
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        if (!first_pass && statusg[inst] != 0) continue;
+        const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
+        const double* ubg = ubarg + (size_t)inst * N * NU;
+        const double* yrg = yrefg + (size_t)inst * N * NY;
+        const double* gtg = GTg + (size_t)inst * N * GTS;
+        // ---------------- stage: condensed Hessian (kernel C) and per-lane data ----------------
+        for (int i = lane; i < NTRI; i += WAVE) Hp[i] = Hg[(size_t)inst * NTRI + i];
+        const int sc = uact ? lane : 0;
+        const double ubar_i = ubg[sc];
+        const double dl_i = cfg->lbu[ji] - ubar_i, duu_i = cfg->ubu[ji] - ubar_i;
+        const double g0 = auxg[(size_t)inst * 128 + lane];
+        const double xh6_own = auxg[(size_t)inst * 128 + 64 + lane];
         // ---------------- interior point start ----------------
         double t[4], lam[4], du = 0.0, sl = thr, su = thr;
         {
@@ -1155,6 +1205,89 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
                 rmax_prev = rmax;
             }
+#ifdef ADMPC_CHOL_MFMA
+            // ---- Newton matrix M = H + diag(R + barrier) + h^2 S_{max(k,k')} (u1 x u1 block) in MFMA tile layout, blocked right-looking
+            //      Cholesky: 4-column panels are factored on the VALU with one matrix row per lane, the trailing update
+            //      A22 -= L21 L21' runs on the matrix cores (v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C, K = 4 = panel width).
+            //      Tile layout of C/D: element (row, col) of a 16x16 tile sits in lane col + 16*(row % 4), register row / 4.
+            {
+                typedef double d4 __attribute__((ext_vector_type(4)));
+                const double hh = h * h;
+                cb[lane] = Dbar;                                   // lane = input: diagonal of R + barrier terms (1.0 on idle lanes)
+                WSYNC();
+                const int tq = lz >> 4, tc = lz & 15;
+                d4 acc[6];                                         // lower tiles (R,C): (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) at R(R+1)/2 + C
+#pragma unroll
+                for (int R = 0; R < 3; ++R)
+#pragma unroll
+                    for (int Cc = 0; Cc <= R; ++Cc)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int i = 16 * R + tq + 4 * rg, j = 16 * Cc + tc;
+                            const bool val = i >= j && i < n;
+                            double v = Hp[val ? (i * (i + 1)) / 2 + j : 0];
+                            v = val ? v : 0.0;
+                            v += (val && (i & 1) && (j & 1)) ? hh * sb2[val ? (i >> 1) : 0] : 0.0;     // max(k_i, k_j) = k_i on the lower triangle
+                            if (R == Cc) v += (i == j) ? (i < n ? cb[i < n ? i : 0] : 1.0) : 0.0;
+                            acc[R * (R + 1) / 2 + Cc][rg] = v;
+                        }
+#pragma unroll
+                for (int p = 0; p < n / 4; ++p) {
+                    const int Cp = p / 4, c0 = 4 * p - 16 * Cp, j0 = 4 * p;
+                    // panel columns j0..j0+3 (rows of tiles (R,Cp), R >= Cp) -> LDS pan[row][0..3]
+                    const bool part = tc >= c0 && tc < c0 + 4;
+#pragma unroll
+                    for (int R = Cp; R < 3; ++R)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int i = 16 * R + tq + 4 * rg;
+                            double* dst = part ? pan + i * 4 + (tc - c0) : sb + lane;      // predicated-off lanes: dummy slot
+                            *dst = acc[R * (R + 1) / 2 + Cp][rg];
+                        }
+                    WSYNC();
+                    double pv[4];
+                    {
+                        const double2 v01 = *reinterpret_cast<const double2*>(pan + (lz < 48 ? lz : 0) * 4);
+                        const double2 v23 = *reinterpret_cast<const double2*>(pan + (lz < 48 ? lz : 0) * 4 + 2);
+                        pv[0] = v01.x; pv[1] = v01.y; pv[2] = v23.x; pv[3] = v23.y;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int jc = j0 + c;
+                        const double dj = rdlane(pv[c], jc);
+                        const double inv = rsqrt_nr(dj);                         // 1 / L_jj
+                        const double l = (uz && lz > jc) ? pv[c] * inv : 0.0;     // strictly-lower column; 0 on and above the diagonal
+                        invd[jc] = inv;
+                        Lp[(uz && lz > jc) ? trz + jc : dummy_off] = l;           // packed factor for the triangular solves
+                        pv[c] = l;
+#pragma unroll
+                        for (int c2 = c + 1; c2 < 4; ++c2) pv[c2] -= l * rdlane(l, j0 + c2);
+                    }
+                    if (p + 1 < n / 4) {
+                        // finished panel rows back to LDS, then as MFMA operands: A[i][k] = B[k][i] = L[16R + i][j0 + k], lane = i + 16 k
+                        WSYNC();
+                        *reinterpret_cast<double2*>(pan + (lz < 48 ? lz * 4 : 192)) = make_double2(pv[0], pv[1]);
+                        *reinterpret_cast<double2*>(pan + (lz < 48 ? lz * 4 : 192) + 2) = make_double2(pv[2], pv[3]);
+                        WSYNC();
+                        const int Ct = (j0 + 4) / 16;
+                        double op[3];
+#pragma unroll
+                        for (int R = 0; R < 3; ++R) {
+                            const int row = 16 * R + tc;
+                            const bool on = row >= j0 + 4 && row < n;
+                            const double v = pan[(on ? row : 0) * 4 + tq];
+                            op[R] = on ? v : 0.0;
+                        }
+#pragma unroll
+                        for (int R = Ct; R < 3; ++R)
+#pragma unroll
+                            for (int Cc = Ct; Cc <= R; ++Cc)
+                                acc[R * (R + 1) / 2 + Cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[R], op[Cc], acc[R * (R + 1) / 2 + Cc], 0, 0, 0);
+                    }
+                }
+                WSYNC();
+            }
+#else
             // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block; right-looking Cholesky
             {
                 double a[n];
@@ -1188,6 +1321,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
               }
 #endif
             }
+#endif
             // ---- phase C: re-derive the barrier quantities from (t, lam).  The asm statements make the compiler forget what
             //      it computed in phase A so that nothing but the state itself stays live across the factorisation.
 #pragma unroll
@@ -1608,6 +1742,8 @@ struct AdmpcSolver {
     double* d_GT;            // [cap][N][42]
     double* d_bl;            // [cap][N][7]
     int32_t* d_status;       // [cap] used when the caller passes status == NULL
+    double* d_H;             // [cap][NTRI] condensed Hessians (dense path)
+    double* d_aux;           // [cap][128]
 };
 
 static thread_local std::string g_err;
@@ -1671,7 +1807,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     s->blocks_per_cu = (160 * 1024) / s->lds_bytes;
     if (s->blocks_per_cu > 4) s->blocks_per_cu = 4;          // register-limited: one wave per SIMD
     if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
-    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr;
+    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr;
     {   // ADMPC_QP=riccati forces the stage-wise Riccati kernel (A/B tests); default: condensed kernel where instantiated
         const char* e = getenv("ADMPC_QP");
         s->use_dense = (cfg->N == 20) && !(e && strcmp(e, "riccati") == 0);
@@ -1699,6 +1835,8 @@ void admpc_destroy(AdmpcSolver* s)
     if (s->d_GT) (void)hipFree(s->d_GT);
     if (s->d_bl) (void)hipFree(s->d_bl);
     if (s->d_status) (void)hipFree(s->d_status);
+    if (s->d_H) (void)hipFree(s->d_H);
+    if (s->d_aux) (void)hipFree(s->d_aux);
     delete s;
 }
 
@@ -1711,11 +1849,17 @@ int admpc_reserve(AdmpcSolver* s, int B)
     if (s->d_GT) (void)hipFree(s->d_GT);
     if (s->d_bl) (void)hipFree(s->d_bl);
     if (s->d_status) (void)hipFree(s->d_status);
-    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->cap = 0;
+    if (s->d_H) (void)hipFree(s->d_H);
+    if (s->d_aux) (void)hipFree(s->d_aux);
+    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->cap = 0;
     const size_t N = (size_t)s->cfg.N;
     HIPCHK(hipMalloc((void**)&s->d_GT, (size_t)B * N * GTS * sizeof(double)));
     HIPCHK(hipMalloc((void**)&s->d_bl, (size_t)B * N * NX * sizeof(double)));
     HIPCHK(hipMalloc((void**)&s->d_status, (size_t)B * sizeof(int32_t)));
+    if (s->use_dense) {
+        HIPCHK(hipMalloc((void**)&s->d_H, (size_t)B * DenseLds<20>::NTRI * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s->d_aux, (size_t)B * 128 * sizeof(double)));
+    }
     s->cap = B;
     return ADMPC_OK;
 }
@@ -1745,10 +1889,16 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
 #define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
         if (s->use_dense) {
+            constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + 64) * (int)sizeof(double);
+            int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
+            hipLaunchKernelGGL((admpc_condense_kernel<20>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
+                               (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
+                               (const int32_t*)stat, first, s->d_H, s->d_aux);
             int gridD = s->num_cu * ((160 * 1024) / s->dense_lds_bytes < 8 ? (160 * 1024) / s->dense_lds_bytes : 8);   // two waves per SIMD
             if (gridD > B) gridD = B;
             hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B, x0, yref, yref_e,
-                               (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first);
+                               (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first,
+                               (const double*)s->d_H, (const double*)s->d_aux);
         }
         // (the NT template parameter allows compile-time-N instantiations; none is dispatched: a <2,5,40> build gave
         //  nondeterministic results at B >= 64 on MI355X while the runtime-N kernels are correct -- cause not yet understood)
