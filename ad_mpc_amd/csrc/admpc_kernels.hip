@@ -203,14 +203,20 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
 #define GTS 42           // doubles per stage of the packed linearisation
 #define PKS 28           // packed symmetric 7x7
 #define KLS 17           // K0[7] K1[7] i00 i01 i11
+// work scheduler of the condensed path (int array): [0] ticket counter, [64 + q] number of instances in effort bucket q,
+// [SCHED_HDR + q * cap + j] j-th instance of bucket q.  Zeroed by the linearisation kernel, filled by the condensing kernel,
+// drained (highest bucket first) by the persistent interior-point waves.
+#define SCHED_NB 64
+#define SCHED_HDR 128
 
 __global__ __launch_bounds__(256) void admpc_linearize_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                               const double* __restrict__ xbarg, const double* __restrict__ ubarg,
                                                               const double* __restrict__ pg, const int32_t* __restrict__ skip,
-                                                              double* __restrict__ GTg, double* __restrict__ blg)
+                                                              double* __restrict__ GTg, double* __restrict__ blg, int* __restrict__ sched)
 {
     const int N = cfg->N;
     const long total = (long)B * N * 3;
+    if (sched && blockIdx.x == 0 && threadIdx.x < SCHED_HDR) sched[threadIdx.x] = 0;     // ticket counter + bucket counts of this step
     for (long tsk = (long)blockIdx.x * blockDim.x + threadIdx.x; tsk < total; tsk += (long)gridDim.x * blockDim.x) {
         const long sk = tsk / 3; const int g = (int)(tsk % 3);
         const long inst = sk / N; const int k = (int)(sk % N);
@@ -930,6 +936,33 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return fma(0.5 * r, e, r);
 }
 
+__device__ __forceinline__ int wave_scan_incl_int(int v) {        // inclusive prefix sum over lanes 0..lane
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// next instance for a persistent wave (wave-uniform), -1 when the step is drained.  Instances were binned by predicted
+// interior-point effort; tickets walk the bins from the most expensive down (longest-processing-time-first), so the
+// stragglers start early instead of last.  Lane l looks at bin SCHED_NB-1-l.
+__device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap) {
+    const int lane = threadIdx.x;
+    int t = 0;
+    if (lane == 0) t = atomicAdd(sched, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int c = sched[64 + SCHED_NB - 1 - lane];
+    const int incl = wave_scan_incl_int(c);
+    const unsigned long long m = __ballot(incl > t);
+    if (m == 0ull) return -1;
+    const int l = __ffsll((long long)m) - 1;
+    const int base = __builtin_amdgcn_readlane(incl - c, l);
+    return sched[SCHED_HDR + (size_t)(SCHED_NB - 1 - l) * cap + (t - base)];
+}
+
 template <int NT>
 struct DenseLds {
     static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
@@ -949,7 +982,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                                                               const double* __restrict__ GTg, const double* __restrict__ blg,
                                                               const double* __restrict__ xbarg, const double* __restrict__ ubarg,
                                                               const int32_t* __restrict__ statusg, int first_pass,
-                                                              double* __restrict__ Hg, double* __restrict__ auxg)
+                                                              double* __restrict__ Hg, double* __restrict__ auxg,
+                                                              int* __restrict__ sched, int cap)
 {
     constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI;
     extern __shared__ double lds_raw[];
@@ -1059,6 +1093,20 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
         for (int i = lane; i < NTRI; i += WAVE) Hg[(size_t)inst * NTRI + i] = Hp[i];
         auxg[(size_t)inst * 128 + lane] = g0;
         auxg[(size_t)inst * 128 + 64 + lane] = xh6_own;
+        // ---- effort bin for the scheduler: how far the diagonally scaled gradient step -g0_i / (H_ii + R_i) overshoots the input
+        //      box, relative to the box width (max over inputs).  0 = no bound in sight (4-5 interior-point iterations); the
+        //      iteration count grows with it (correlation 0.86 on the config-2 scenarios).  A heuristic: it orders work, nothing else.
+        {
+            const double hii = Hp[uact ? (lane * (lane + 1)) / 2 + lane : 0] + Rj;
+            const double sstep = -g0 / hii;
+            const double over = fmax(sstep - (cfg->ubu[ji] - ubar_i), (cfg->lbu[ji] - ubar_i) - sstep) / (cfg->ubu[ji] - cfg->lbu[ji]);
+            const double score = wave_reduce<OpMax>(uact ? fmax(over, 0.0) : 0.0);
+            const int q = (int)fmin(fmax(score * 32.0, 0.0), (double)(SCHED_NB - 1));
+            if (lane == 0) {
+                const int pos = atomicAdd(sched + 64 + q, 1);
+                sched[SCHED_HDR + (size_t)q * cap + pos] = inst;
+            }
+        }
         WSYNC();
     }
 }
@@ -1071,7 +1119,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                                                                  double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                                  double* __restrict__ costg, int32_t* __restrict__ statusg,
                                                                  int32_t* __restrict__ itersg, int first_pass,
-                                                                 const double* __restrict__ Hg, const double* __restrict__ auxg)
+                                                                 const double* __restrict__ Hg, const double* __restrict__ auxg,
+                                                                 int* __restrict__ sched, int cap)
 {
     constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI, LSZ = DenseLds<NT>::LSZ;
     extern __shared__ double lds_raw[];
@@ -1113,8 +1162,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const int itmax = cfg->ipm_iter_max;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
 
-    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
-        if (!first_pass && statusg[inst] != 0) continue;
+    // Instances need 4 .. 15+ interior-point iterations each: a static instance -> wave map leaves most of the chip idle while
+    // the unlucky waves finish.  The waves draw instances from the scheduler, predicted-expensive ones first.
+    // (Instances that failed in an earlier SQP iteration were not queued by the condensing kernel.)
+    for (int inst = sched_next(sched, cap); inst >= 0; inst = sched_next(sched, cap)) {
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
         const double* yrg = yrefg + (size_t)inst * N * NY;
@@ -1312,9 +1363,23 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     const double l = lz > j ? a[j] * inv : 0.0;                 // strictly-lower column j; 0 on and above the diagonal
                     invd[j] = inv;                                              // uniform value, same address
                     Lp[(uz && lz > j) ? trz + j : dummy_off] = l;               // packed strictly-lower factor; branch-free
+#ifdef ADMPC_CHOL_LDS
+                    // column broadcast through LDS: one ds_write_b64 + (n-j)/2 broadcast ds_read_b128 instead of 2 v_readlane per entry
+                    {
+                        double* const cbuf = pan + (j & 1) * 64;
+                        cbuf[lane] = l;
+                        if (((j + 1) & 1) && j + 1 < n) a[j + 1] -= l * cbuf[j + 1];
+#pragma unroll
+                        for (int jj = (j + 2) & ~1; jj < n; jj += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(cbuf + jj);
+                            a[jj] -= l * v.x; a[jj + 1] -= l * v.y;
+                        }
+                    }
+#else
                     // column broadcast by v_readlane: no LDS round trip (and no wait) on the critical path of the factorisation
 #pragma unroll
                     for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * rdlane(l, jj);
+#endif
                 }
                 WSYNC();
 #ifdef ADMPC_DUP_CHOL
@@ -1744,6 +1809,7 @@ struct AdmpcSolver {
     int32_t* d_status;       // [cap] used when the caller passes status == NULL
     double* d_H;             // [cap][NTRI] condensed Hessians (dense path)
     double* d_aux;           // [cap][128]
+    int* d_sched;            // [SCHED_HDR + SCHED_NB * cap] work scheduler of the persistent interior-point waves
 };
 
 static thread_local std::string g_err;
@@ -1817,6 +1883,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcConfig), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_cfg); delete s; return fail(ADMPC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+    s->d_sched = nullptr;
     // opt in to > 64 KB of dynamic LDS
     const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
                              (const void*)admpc_qp_kernel<2, 5, 1, 0>, (const void*)admpc_qp_kernel<2, 7, 1, 0>,
@@ -1832,6 +1899,7 @@ void admpc_destroy(AdmpcSolver* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_cfg);
+    if (s->d_sched) (void)hipFree(s->d_sched);
     if (s->d_GT) (void)hipFree(s->d_GT);
     if (s->d_bl) (void)hipFree(s->d_bl);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -1851,7 +1919,8 @@ int admpc_reserve(AdmpcSolver* s, int B)
     if (s->d_status) (void)hipFree(s->d_status);
     if (s->d_H) (void)hipFree(s->d_H);
     if (s->d_aux) (void)hipFree(s->d_aux);
-    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->cap = 0;
+    if (s->d_sched) (void)hipFree(s->d_sched);
+    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_sched = nullptr; s->cap = 0;
     const size_t N = (size_t)s->cfg.N;
     HIPCHK(hipMalloc((void**)&s->d_GT, (size_t)B * N * GTS * sizeof(double)));
     HIPCHK(hipMalloc((void**)&s->d_bl, (size_t)B * N * NX * sizeof(double)));
@@ -1859,6 +1928,7 @@ int admpc_reserve(AdmpcSolver* s, int B)
     if (s->use_dense) {
         HIPCHK(hipMalloc((void**)&s->d_H, (size_t)B * DenseLds<20>::NTRI * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s->d_aux, (size_t)B * 128 * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s->d_sched, ((size_t)SCHED_HDR + (size_t)SCHED_NB * B) * sizeof(int)));
     }
     s->cap = B;
     return ADMPC_OK;
@@ -1885,7 +1955,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     for (int sq = 0; sq < nsqp; ++sq) {
         const int first = sq == 0 ? 1 : 0;
         hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(256), 0, st, s->d_cfg, B, xbar, ubar, p,
-                           first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl);
+                           first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->use_dense ? s->d_sched : (int*)nullptr);
 #define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
         if (s->use_dense) {
@@ -1893,12 +1963,12 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
             hipLaunchKernelGGL((admpc_condense_kernel<20>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
-                               (const int32_t*)stat, first, s->d_H, s->d_aux);
+                               (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
             int gridD = s->num_cu * ((160 * 1024) / s->dense_lds_bytes < 8 ? (160 * 1024) / s->dense_lds_bytes : 8);   // two waves per SIMD
             if (gridD > B) gridD = B;
             hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first,
-                               (const double*)s->d_H, (const double*)s->d_aux);
+                               (const double*)s->d_H, (const double*)s->d_aux, s->d_sched, s->cap);
         }
         // (the NT template parameter allows compile-time-N instantiations; none is dispatched: a <2,5,40> build gave
         //  nondeterministic results at B >= 64 on MI355X while the runtime-N kernels are correct -- cause not yet understood)
