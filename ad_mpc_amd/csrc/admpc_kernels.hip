@@ -22,6 +22,7 @@
 //   d-constraint  stage k      -> hard box on delta (state 6), stages 1..N-1
 //   Riccati       lane l<63    -> matrix entry (l/9,l%9) / (l/7,l%7) of the 7x9 / 9x7 stage products
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <math.h>
 #include "../../include/admpc.h"
@@ -963,12 +964,60 @@ __device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap) {
     return sched[SCHED_HDR + (size_t)(SCHED_NB - 1 - l) * cap + (t - base)];
 }
 
+// ---- compile-time loop (indices must be immediates of the DPP instructions below)
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) { f(std::integral_constant<int, I>{}); static_for<I + 1, E>(f); }
+}
+// acc += L[lane BC of this lane's 16-lane row] * s : v_fmac_f64 with a DPP row broadcast on its first source (gfx90a+ "DP ALU DPP",
+// row_newbcast is the one control it supports).  The leading s_nop covers the VALU-write -> DPP-read hazard on L (2 wait states);
+// inline assembly is invisible to the compiler's hazard recogniser.
+template <int BC>
+__device__ __forceinline__ void fmac_rowbc(double& acc, const double L, const double s) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
+}
+template <int BC>
+__device__ __forceinline__ void fmac_rowbc4(double& a0, double& a1, double& a2, double& a3, const double L, const double s) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(L), "v"(s), "n"(BC), "n"(BC + 1), "n"(BC + 2), "n"(BC + 3));
+}
+// Copies of 16-lane row r of v in all four rows, r = 0..2 (row 3 is idle in the 40-row factorisation): gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
+//   swap16(X, X) -> (R0,R0,R2,R2), (R1,R1,R3,R3);  swap32(E, E) -> (R0 x4), (R2 x4);  swap32(O, O) -> (R1 x4), (R3 x4)
+template <int FIRST_ROW>
+__device__ __forceinline__ void rows_replicate(const double v, double (&R)[3]) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto plo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto phi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto elo = __builtin_amdgcn_permlane32_swap(plo[0], plo[0], false, false);
+    const auto ehi = __builtin_amdgcn_permlane32_swap(phi[0], phi[0], false, false);
+    if (FIRST_ROW <= 0) R[0] = __hiloint2double((int)ehi[0], (int)elo[0]);
+    R[2] = __hiloint2double((int)ehi[1], (int)elo[1]);
+    if (FIRST_ROW <= 1) {
+        const auto olo = __builtin_amdgcn_permlane32_swap(plo[1], plo[1], false, false);
+        const auto ohi = __builtin_amdgcn_permlane32_swap(phi[1], phi[1], false, false);
+        R[1] = __hiloint2double((int)ohi[0], (int)olo[0]);
+    }
+}
+
+// 1/d: hardware estimate + two Newton steps (full double accuracy; no range handling, the pivots seen here are 1e-3 .. 1e15)
+__device__ __forceinline__ double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
 template <int NT>
 struct DenseLds {
     static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
     static constexpr int LSZ = NTRI > N * GTS ? NTRI : N * GTS;
     static constexpr int BLS = (N * 7 + 1) & ~1, DQS = ((N + 1) * 7 + 1) & ~1;     // keep every sub-array 16-byte aligned
-    static constexpr int total = NTRI + (NTRI & 1) + LSZ + BLS + DQS + 5 * 64 + 196;       // + panel buffer [48][4] (+4 spare)
+    static constexpr int total = NTRI + (NTRI & 1) + LSZ + BLS + DQS + 5 * 64;
 };
 
 // kernel C (N = 20 path): condensing.  One instance per wavefront, lane i <-> input i.  Writes, per instance, the packed
@@ -1134,7 +1183,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     double* const invd = cb + 64;               // [64] 1 / L_jj
     double* const sb = invd + 64;               // [64] per-stage exchange
     double* const sb2 = sb + 64;                // [64]
-    double* const pan = sb2 + 64;               // [48][4] Cholesky panel exchange (+4 spare doubles for predicated-off stores)
     double* const park = bl;                    // [5][64] per-lane constants during the IPM loop (bl, dq, gam are dead then)
 #define PK_DL   park[0 * 64 + lane]
 #define PK_DUU  park[1 * 64 + lane]
@@ -1146,7 +1194,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
     const bool dact = lane >= 1 && lane < N;
-    const int trow = lane * (lane + 1) / 2;
     const int zero_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 3 * 64 + 63;        // = &sb[63] relative to Lp: always 0.0 (no stage 63)
     const int dummy_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 4 * 64 + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
     const double Ts = cfg->Ts, h = cfg->Ts;
@@ -1256,90 +1303,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
                 rmax_prev = rmax;
             }
-#ifdef ADMPC_CHOL_MFMA
-            // ---- Newton matrix M = H + diag(R + barrier) + h^2 S_{max(k,k')} (u1 x u1 block) in MFMA tile layout, blocked right-looking
-            //      Cholesky: 4-column panels are factored on the VALU with one matrix row per lane, the trailing update
-            //      A22 -= L21 L21' runs on the matrix cores (v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C, K = 4 = panel width).
-            //      Tile layout of C/D: element (row, col) of a 16x16 tile sits in lane col + 16*(row % 4), register row / 4.
-            {
-                typedef double d4 __attribute__((ext_vector_type(4)));
-                const double hh = h * h;
-                cb[lane] = Dbar;                                   // lane = input: diagonal of R + barrier terms (1.0 on idle lanes)
-                WSYNC();
-                const int tq = lz >> 4, tc = lz & 15;
-                d4 acc[6];                                         // lower tiles (R,C): (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) at R(R+1)/2 + C
-#pragma unroll
-                for (int R = 0; R < 3; ++R)
-#pragma unroll
-                    for (int Cc = 0; Cc <= R; ++Cc)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const int i = 16 * R + tq + 4 * rg, j = 16 * Cc + tc;
-                            const bool val = i >= j && i < n;
-                            double v = Hp[val ? (i * (i + 1)) / 2 + j : 0];
-                            v = val ? v : 0.0;
-                            v += (val && (i & 1) && (j & 1)) ? hh * sb2[val ? (i >> 1) : 0] : 0.0;     // max(k_i, k_j) = k_i on the lower triangle
-                            if (R == Cc) v += (i == j) ? (i < n ? cb[i < n ? i : 0] : 1.0) : 0.0;
-                            acc[R * (R + 1) / 2 + Cc][rg] = v;
-                        }
-#pragma unroll
-                for (int p = 0; p < n / 4; ++p) {
-                    const int Cp = p / 4, c0 = 4 * p - 16 * Cp, j0 = 4 * p;
-                    // panel columns j0..j0+3 (rows of tiles (R,Cp), R >= Cp) -> LDS pan[row][0..3]
-                    const bool part = tc >= c0 && tc < c0 + 4;
-#pragma unroll
-                    for (int R = Cp; R < 3; ++R)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const int i = 16 * R + tq + 4 * rg;
-                            double* dst = part ? pan + i * 4 + (tc - c0) : sb + lane;      // predicated-off lanes: dummy slot
-                            *dst = acc[R * (R + 1) / 2 + Cp][rg];
-                        }
-                    WSYNC();
-                    double pv[4];
-                    {
-                        const double2 v01 = *reinterpret_cast<const double2*>(pan + (lz < 48 ? lz : 0) * 4);
-                        const double2 v23 = *reinterpret_cast<const double2*>(pan + (lz < 48 ? lz : 0) * 4 + 2);
-                        pv[0] = v01.x; pv[1] = v01.y; pv[2] = v23.x; pv[3] = v23.y;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int jc = j0 + c;
-                        const double dj = rdlane(pv[c], jc);
-                        const double inv = rsqrt_nr(dj);                         // 1 / L_jj
-                        const double l = (uz && lz > jc) ? pv[c] * inv : 0.0;     // strictly-lower column; 0 on and above the diagonal
-                        invd[jc] = inv;
-                        Lp[(uz && lz > jc) ? trz + jc : dummy_off] = l;           // packed factor for the triangular solves
-                        pv[c] = l;
-#pragma unroll
-                        for (int c2 = c + 1; c2 < 4; ++c2) pv[c2] -= l * rdlane(l, j0 + c2);
-                    }
-                    if (p + 1 < n / 4) {
-                        // finished panel rows back to LDS, then as MFMA operands: A[i][k] = B[k][i] = L[16R + i][j0 + k], lane = i + 16 k
-                        WSYNC();
-                        *reinterpret_cast<double2*>(pan + (lz < 48 ? lz * 4 : 192)) = make_double2(pv[0], pv[1]);
-                        *reinterpret_cast<double2*>(pan + (lz < 48 ? lz * 4 : 192) + 2) = make_double2(pv[2], pv[3]);
-                        WSYNC();
-                        const int Ct = (j0 + 4) / 16;
-                        double op[3];
-#pragma unroll
-                        for (int R = 0; R < 3; ++R) {
-                            const int row = 16 * R + tc;
-                            const bool on = row >= j0 + 4 && row < n;
-                            const double v = pan[(on ? row : 0) * 4 + tq];
-                            op[R] = on ? v : 0.0;
-                        }
-#pragma unroll
-                        for (int R = Ct; R < 3; ++R)
-#pragma unroll
-                            for (int Cc = Ct; Cc <= R; ++Cc)
-                                acc[R * (R + 1) / 2 + Cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[R], op[Cc], acc[R * (R + 1) / 2 + Cc], 0, 0, 0);
-                    }
-                }
-                WSYNC();
-            }
-#else
-            // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block; right-looking Cholesky
+            // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block, then its factorisation
             {
                 double a[n];
 #pragma unroll
@@ -1349,44 +1313,35 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     if ((i2 & 1) && ji) v += S_i;                                // k_{i2} <= k_i on the lower triangle
                     a[i2] = v + ((i2 == lz) ? Dbar : 0.0);
                 }
-#ifdef ADMPC_DUP_CHOL
-              for (int dup_ = 0; dup_ < 2; ++dup_) {
-                if (dup_ == 1) {
-#pragma unroll
-                    for (int i2 = 0; i2 < n; ++i2) { double v = Hp[trz + i2]; v = (uz && i2 <= lz) ? v : 0.0; if ((i2 & 1) && ji) v += S_i; a[i2] = v + ((i2 == lz) ? Dbar : 0.0); }
-                }
-#endif
-#pragma unroll
-                for (int j = 0; j < n; ++j) {
+                // square-root-free factorisation M = L D L' (unit lower L): column j is replicated into every 16-lane row
+                // (row swaps, no v_readlane) and each rank-1 update is ONE v_fmac_f64 that picks lane jj % 16 of its own row
+                // through DPP.  Columns j >= 31 only touch lanes 32..39, which already hold what they need.
+                static_for<0, n>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
                     const double dj = rdlane(a[j], j);
-                    const double inv = rsqrt_nr(dj);                            // 1 / L_jj
-                    const double l = lz > j ? a[j] * inv : 0.0;                 // strictly-lower column j; 0 on and above the diagonal
-                    invd[j] = inv;                                              // uniform value, same address
-                    Lp[(uz && lz > j) ? trz + j : dummy_off] = l;               // packed strictly-lower factor; branch-free
-#ifdef ADMPC_CHOL_LDS
-                    // column broadcast through LDS: one ds_write_b64 + (n-j)/2 broadcast ds_read_b128 instead of 2 v_readlane per entry
-                    {
-                        double* const cbuf = pan + (j & 1) * 64;
-                        cbuf[lane] = l;
-                        if (((j + 1) & 1) && j + 1 < n) a[j + 1] -= l * cbuf[j + 1];
-#pragma unroll
-                        for (int jj = (j + 2) & ~1; jj < n; jj += 2) {
-                            const double2 v = *reinterpret_cast<const double2*>(cbuf + jj);
-                            a[jj] -= l * v.x; a[jj + 1] -= l * v.y;
-                        }
+                    const double dinv = rcp_nr(dj);                             // 1 / D_jj
+                    const double w = lz > j ? a[j] : 0.0;                       // unscaled strictly-lower column j; 0 on and above the diagonal
+                    const double lu = w * dinv;                                 // L_ij
+                    invd[j] = dinv;                                             // uniform value, same address
+                    Lp[(uz && lz > j) ? trz + j : dummy_off] = lu;              // packed strictly-lower factor; branch-free
+                    if constexpr (j + 1 < n) {
+                        double R[3];
+                        if constexpr ((j + 1) / 16 == 2) R[2] = w;
+                        else rows_replicate<(j + 1) / 16>(w, R);
+                        const double nl = -lu;
+                        constexpr int j4 = ((j + 1 + 3) / 4) * 4 < n ? ((j + 1 + 3) / 4) * 4 : n;        // first 4-aligned column > j
+                        static_for<j + 1, j4>([&](auto c) __attribute__((always_inline)) {
+                            constexpr int jj = decltype(c)::value;
+                            fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
+                        });
+                        static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
+                            constexpr int jj = 4 * decltype(c)::value;
+                            fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+                        });
                     }
-#else
-                    // column broadcast by v_readlane: no LDS round trip (and no wait) on the critical path of the factorisation
-#pragma unroll
-                    for (int jj = j + 1; jj < n; ++jj) a[jj] -= l * rdlane(l, jj);
-#endif
-                }
+                });
                 WSYNC();
-#ifdef ADMPC_DUP_CHOL
-              }
-#endif
             }
-#endif
             // ---- phase C: re-derive the barrier quantities from (t, lam).  The asm statements make the compiler forget what
             //      it computed in phase A so that nothing but the state itself stays live across the factorisation.
 #pragma unroll
@@ -1419,35 +1374,22 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 sb[lane] = rdlane(epref, 63) - epref;
                 WSYNC();
                 double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
-#ifdef ADMPC_DUP_SUBST
-                double y_keep = y; double x = 0.0;
-              for (int dup_ = 0; dup_ < 2; ++dup_) {
-                y = y_keep; asm volatile("" : "+v"(y));
-#endif
-                // ---- forward substitution  L z = y : strictly-lower L[lane][j] from the packed LDS factor (0 for lanes <= j), so
-                //      lane j's value is final after step j-1 and no per-step select is needed; z = y * invd afterwards
+                // ---- forward substitution  L z = y  (unit lower L): strictly-lower L[lane][j] from the packed LDS factor (0 for
+                //      lanes <= j), so lane j's value is final after step j-1 and no per-step select or scaling is needed
 #pragma unroll
                 for (int j = 0; j < n - 1; ++j) {
-                    const double zj = rdlane(y, j) * invd[j];
+                    const double zj = rdlane(y, j);
                     const double lij = Lp[(uz && lz > j) ? trz + j : zero_off];
                     y -= lij * zj;
                 }
-#ifdef ADMPC_DUP_SUBST
-                x = y * invd[uact ? lane : 0];
-#else
-                double x = y * invd[uact ? lane : 0];
-#endif
+                double x = y * invd[uact ? lane : 0];                           // D^-1
                 // ---- backward substitution  L' x = z : column entries L[j][lane] (lane < j) from the packed LDS copy
 #pragma unroll
                 for (int j = n - 1; j >= 1; --j) {
-                    const double xj = rdlane(x, j) * invd[j];
+                    const double xj = rdlane(x, j);
                     const double lji = Lp[lz < j ? (j * (j + 1)) / 2 + lz : zero_off];
                     x -= lji * xj;
                 }
-                x *= invd[uact ? lane : 0];
-#ifdef ADMPC_DUP_SUBST
-              }
-#endif
                 ddu = uact ? x : 0.0;
                 // ---- delta rows: ddx6_k = h * sum_{k'<k} ddu_{(k',1)}
                 cb[lane] = ddu;
