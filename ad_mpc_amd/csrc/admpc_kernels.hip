@@ -964,6 +964,51 @@ __device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap) {
     return sched[SCHED_HDR + (size_t)(SCHED_NB - 1 - l) * cap + (t - base)];
 }
 
+// ---- staging of one instance between HBM and LDS.  All loads of a block are issued before the first use, so a wave pays
+//      one memory round trip per block instead of one per 64 elements (the plain copy loop serialises load -> ds_write).
+//      CNT doubles, CNT even, both sides 16-byte aligned; the clamped tail re-copies the last element pair (same value).
+template <int CNT>
+__device__ __forceinline__ void stage_in(double* __restrict__ dst, const double* __restrict__ src, const int lane) {
+    static_assert(CNT % 2 == 0, "stage_in copies double2");
+    constexpr int C2 = CNT / 2, IT = (C2 + WAVE - 1) / WAVE;
+    double2 tmp[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < C2 ? i : C2 - 1; tmp[it] = reinterpret_cast<const double2*>(src)[i]; }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < C2 ? i : C2 - 1; reinterpret_cast<double2*>(dst)[i] = tmp[it]; }
+}
+// dq[k][c] = xbar[k][c] - (k < N ? yref[k][c] : yref_e[c]), k = 0..N: the same, for the tracking-error block
+template <int NN>
+__device__ __forceinline__ void stage_dq(double* __restrict__ dq, const double* __restrict__ xb, const double* __restrict__ yr,
+                                         const double* __restrict__ yre, const int lane) {
+    constexpr int CNT = (NN + 1) * NX, IT = (CNT + WAVE - 1) / WAVE;
+    double xv[IT], yv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1;
+        const int k = i / 7, c = i - 7 * k;
+        xv[it] = xb[i];
+        yv[it] = k < NN ? yr[k * 9 + c] : yre[c];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
+}
+
+// ---- triangular substitutions of the condensed interior-point kernel: hand-scheduled assembly, generated by gen_subst_asm.py
+//      (register contract and rationale there).  y lives in v[100:101], the per-lane LDS byte address in v102.
+#include "subst_asm.inc"
+__device__ __forceinline__ unsigned lds_byte_addr(const double* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const double*)p;
+}
+// L z = y in place (unit lower-triangular L, rows packed at Lp[i (i + 1) / 2 + j]); row_addr = &Lp[row start of this lane]
+__device__ __forceinline__ void fwd_subst_40(double& y, const unsigned row_addr) {
+    asm volatile(ADMPC_FWD_SUBST_ASM_40 : "+{v[100:101]}"(y) : "{v102}"(row_addr) : ADMPC_SUBST_CLOBBERS);
+}
+// L' x = z in place; col_addr = &Lp[lane]
+__device__ __forceinline__ void bwd_subst_40(double& x, const unsigned col_addr) {
+    asm volatile(ADMPC_BWD_SUBST_ASM_40 : "+{v[100:101]}"(x) : "{v102}"(col_addr) : ADMPC_SUBST_CLOBBERS);
+}
+
 // ---- compile-time loop (indices must be immediates of the DPP instructions below)
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -987,16 +1032,18 @@ __device__ __forceinline__ void fmac_rowbc4(double& a0, double& a1, double& a2, 
 // Copies of 16-lane row r of v in all four rows, r = 0..2 (row 3 is idle in the 40-row factorisation): gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
 //   swap16(X, X) -> (R0,R0,R2,R2), (R1,R1,R3,R3);  swap32(E, E) -> (R0 x4), (R2 x4);  swap32(O, O) -> (R1 x4), (R3 x4)
-template <int FIRST_ROW>
+template <int FIRST_ROW, int LAST_ROW = 2>
 __device__ __forceinline__ void rows_replicate(const double v, double (&R)[3]) {
     const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
     const auto plo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
     const auto phi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const auto elo = __builtin_amdgcn_permlane32_swap(plo[0], plo[0], false, false);
-    const auto ehi = __builtin_amdgcn_permlane32_swap(phi[0], phi[0], false, false);
-    if (FIRST_ROW <= 0) R[0] = __hiloint2double((int)ehi[0], (int)elo[0]);
-    R[2] = __hiloint2double((int)ehi[1], (int)elo[1]);
-    if (FIRST_ROW <= 1) {
+    if (FIRST_ROW <= 0 || LAST_ROW >= 2) {
+        const auto elo = __builtin_amdgcn_permlane32_swap(plo[0], plo[0], false, false);
+        const auto ehi = __builtin_amdgcn_permlane32_swap(phi[0], phi[0], false, false);
+        if (FIRST_ROW <= 0) R[0] = __hiloint2double((int)ehi[0], (int)elo[0]);
+        if (LAST_ROW >= 2) R[2] = __hiloint2double((int)ehi[1], (int)elo[1]);
+    }
+    if (FIRST_ROW <= 1 && LAST_ROW >= 1) {
         const auto olo = __builtin_amdgcn_permlane32_swap(plo[1], plo[1], false, false);
         const auto ohi = __builtin_amdgcn_permlane32_swap(phi[1], phi[1], false, false);
         R[1] = __hiloint2double((int)ohi[0], (int)olo[0]);
@@ -1040,7 +1087,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
     double* const GT = Hp + NTRI + (NTRI & 1);
     double* const bl = GT + N * GTS;
     double* const dq = bl + DenseLds<NT>::BLS;
-    double* const gam = dq + DenseLds<NT>::DQS;
     const int lane = threadIdx.x;
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
@@ -1056,12 +1102,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
         const double* yrg = yrefg + (size_t)inst * N * NY;
         const double* gtg = GTg + (size_t)inst * N * GTS;
         // ---------------- stage the instance ----------------
-        for (int i = lane; i < N * GTS; i += WAVE) GT[i] = gtg[i];
-        for (int i = lane; i < N * NX; i += WAVE) bl[i] = blg[(size_t)inst * N * NX + i];
-        for (int i = lane; i < (N + 1) * NX; i += WAVE) {
-            const int k = i / 7, c = i % 7;
-            dq[i] = xbg[i] - (k < N ? yrg[k * 9 + c] : yrefeg[(size_t)inst * NX + c]);
-        }
+        stage_in<N * GTS>(GT, gtg, lane);
+        stage_in<N * NX>(bl, blg + (size_t)inst * N * NX, lane);
+        stage_dq<N>(dq, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
         const int sc = uact ? lane : 0;
         const double ubar_i = ubg[sc];
         const double r_i = Rj * (ubar_i - yrg[(sc >> 1) * 9 + 7 + (sc & 1)]);
@@ -1077,10 +1120,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
         for (int i = 0; i < n; ++i) hrow[i] = 0.0;
         double g0 = r_i;
         double xh6_own = 0.0;                   // xhat_k[6] of the stage whose delta box this lane owns
-#pragma unroll
-        for (int k = 0; k <= N; ++k) {
-            if (k >= 1) {
-                // ---- cost of stage k: H += Gamma_k' Q Gamma_k over the inputs of stages < k, g0 += Gamma_k' Q (xhat + dq)
+        static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k >= 1) {
+                // ---- cost of stage k: H += Gamma_k' Q Gamma_k over the inputs of stages < k, g0 += Gamma_k' Q (xhat + dq).
+                //      Component c of every lane's Gamma column is replicated into all 16-lane rows and picked up by DPP row
+                //      broadcasts inside the FMAs: no LDS exchange, no wait.
                 if (lane == k) xh6_own = xh[6];
 #pragma unroll 1
                 for (int c = 0; c < NX; ++c) {
@@ -1088,23 +1133,22 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                     if (w != 0.0) {                                   // wave-uniform
                         const double gc = sel7(g, c);
                         const double wg = w * gc;
-                        gam[lane] = gc;
-                        WSYNC();
                         g0 += wg * (sel7(xh, c) + dq[k * 7 + c]);
-                        const int lim = 2 * k < n ? 2 * k : n;
-#pragma unroll
-                        for (int i2 = 0; i2 < n; i2 += 2) {
-                            if (i2 < lim) {
-                                const double2 v = *reinterpret_cast<const double2*>(gam + i2);
-                                hrow[i2] += wg * v.x;
-                                hrow[i2 + 1] += wg * v.y;
-                            }
+                        constexpr int lim = 2 * k < n ? 2 * k : n;    // inputs of stages < k (even)
+                        double R[3];
+                        rows_replicate<0, (lim - 1) / 16>(gc, R);
+                        static_for<0, lim / 4>([&](auto q) __attribute__((always_inline)) {
+                            constexpr int i2 = 4 * decltype(q)::value;
+                            fmac_rowbc4<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], R[i2 / 16], wg);
+                        });
+                        if constexpr (lim % 4 == 2) {
+                            fmac_rowbc<(lim - 2) % 16>(hrow[lim - 2], R[(lim - 2) / 16], wg);
+                            fmac_rowbc<(lim - 1) % 16>(hrow[lim - 1], R[(lim - 1) / 16], wg);
                         }
-                        WSYNC();
                     }
                 }
             }
-            if (k < N) {
+            if constexpr (k < N) {
                 // ---- propagate: xhat_{k+1} = A xhat + b ; Gamma_{k+1}[:,i] = A Gamma_k[:,i]  (or B[:,j] for the inputs of stage k)
                 const double* Gk = GT + k * GTS;
                 double xn[NX], gn[NX];
@@ -1130,7 +1174,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                 g[6] = mine ? (ji ? h : 0.0) : gn[6];
                 xh[6] = xn[6];
             }
-        }
+        });
         // packed lower-triangular rows of H into LDS
         {
             int lw = lane; asm volatile("" : "+v"(lw));
@@ -1139,7 +1183,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
             for (int i2 = 0; i2 < n; ++i2) Hp[(lw < n && i2 <= lw) ? trw + i2 : NTRI + (NTRI & 1) + lw] = hrow[i2];    // predicated-off lanes: dummy slots in the GT area (dead by now)
         }
         WSYNC();
-        for (int i = lane; i < NTRI; i += WAVE) Hg[(size_t)inst * NTRI + i] = Hp[i];
+        stage_in<NTRI>(Hg + (size_t)inst * NTRI, Hp, lane);
         auxg[(size_t)inst * 128 + lane] = g0;
         auxg[(size_t)inst * 128 + 64 + lane] = xh6_own;
         // ---- effort bin for the scheduler: how far the diagonally scaled gradient step -g0_i / (H_ii + R_i) overshoots the input
@@ -1194,7 +1238,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
     const bool dact = lane >= 1 && lane < N;
-    const int zero_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 3 * 64 + 63;        // = &sb[63] relative to Lp: always 0.0 (no stage 63)
     const int dummy_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 4 * 64 + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
     const double Ts = cfg->Ts, h = cfg->Ts;
     double Qd[NX], Qe[NX], Rd[NU];
@@ -1218,7 +1261,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         const double* yrg = yrefg + (size_t)inst * N * NY;
         const double* gtg = GTg + (size_t)inst * N * GTS;
         // ---------------- stage: condensed Hessian (kernel C) and per-lane data ----------------
-        for (int i = lane; i < NTRI; i += WAVE) Hp[i] = Hg[(size_t)inst * NTRI + i];
+        stage_in<NTRI>(Hp, Hg + (size_t)inst * NTRI, lane);
         const int sc = uact ? lane : 0;
         const double ubar_i = ubg[sc];
         const double dl_i = cfg->lbu[ji] - ubar_i, duu_i = cfg->ubu[ji] - ubar_i;
@@ -1374,22 +1417,11 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 sb[lane] = rdlane(epref, 63) - epref;
                 WSYNC();
                 double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
-                // ---- forward substitution  L z = y  (unit lower L): strictly-lower L[lane][j] from the packed LDS factor (0 for
-                //      lanes <= j), so lane j's value is final after step j-1 and no per-step select or scaling is needed
-#pragma unroll
-                for (int j = 0; j < n - 1; ++j) {
-                    const double zj = rdlane(y, j);
-                    const double lij = Lp[(uz && lz > j) ? trz + j : zero_off];
-                    y -= lij * zj;
-                }
-                double x = y * invd[uact ? lane : 0];                           // D^-1
-                // ---- backward substitution  L' x = z : column entries L[j][lane] (lane < j) from the packed LDS copy
-#pragma unroll
-                for (int j = n - 1; j >= 1; --j) {
-                    const double xj = rdlane(x, j);
-                    const double lji = Lp[lz < j ? (j * (j + 1)) / 2 + lz : zero_off];
-                    x -= lji * xj;
-                }
+                // ---- L z = y, z *= D^-1, L' x = z  (unit lower L packed by rows in LDS; assembly, see gen_subst_asm.py)
+                static_assert(n == 40, "the substitution assembly is generated for n = 40");
+                fwd_subst_40(y, lds_byte_addr(Lp + (uz ? trz : 0)));           // idle lanes: a harmless in-bounds row
+                double x = y * invd[uact ? lane : 0];
+                bwd_subst_40(x, lds_byte_addr(Lp + (uz ? lz : 0)));
                 ddu = uact ? x : 0.0;
                 // ---- delta rows: ddx6_k = h * sum_{k'<k} ddu_{(k',1)}
                 cb[lane] = ddu;
@@ -1447,12 +1479,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         }
         // ---------------- H6: expand the states through the linearised dynamics, full step, cost ----------------
         cb[lane] = uact ? du : 0.0;
-        for (int i = lane; i < N * GTS; i += WAVE) GT[i] = gtg[i];           // Lp region held the factor: stage the linearisation again
-        for (int i = lane; i < N * NX; i += WAVE) bl[i] = blg[(size_t)inst * N * NX + i];     // bl / dq held the parked constants
-        for (int i = lane; i < (N + 1) * NX; i += WAVE) {
-            const int k = i / 7, c = i % 7;
-            dq[i] = xbg[i] - (k < N ? yrg[k * 9 + c] : yrefeg[(size_t)inst * NX + c]);
-        }
+        stage_in<N * GTS>(GT, gtg, lane);                                    // Lp region held the factor: stage the linearisation again
+        stage_in<N * NX>(bl, blg + (size_t)inst * N * NX, lane);             // bl / dq held the parked constants
+        stage_dq<N>(dq, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
         WSYNC();
         bool bad = failed;
         double J = 0.0;
@@ -1498,7 +1527,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
         double Ju = 0.0;
         if (status == ADMPC_STATUS_SUCCESS) {
-            for (int i = lane; i < (N + 1) * NX; i += WAVE) xo[i] = xbg[i] + dq[i];
+#pragma unroll
+            for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i < (N + 1) * NX) xo[i] = xbg[i] + dq[i]; }
             if (uact) {
                 const double e = unew - yrg[(sc >> 1) * 9 + 7 + (sc & 1)];
                 Ju = 0.5 * Rj * e * e;
