@@ -1059,12 +1059,30 @@ __device__ __forceinline__ double rcp_nr(double d) {
     return fma(r, e, r);
 }
 
+// ---- optional in-kernel phase timers of the interior-point kernel (build with -DADMPC_PHASE_TIMERS; totals are printed by
+//      admpc_destroy).  s_memtime ticks, summed over all waves: 0 staging, 1 phase A, 2 factorisation, 3 phase C,
+//      4 substitutions, 5 expand/step, 6 final roll-out + outputs, 7 scheduler draw
+#ifdef ADMPC_PHASE_TIMERS
+__device__ unsigned long long g_phase_ticks[12];
+__device__ __forceinline__ unsigned long long phase_now() {
+    unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t;
+}
+#define PHASE_DECL() unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last = phase_now()
+#define PHASE_STAMP(k) do { const unsigned long long t_ = phase_now(); ph_acc[k] += t_ - ph_last; ph_last = t_; } while (0)
+#define PHASE_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&g_phase_ticks[q_], ph_acc[q_]); } } while (0)
+#else
+#define PHASE_DECL() do { } while (0)
+#define PHASE_STAMP(k) do { } while (0)
+#define PHASE_FLUSH() do { } while (0)
+#endif
+
 template <int NT>
 struct DenseLds {
     static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
     static constexpr int LSZ = NTRI > N * GTS ? NTRI : N * GTS;
     static constexpr int BLS = (N * 7 + 1) & ~1, DQS = ((N + 1) * 7 + 1) & ~1;     // keep every sub-array 16-byte aligned
-    static constexpr int total = NTRI + (NTRI & 1) + LSZ + BLS + DQS + 5 * 64;
+    static constexpr int total = 2 * (NTRI + (NTRI & 1)) + 5 * 64 + 4 * 64;     // interior-point kernel: H, L, parked constants, exchange buffers
+    static constexpr int expand_total = N * GTS + BLS + DQS + 64;                 // expand kernel: linearisation, defects, tracking error, du
 };
 
 // kernel C (N = 20 path): condensing.  One instance per wavefront, lane i <-> input i.  Writes, per instance, the packed
@@ -1206,28 +1224,22 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
 
 template <int NT>
 __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
-                                                                 const double* __restrict__ x0g, const double* __restrict__ yrefg,
-                                                                 const double* __restrict__ yrefeg,
-                                                                 const double* __restrict__ GTg, const double* __restrict__ blg,
-                                                                 double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                                 const double* __restrict__ xbarg, const double* __restrict__ ubarg,
                                                                  double* __restrict__ costg, int32_t* __restrict__ statusg,
-                                                                 int32_t* __restrict__ itersg, int first_pass,
-                                                                 const double* __restrict__ Hg, const double* __restrict__ auxg,
+                                                                 int32_t* __restrict__ itersg,
+                                                                 const double* __restrict__ Hg, double* auxg_out,
                                                                  int* __restrict__ sched, int cap)
 {
-    constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI, LSZ = DenseLds<NT>::LSZ;
+    const double* auxg = auxg_out;              // in: g0[64] | xhat6[64] per instance; out: du[64] over the g0 slot
+    constexpr int N = NT, n = 2 * NT, NTRI = DenseLds<NT>::NTRI;
     extern __shared__ double lds_raw[];
     double* const Hp = lds_raw;                 // packed lower-triangular rows of H
-    double* const Lp = Hp + NTRI + (NTRI & 1);  // packed lower-triangular rows of the Cholesky factor (IPM loop)
-    double* const GT = Lp;                      //   aliased: packed linearisation (set-up and final roll-out)
-    double* const bl = Lp + LSZ;                // defects b_k
-    double* const dq = bl + DenseLds<NT>::BLS;  // xbar_k - xref_k, k = 0..N (later: dx_k)
-    double* const gam = dq + DenseLds<NT>::DQS;       // [64] cross-lane exchange of one Gamma component
-    double* const cb = gam + 64;                // [64] Cholesky column / step broadcast buffer
-    double* const invd = cb + 64;               // [64] 1 / L_jj
+    double* const Lp = Hp + NTRI + (NTRI & 1);  // packed strictly-lower rows of the unit factor L (M = L D L')
+    double* const park = Lp + NTRI + (NTRI & 1);   // [5][64] per-lane constants (registers are the scarce resource)
+    double* const cb = park + 5 * 64;           // [64] step broadcast buffer
+    double* const invd = cb + 64;               // [64] 1 / D_jj
     double* const sb = invd + 64;               // [64] per-stage exchange
     double* const sb2 = sb + 64;                // [64]
-    double* const park = bl;                    // [5][64] per-lane constants during the IPM loop (bl, dq, gam are dead then)
 #define PK_DL   park[0 * 64 + lane]
 #define PK_DUU  park[1 * 64 + lane]
 #define PK_G0   park[2 * 64 + lane]
@@ -1238,14 +1250,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
     const bool dact = lane >= 1 && lane < N;
-    const int dummy_off = LSZ + DenseLds<NT>::BLS + DenseLds<NT>::DQS + 4 * 64 + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
+    const int dummy_off = (int)(sb2 - Lp) + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
     const double Ts = cfg->Ts, h = cfg->Ts;
-    double Qd[NX], Qe[NX], Rd[NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cfg->W[i]; Qe[i] = cfg->We[i]; }
-#pragma unroll
-    for (int j = 0; j < NU; ++j) Rd[j] = Ts * cfg->W[NX + j];
-    const double Rj = ji ? Rd[1] : Rd[0];
+    const double Rj = Ts * cfg->W[NX + ji];
     const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
     const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
     const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
@@ -1255,11 +1262,11 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     // Instances need 4 .. 15+ interior-point iterations each: a static instance -> wave map leaves most of the chip idle while
     // the unlucky waves finish.  The waves draw instances from the scheduler, predicted-expensive ones first.
     // (Instances that failed in an earlier SQP iteration were not queued by the condensing kernel.)
+    PHASE_DECL();
     for (int inst = sched_next(sched, cap); inst >= 0; inst = sched_next(sched, cap)) {
+        PHASE_STAMP(7);
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
-        const double* yrg = yrefg + (size_t)inst * N * NY;
-        const double* gtg = GTg + (size_t)inst * N * GTS;
         // ---------------- stage: condensed Hessian (kernel C) and per-lane data ----------------
         stage_in<NTRI>(Hp, Hg + (size_t)inst * NTRI, lane);
         const int sc = uact ? lane : 0;
@@ -1290,6 +1297,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         bool failed = false;
         double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
         int it = 0;
+        PHASE_STAMP(0);
         for (; it < itmax; ++it) {
             int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
             asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops (hipcc parked ~200 of them in scratch)
@@ -1346,6 +1354,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
                 rmax_prev = rmax;
             }
+            PHASE_STAMP(1);
             // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block, then its factorisation
             {
                 double a[n];
@@ -1385,6 +1394,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 });
                 WSYNC();
             }
+            PHASE_STAMP(2);
             // ---- phase C: re-derive the barrier quantities from (t, lam).  The asm statements make the compiler forget what
             //      it computed in phase A so that nothing but the state itself stays live across the factorisation.
 #pragma unroll
@@ -1417,11 +1427,13 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 sb[lane] = rdlane(epref, 63) - epref;
                 WSYNC();
                 double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
+                PHASE_STAMP(pass == 0 ? 3 : 5);
                 // ---- L z = y, z *= D^-1, L' x = z  (unit lower L packed by rows in LDS; assembly, see gen_subst_asm.py)
                 static_assert(n == 40, "the substitution assembly is generated for n = 40");
                 fwd_subst_40(y, lds_byte_addr(Lp + (uz ? trz : 0)));           // idle lanes: a harmless in-bounds row
                 double x = y * invd[uact ? lane : 0];
                 bwd_subst_40(x, lds_byte_addr(Lp + (uz ? lz : 0)));
+                PHASE_STAMP(4);
                 ddu = uact ? x : 0.0;
                 // ---- delta rows: ddx6_k = h * sum_{k'<k} ddu_{(k',1)}
                 cb[lane] = ddu;
@@ -1477,71 +1489,112 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 WSYNC();
             }
         }
-        // ---------------- H6: expand the states through the linearised dynamics, full step, cost ----------------
-        cb[lane] = uact ? du : 0.0;
-        stage_in<N * GTS>(GT, gtg, lane);                                    // Lp region held the factor: stage the linearisation again
-        stage_in<N * NX>(bl, blg + (size_t)inst * N * NX, lane);             // bl / dq held the parked constants
-        stage_dq<N>(dq, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
-        WSYNC();
-        bool bad = failed;
-        double J = 0.0;
-        double* xo = xbarg + (size_t)inst * (N + 1) * NX;
-        double* uo = ubarg + (size_t)inst * N * NU;
-        double dxv[NX];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) dxv[c] = x0g[(size_t)inst * NX + c] - xbg[c];
-        // the new states are staged in the dq slots (uniform values, lane c writes component c)
-#pragma unroll 1
-        for (int k = 0; k <= N; ++k) {
-            // cost and output of stage k
-            double e2sum = 0.0;
-#pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                const double dqk = dq[k * 7 + c];
-                const double e = dxv[c] + dqk;
-                e2sum += 0.5 * (k < N ? Qd[c] : Qe[c]) * e * e;
-                if (!(fabs(dxv[c]) <= 1e300)) bad = true;
-            }
-            J += e2sum;                            // uniform: every lane accumulates the same value
-            WSYNC();
-            if (lane < NX) dq[k * 7 + lane] = sel7(dxv, lane);     // dq slot k now holds dx_k (dq_k itself is no longer needed)
-            if (k < N) {
-                const double* Gk = GT + k * GTS;
-                const double u0 = cb[2 * k], u1 = cb[2 * k + 1];
-                double xn[NX];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) xn[r] = bl[k * 7 + r] + (r < 2 ? dxv[r] : 0.0) + Gk[5 * 6 + r] * u0 + Gk[6 * 6 + r] * u1;
-                xn[6] = bl[k * 7 + 6] + dxv[6] + h * u1;
-#pragma unroll
-                for (int c = 0; c < 5; ++c)
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) xn[r] += Gk[c * 6 + r] * dxv[c + 2];
-#pragma unroll
-                for (int r = 0; r < NX; ++r) dxv[r] = xn[r];
-            }
-            WSYNC();
+        PHASE_STAMP(5);
+        // ---------------- hand the step over to the expand kernel (H6): du per input, preliminary status, iteration count ----------------
+        auxg_out[(size_t)inst * 128 + lane] = uact ? du : 0.0;          // the g0 slot of this instance is dead by now
+        if (lane == 0) {
+            statusg[inst] = failed ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+            if (failed && costg) costg[inst] = INFINITY;
+            if (itersg) itersg[inst] = it;
         }
-        const double ubar_f = ubg[sc];
-        const double unew = ubar_f + du;
+        WSYNC();
+        PHASE_STAMP(6);
+    }
+    PHASE_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel E (N = 20 path): H6 -- expand the states through the linearised dynamics, full step, cost, status.
+// One instance per wavefront.  Lane r < 7 owns state component r: dx_{k+1}[r] = b_k[r] + sum_c [A_k B_k][r][c] (dx_k, du_k)[c],
+// the dx_k[c] picked up inside the FMAs by DPP row broadcasts (v_fmac_f64_dpp row_newbcast:c) -- no cross-lane exchange, no
+// wait in the 20-stage chain; everything the chain needs from LDS is independent of it and prefetched by the compiler.
+// A kernel of its own: inside the interior-point kernel (256 registers, 2 waves/SIMD) the same work ran serialised on
+// single loads and took as long as six factorisations.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                            const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                            const double* __restrict__ yrefeg,
+                                                            const double* __restrict__ GTg, const double* __restrict__ blg,
+                                                            double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                            double* __restrict__ costg, int32_t* __restrict__ statusg,
+                                                            const double* __restrict__ dug)
+{
+    constexpr int N = NT, n = 2 * NT;
+    extern __shared__ double lds_raw[];
+    double* const GT = lds_raw;                             // packed linearisation
+    double* const bl = GT + N * GTS;                        // defects b_k
+    double* const dq = bl + DenseLds<NT>::BLS;              // xbar_k - xref_k, k = 0..N (overwritten by dx_k)
+    double* const dus = dq + DenseLds<NT>::DQS;             // [64] du per input
+    const int lane = threadIdx.x;
+    const int ji = lane & 1;
+    const bool uact = lane < n;
+    const int r6 = lane < 6 ? lane : 0;                     // row of the packed linearisation this lane reads
+    const int r7 = lane < NX ? lane : 0;
+    const double Ts = cfg->Ts, h = cfg->Ts;
+    const double wq = lane < NX ? Ts * cfg->W[r7] : 0.0, wqe = lane < NX ? cfg->We[r7] : 0.0;
+    const double Rj = Ts * cfg->W[NX + ji];
+    const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        if (statusg[inst] != 0) continue;                   // failed in the interior-point kernel (or in an earlier SQP iteration)
+        const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
+        const double* ubg = ubarg + (size_t)inst * N * NU;
+        const double* yrg = yrefg + (size_t)inst * N * NY;
+        stage_in<N * GTS>(GT, GTg + (size_t)inst * N * GTS, lane);
+        stage_in<N * NX>(bl, blg + (size_t)inst * N * NX, lane);
+        stage_dq<N>(dq, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
+        const double du = dug[(size_t)inst * 128 + lane];  // 0 on idle lanes
+        dus[lane] = du;
+        const int sc = uact ? lane : 0;
+        const double ubar_i = ubg[sc];
+        const double uref_i = yrg[(sc >> 1) * 9 + 7 + (sc & 1)];
+        double dx = lane < NX ? x0g[(size_t)inst * NX + r7] - xbg[r7] : 0.0;      // dx_0 (lanes 0..6)
+        WSYNC();
+        bool bad = false;
+        double J = 0.0;
+        static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const double e = dx + dq[k * 7 + r7];
+            J += 0.5 * (k < N ? wq : wqe) * e * e;
+            if (!(fabs(dx) <= 1e300)) bad = true;
+            if (lane < NX) dq[k * 7 + lane] = dx;            // slot k now holds dx_k
+            if constexpr (k < N) {
+                const double* Gk = GT + k * GTS;
+                const double u0 = dus[2 * k], u1 = dus[2 * k + 1];
+                // rows 0..5: b + [e0 e1 A(:,2..6)] dx + B du ; row 6: delta' = delta + h u1
+                double acc = bl[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                double g[5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) g[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
+                const double b0 = lane < 6 ? Gk[5 * 6 + r6] : 0.0, b1 = lane < 6 ? Gk[6 * 6 + r6] : (lane == 6 ? h : 0.0);
+                acc += b0 * u0 + b1 * u1;
+                fmac_rowbc<2>(acc, dx, g[0]); fmac_rowbc<3>(acc, dx, g[1]); fmac_rowbc<4>(acc, dx, g[2]);
+                fmac_rowbc<5>(acc, dx, g[3]); fmac_rowbc<6>(acc, dx, g[4]);
+                dx = lane < NX ? acc : 0.0;
+            }
+        });
+        const double unew = ubar_i + du;
         if (uact && !(fabs(unew) <= 1e300)) bad = true;
         const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
         double Ju = 0.0;
+        WSYNC();
         if (status == ADMPC_STATUS_SUCCESS) {
+            double* xo = xbarg + (size_t)inst * (N + 1) * NX;
+            double* uo = ubarg + (size_t)inst * N * NU;
 #pragma unroll
             for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i < (N + 1) * NX) xo[i] = xbg[i] + dq[i]; }
             if (uact) {
-                const double e = unew - yrg[(sc >> 1) * 9 + 7 + (sc & 1)];
+                const double e = unew - uref_i;
                 Ju = 0.5 * Rj * e * e;
                 if (unew < cfg->lbu[ji]) Ju += rho_l * (cfg->lbu[ji] - unew);
                 if (unew > cfg->ubu[ji]) Ju += rho_u * (unew - cfg->ubu[ji]);
                 uo[lane] = unew;
             }
         }
-        Ju = wave_reduce<OpSum>(Ju);
+        const double Jt = wave_reduce<OpSum>(J + Ju);
         if (lane == 0) {
-            if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? J + Ju : INFINITY;
+            if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? Jt : INFINITY;
             statusg[inst] = status;
-            if (itersg) itersg[inst] = it;
         }
         WSYNC();
     }
@@ -1870,6 +1923,17 @@ void admpc_destroy(AdmpcSolver* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
+#ifdef ADMPC_PHASE_TIMERS
+    {
+        unsigned long long h[12] = {0};
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_ticks), sizeof h) == hipSuccess) {
+            static const char* nm[12] = {"staging", "phase A", "factorisation", "phase C", "substitutions", "expand/step", "outputs", "scheduler draw", "H6 restage", "H6 roll-out", "-", "-"};
+            unsigned long long tot = 0; for (int i = 0; i < 12; ++i) tot += h[i];
+            for (int i = 0; i < 10; ++i) fprintf(stderr, "[admpc phase] %-18s %14llu ticks %5.1f %%\n", nm[i], h[i], tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
+        }
+    }
+#endif
     (void)hipFree(s->d_cfg);
     if (s->d_sched) (void)hipFree(s->d_sched);
     if (s->d_GT) (void)hipFree(s->d_GT);
@@ -1938,9 +2002,13 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
                                (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
             int gridD = s->num_cu * ((160 * 1024) / s->dense_lds_bytes < 8 ? (160 * 1024) / s->dense_lds_bytes : 8);   // two waves per SIMD
             if (gridD > B) gridD = B;
-            hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B, x0, yref, yref_e,
-                               (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first,
-                               (const double*)s->d_H, (const double*)s->d_aux, s->d_sched, s->cap);
+            hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B,
+                               (const double*)xbar, (const double*)ubar, cost, stat, iters,
+                               (const double*)s->d_H, s->d_aux, s->d_sched, s->cap);
+            constexpr int exp_lds = DenseLds<20>::expand_total * (int)sizeof(double);
+            int gridE = s->num_cu * 16; if (gridE > B) gridE = B;
+            hipLaunchKernelGGL((admpc_expand_kernel<20>), dim3(gridE), dim3(WAVE), exp_lds, st, s->d_cfg, B, x0, yref, yref_e,
+                               (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, (const double*)s->d_aux);
         }
         // (the NT template parameter allows compile-time-N instantiations; none is dispatched: a <2,5,40> build gave
         //  nondeterministic results at B >= 64 on MI355X while the runtime-N kernels are correct -- cause not yet understood)
