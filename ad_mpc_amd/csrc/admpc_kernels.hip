@@ -950,11 +950,16 @@ __device__ __forceinline__ int wave_scan_incl_int(int v) {        // inclusive p
 // next instance for a persistent wave (wave-uniform), -1 when the step is drained.  Instances were binned by predicted
 // interior-point effort; tickets walk the bins from the most expensive down (longest-processing-time-first), so the
 // stragglers start early instead of last.  Lane l looks at bin SCHED_NB-1-l.
-__device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap) {
+// The first ticket of a wave is its block index (no atomic: 2048 simultaneous draws on one word queue up for ~20 us),
+// later ones are gridDim.x + a global counter.
+__device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap, bool first) {
     const int lane = threadIdx.x;
-    int t = 0;
-    if (lane == 0) t = atomicAdd(sched, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
+    int t = blockIdx.x;
+    if (!first) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(sched, 1);
+        t = (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
+    }
     const int c = sched[64 + SCHED_NB - 1 - lane];
     const int incl = wave_scan_incl_int(c);
     const unsigned long long m = __ballot(incl > t);
@@ -1007,6 +1012,15 @@ __device__ __forceinline__ void fwd_subst_40(double& y, const unsigned row_addr)
 // L' x = z in place; col_addr = &Lp[lane]
 __device__ __forceinline__ void bwd_subst_40(double& x, const unsigned col_addr) {
     asm volatile(ADMPC_BWD_SUBST_ASM_40 : "+{v[100:101]}"(x) : "{v102}"(col_addr) : ADMPC_SUBST_CLOBBERS);
+}
+
+// Newton-matrix row of this lane (see rowbuild() in gen_subst_asm.py): 20 columns per statement (operand limit of inline assembly)
+#define RB_OUT(a, o) "=&v"(a[o + 0]), "=&v"(a[o + 1]), "=&v"(a[o + 2]), "=&v"(a[o + 3]), "=&v"(a[o + 4]), "=&v"(a[o + 5]), "=&v"(a[o + 6]), \
+                     "=&v"(a[o + 7]), "=&v"(a[o + 8]), "=&v"(a[o + 9]), "=&v"(a[o + 10]), "=&v"(a[o + 11]), "=&v"(a[o + 12]), "=&v"(a[o + 13]), \
+                     "=&v"(a[o + 14]), "=&v"(a[o + 15]), "=&v"(a[o + 16]), "=&v"(a[o + 17]), "=&v"(a[o + 18]), "=&v"(a[o + 19])
+__device__ __forceinline__ void newton_row_40(double (&a)[40], const unsigned row_addr, const double dbar, const double s_odd) {
+    asm volatile(ADMPC_ROWBUILD_ASM_40_A : RB_OUT(a, 0) : "v"(row_addr), "v"(dbar), "v"(s_odd) : "s46", "s47", "memory");
+    asm volatile(ADMPC_ROWBUILD_ASM_40_B : RB_OUT(a, 20) : "v"(row_addr), "v"(dbar), "v"(s_odd) : "s46", "s47", "memory");
 }
 
 // ---- compile-time loop (indices must be immediates of the DPP instructions below)
@@ -1063,13 +1077,13 @@ __device__ __forceinline__ double rcp_nr(double d) {
 //      admpc_destroy).  s_memtime ticks, summed over all waves: 0 staging, 1 phase A, 2 factorisation, 3 phase C,
 //      4 substitutions, 5 expand/step, 6 final roll-out + outputs, 7 scheduler draw
 #ifdef ADMPC_PHASE_TIMERS
-__device__ unsigned long long g_phase_ticks[12];
+__device__ unsigned long long g_phase_ticks[16];
 __device__ __forceinline__ unsigned long long phase_now() {
     unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t;
 }
-#define PHASE_DECL() unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last = phase_now()
+#define PHASE_DECL() unsigned long long ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last = phase_now()
 #define PHASE_STAMP(k) do { const unsigned long long t_ = phase_now(); ph_acc[k] += t_ - ph_last; ph_last = t_; } while (0)
-#define PHASE_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&g_phase_ticks[q_], ph_acc[q_]); } } while (0)
+#define PHASE_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_phase_ticks[q_], ph_acc[q_]); } } while (0)
 #else
 #define PHASE_DECL() do { } while (0)
 #define PHASE_STAMP(k) do { } while (0)
@@ -1113,12 +1127,14 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
 #pragma unroll
     for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cfg->W[i]; Qe[i] = cfg->We[i]; }
     const double Rj = Ts * cfg->W[NX + ji];
+    PHASE_DECL();
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
         if (!first_pass && statusg[inst] != 0) continue;
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
         const double* yrg = yrefg + (size_t)inst * N * NY;
         const double* gtg = GTg + (size_t)inst * N * GTS;
+        PHASE_STAMP(13);
         // ---------------- stage the instance ----------------
         stage_in<N * GTS>(GT, gtg, lane);
         stage_in<N * NX>(bl, blg + (size_t)inst * N * NX, lane);
@@ -1130,6 +1146,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
 #pragma unroll
         for (int c = 0; c < NX; ++c) xh[c] = x0g[(size_t)inst * NX + c] - xbg[c];      // uniform
         WSYNC();
+        PHASE_STAMP(10);
         // ---------------- condensing ----------------
         double g[NX], hrow[n];
 #pragma unroll
@@ -1166,6 +1183,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                     }
                 }
             }
+            PHASE_STAMP(11);
             if constexpr (k < N) {
                 // ---- propagate: xhat_{k+1} = A xhat + b ; Gamma_{k+1}[:,i] = A Gamma_k[:,i]  (or B[:,j] for the inputs of stage k)
                 const double* Gk = GT + k * GTS;
@@ -1192,6 +1210,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                 g[6] = mine ? (ji ? h : 0.0) : gn[6];
                 xh[6] = xn[6];
             }
+            PHASE_STAMP(12);
         });
         // packed lower-triangular rows of H into LDS
         {
@@ -1220,6 +1239,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
         }
         WSYNC();
     }
+    PHASE_FLUSH();
 }
 
 template <int NT>
@@ -1263,7 +1283,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     // the unlucky waves finish.  The waves draw instances from the scheduler, predicted-expensive ones first.
     // (Instances that failed in an earlier SQP iteration were not queued by the condensing kernel.)
     PHASE_DECL();
-    for (int inst = sched_next(sched, cap); inst >= 0; inst = sched_next(sched, cap)) {
+    for (int inst = sched_next(sched, cap, true); inst >= 0; inst = sched_next(sched, cap, false)) {
         PHASE_STAMP(7);
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
@@ -1358,13 +1378,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block, then its factorisation
             {
                 double a[n];
-#pragma unroll
-                for (int i2 = 0; i2 < n; ++i2) {
-                    double v = Hp[trz + i2];                                      // in-bounds for every lane; masked below
-                    v = (uz && i2 <= lz) ? v : 0.0;
-                    if ((i2 & 1) && ji) v += S_i;                                // k_{i2} <= k_i on the lower triangle
-                    a[i2] = v + ((i2 == lz) ? Dbar : 0.0);
-                }
+                // a[c] = (c <= lane ? H[lane][c] : 0) + (c odd and this lane is a u1 input ? S_i : 0) + (c == lane ? Dbar : 0);
+                // idle lanes: unit rows (Dbar = 1 on a diagonal that never becomes a pivot, zeros elsewhere)
+                newton_row_40(a, lds_byte_addr(Hp + (uz ? trz : 0)), Dbar, (uz && ji) ? S_i : 0.0);
                 // square-root-free factorisation M = L D L' (unit lower L): column j is replicated into every 16-lane row
                 // (row swaps, no v_readlane) and each rank-1 update is ONE v_fmac_f64 that picks lane jj % 16 of its own row
                 // through DPP.  Columns j >= 31 only touch lanes 32..39, which already hold what they need.
@@ -1925,12 +1941,14 @@ void admpc_destroy(AdmpcSolver* s)
     (void)hipSetDevice(s->device);
 #ifdef ADMPC_PHASE_TIMERS
     {
-        unsigned long long h[12] = {0};
+        unsigned long long h[16] = {0};
         (void)hipDeviceSynchronize();
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_ticks), sizeof h) == hipSuccess) {
-            static const char* nm[12] = {"staging", "phase A", "factorisation", "phase C", "substitutions", "expand/step", "outputs", "scheduler draw", "H6 restage", "H6 roll-out", "-", "-"};
-            unsigned long long tot = 0; for (int i = 0; i < 12; ++i) tot += h[i];
-            for (int i = 0; i < 10; ++i) fprintf(stderr, "[admpc phase] %-18s %14llu ticks %5.1f %%\n", nm[i], h[i], tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
+            static const char* nm[16] = {"ipm staging", "ipm phase A", "ipm factorisation", "ipm phase C", "ipm substitutions", "ipm expand/step", "ipm hand-over", "ipm scheduler draw", "-", "-",
+                                         "cond staging", "cond H accumulate", "cond propagate", "cond store+bin", "-", "-"};
+            unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += h[i];
+            unsigned long long totc = 0; for (int i = 10; i < 16; ++i) totc += h[i];
+            for (int i = 0; i < 14; ++i) if (i < 8 || i >= 10) fprintf(stderr, "[admpc phase] %-18s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)((i < 10 ? tot : totc) ? (i < 10 ? tot : totc) : 1));
         }
     }
 #endif
