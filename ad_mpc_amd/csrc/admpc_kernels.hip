@@ -1103,7 +1103,9 @@ struct DenseLds {
 // lower-triangular Hessian rows H[NTRI] and aux[128] = { g0[64] (reduced gradient at du = 0, per input), xhat6[64] (free
 // response of delta per stage) } for the interior-point kernel.  A kernel of its own so that its 40-double Hessian row and
 // the IPM state never compete for registers (and so that the IPM kernel's code stays small).
-template <int NT>
+// QMASK: state components that may carry a tracking weight (bit c <-> W[c] or We[c] non-zero); the host picks 0b0000111
+// (position + heading, the reference's weights) or the general 0b1111111 instantiation, which tests the weights at run time.
+template <int NT, int QMASK>
 __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                               const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                               const double* __restrict__ yrefeg,
@@ -1162,13 +1164,14 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                 //      Component c of every lane's Gamma column is replicated into all 16-lane rows and picked up by DPP row
                 //      broadcasts inside the FMAs: no LDS exchange, no wait.
                 if (lane == k) xh6_own = xh[6];
-#pragma unroll 1
-                for (int c = 0; c < NX; ++c) {
-                    const double w = k < N ? sel7(Qd, c) : sel7(Qe, c);
-                    if (w != 0.0) {                                   // wave-uniform
-                        const double gc = sel7(g, c);
+                static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr ((QMASK >> c) & 1) {
+                    const double w = k < N ? Qd[c] : Qe[c];
+                    if (w != 0.0) {                                   // wave-uniform; the branch also keeps hipcc from merging all stages into one block
+                        const double gc = g[c];
                         const double wg = w * gc;
-                        g0 += wg * (sel7(xh, c) + dq[k * 7 + c]);
+                        g0 += wg * (xh[c] + dq[k * 7 + c]);
                         constexpr int lim = 2 * k < n ? 2 * k : n;    // inputs of stages < k (even)
                         double R[3];
                         rows_replicate<0, (lim - 1) / 16>(gc, R);
@@ -1181,7 +1184,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                             fmac_rowbc<(lim - 1) % 16>(hrow[lim - 1], R[(lim - 1) / 16], wg);
                         }
                     }
-                }
+                    }
+                });
             }
             PHASE_STAMP(11);
             if constexpr (k < N) {
@@ -1851,6 +1855,7 @@ struct AdmpcSolver {
     double* d_H;             // [cap][NTRI] condensed Hessians (dense path)
     double* d_aux;           // [cap][128]
     int* d_sched;            // [SCHED_HDR + SCHED_NB * cap] work scheduler of the persistent interior-point waves
+    int qmask;               // 7 when only x, y, psi carry tracking weights (specialised condensing kernel), else 127
 };
 
 static thread_local std::string g_err;
@@ -1925,6 +1930,8 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     e = hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcConfig), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_cfg); delete s; return fail(ADMPC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     s->d_sched = nullptr;
+    s->qmask = 7;
+    for (int c = 3; c < NX; ++c) if (cfg->W[c] != 0.0 || cfg->We[c] != 0.0) s->qmask = 127;
     // opt in to > 64 KB of dynamic LDS
     const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
                              (const void*)admpc_qp_kernel<2, 5, 1, 0>, (const void*)admpc_qp_kernel<2, 7, 1, 0>,
@@ -2015,9 +2022,14 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
         if (s->use_dense) {
             constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + 64) * (int)sizeof(double);
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
-            hipLaunchKernelGGL((admpc_condense_kernel<20>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
-                               (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
-                               (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
+            if (s->qmask == 7)
+                hipLaunchKernelGGL((admpc_condense_kernel<20, 7>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
+                                   (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
+                                   (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
+            else
+                hipLaunchKernelGGL((admpc_condense_kernel<20, 127>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
+                                   (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
+                                   (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
             int gridD = s->num_cu * ((160 * 1024) / s->dense_lds_bytes < 8 ? (160 * 1024) / s->dense_lds_bytes : 8);   // two waves per SIMD
             if (gridD > B) gridD = B;
             hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B,
