@@ -1043,6 +1043,19 @@ __device__ __forceinline__ void fmac_rowbc4(double& a0, double& a1, double& a2, 
         "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(L), "v"(s), "n"(BC), "n"(BC + 1), "n"(BC + 2), "n"(BC + 3));
 }
+// The same without the hazard pad: for a broadcast source that was loaded from LDS (the s_waitcnt that guards the load is enough)
+template <int BC>
+__device__ __forceinline__ void fmac_rowbc_ld(double& acc, const double L, const double s) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
+}
+template <int BC>
+__device__ __forceinline__ void fmac_rowbc4_ld(double& a0, double& a1, double& a2, double& a3, const double L, const double s) {
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(L), "v"(s), "n"(BC), "n"(BC + 1), "n"(BC + 2), "n"(BC + 3));
+}
 // Copies of 16-lane row r of v in all four rows, r = 0..2 (row 3 is idle in the 40-row factorisation): gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
 //   swap16(X, X) -> (R0,R0,R2,R2), (R1,R1,R3,R3);  swap32(E, E) -> (R0 x4), (R2 x4);  swap32(O, O) -> (R1 x4), (R3 x4)
@@ -1121,6 +1134,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
     double* const GT = Hp + NTRI + (NTRI & 1);
     double* const bl = GT + N * GTS;
     double* const dq = bl + DenseLds<NT>::BLS;
+    double* const gam = dq + DenseLds<NT>::DQS;    // [NX][64] Gamma components of the current stage, lane = input
     const int lane = threadIdx.x;
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
@@ -1159,39 +1173,40 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
         double xh6_own = 0.0;                   // xhat_k[6] of the stage whose delta box this lane owns
         static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
+            constexpr int lim = 2 * k < n ? 2 * k : n;        // inputs of stages < k (even)
+            constexpr int nblk = (lim + 15) / 16;             // 16-lane blocks of Gamma that are non-zero at this stage
+            // One stage = one basic block: merged into a single 21-stage block, hipcc hoists every LDS load of the whole instance
+            // and spills ~1600 registers.  The test is always true (B >= 1) but opaque to the compiler.
+            int tok = B; asm volatile("" : "+s"(tok));
+            if (tok > 0) {
+            double wg[NX], Rb[NX][3];
             if constexpr (k >= 1) {
-                // ---- cost of stage k: H += Gamma_k' Q Gamma_k over the inputs of stages < k, g0 += Gamma_k' Q (xhat + dq).
-                //      Component c of every lane's Gamma column is replicated into all 16-lane rows and picked up by DPP row
-                //      broadcasts inside the FMAs: no LDS exchange, no wait.
+                // ---- cost of stage k, part 1: g0 += Gamma_k' Q (xhat + dq); publish the weighted components of this lane's Gamma
+                //      column in LDS and start reading them back as "block m of component c in every 16-lane row" (the DPP
+                //      sources of part 2).  The reads complete under the propagation below.
                 if (lane == k) xh6_own = xh[6];
                 static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
                     constexpr int c = decltype(cc)::value;
                     if constexpr ((QMASK >> c) & 1) {
-                    const double w = k < N ? Qd[c] : Qe[c];
-                    if (w != 0.0) {                                   // wave-uniform; the branch also keeps hipcc from merging all stages into one block
-                        const double gc = g[c];
-                        const double wg = w * gc;
-                        g0 += wg * (xh[c] + dq[k * 7 + c]);
-                        constexpr int lim = 2 * k < n ? 2 * k : n;    // inputs of stages < k (even)
-                        double R[3];
-                        rows_replicate<0, (lim - 1) / 16>(gc, R);
-                        static_for<0, lim / 4>([&](auto q) __attribute__((always_inline)) {
-                            constexpr int i2 = 4 * decltype(q)::value;
-                            fmac_rowbc4<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], R[i2 / 16], wg);
-                        });
-                        if constexpr (lim % 4 == 2) {
-                            fmac_rowbc<(lim - 2) % 16>(hrow[lim - 2], R[(lim - 2) / 16], wg);
-                            fmac_rowbc<(lim - 1) % 16>(hrow[lim - 1], R[(lim - 1) / 16], wg);
-                        }
+                        const double w = k < N ? Qd[c] : Qe[c];
+                        wg[c] = w * g[c];
+                        g0 += wg[c] * (xh[c] + dq[k * 7 + c]);
+                        gam[c * 64 + lane] = g[c];
                     }
+                });
+                static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr ((QMASK >> c) & 1) {
+#pragma unroll
+                        for (int m = 0; m < nblk; ++m) Rb[c][m] = gam[c * 64 + 16 * m + (lane & 15)];
                     }
                 });
             }
             PHASE_STAMP(11);
+            double xn[NX], gn[NX];
             if constexpr (k < N) {
                 // ---- propagate: xhat_{k+1} = A xhat + b ; Gamma_{k+1}[:,i] = A Gamma_k[:,i]  (or B[:,j] for the inputs of stage k)
                 const double* Gk = GT + k * GTS;
-                double xn[NX], gn[NX];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) { xn[r] = bl[k * 7 + r] + (r < 2 ? xh[r] : 0.0); gn[r] = r < 2 ? g[r] : 0.0; }
                 xn[6] = bl[k * 7 + 6] + xh[6]; gn[6] = g[6];
@@ -1208,13 +1223,33 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     const double b0 = Gk[5 * 6 + r], b1 = Gk[6 * 6 + r];
-                    g[r] = mine ? (ji ? b1 : b0) : gn[r];
-                    xh[r] = xn[r];
+                    gn[r] = mine ? (ji ? b1 : b0) : gn[r];
                 }
-                g[6] = mine ? (ji ? h : 0.0) : gn[6];
-                xh[6] = xn[6];
+                gn[6] = mine ? (ji ? h : 0.0) : gn[6];
             }
             PHASE_STAMP(12);
+            if constexpr (k >= 1) {
+                // ---- cost of stage k, part 2: H += Gamma_k' Q Gamma_k over the inputs of stages < k
+                static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr ((QMASK >> c) & 1) {
+                        static_for<0, lim / 4>([&](auto q) __attribute__((always_inline)) {
+                            constexpr int i2 = 4 * decltype(q)::value;
+                            fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[c][i2 / 16], wg[c]);
+                        });
+                        if constexpr (lim % 4 == 2) {
+                            fmac_rowbc_ld<(lim - 2) % 16>(hrow[lim - 2], Rb[c][(lim - 2) / 16], wg[c]);
+                            fmac_rowbc_ld<(lim - 1) % 16>(hrow[lim - 1], Rb[c][(lim - 1) / 16], wg[c]);
+                        }
+                    }
+                });
+            }
+            if constexpr (k < N) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; }
+            }
+            }
+            PHASE_STAMP(13);
         });
         // packed lower-triangular rows of H into LDS
         {
@@ -2020,7 +2055,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
 #define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
         if (s->use_dense) {
-            constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + 64) * (int)sizeof(double);
+            constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + NX * 64) * (int)sizeof(double);
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
             if (s->qmask == 7)
                 hipLaunchKernelGGL((admpc_condense_kernel<20, 7>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,

@@ -83,6 +83,17 @@ def test_both_qp_kernels_agree_at_n20(gpu_engine_factory, oracle, monkeypatch):
     assert np.abs(g_dense[1] - g_ric[1]).max() <= TOL
 
 
+def test_all_state_weights_nonzero(gpu_engine_factory, oracle):
+    """The shipped weights only track x, y, psi (specialised condensing kernel); with velocity / yaw-rate / steering weights
+    the general instantiation runs.  N = 20 (condensed path) and N = 24 (Riccati path) against the oracle."""
+    for N in (20, 24):
+        cfg = default_config(N=N, q=(10.0, 10.0, 100.0, 1.0, 2.0, 3.0, 4.0))
+        s = random_scenarios(128, N=N, seed=99, blend=(3.0, 5.0))
+        g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+        assert (o[3] == 0).all()
+        _assert_parity(g, o)
+
+
 def test_full_size_batch_4096(gpu_engine_factory, oracle):
     """BASELINE configs[1] at full size: direct parity for every instance plus size-independent properties."""
     cfg = default_config(N=20)
