@@ -1023,6 +1023,15 @@ __device__ __forceinline__ void newton_row_40(double (&a)[40], const unsigned ro
     asm volatile(ADMPC_ROWBUILD_ASM_40_B : RB_OUT(a, 20) : "v"(row_addr), "v"(dbar), "v"(s_odd) : "s46", "s47", "memory");
 }
 
+#define RB_IN(a, o) "v"(a[o + 0]), "v"(a[o + 1]), "v"(a[o + 2]), "v"(a[o + 3]), "v"(a[o + 4]), "v"(a[o + 5]), "v"(a[o + 6]), "v"(a[o + 7]), "v"(a[o + 8]), \
+                    "v"(a[o + 9]), "v"(a[o + 10]), "v"(a[o + 11]), "v"(a[o + 12]), "v"(a[o + 13]), "v"(a[o + 14]), "v"(a[o + 15]), "v"(a[o + 16]), \
+                    "v"(a[o + 17]), "v"(a[o + 18]), "v"(a[o + 19])
+// packed lower-triangular row of this lane to LDS (rowstore() in gen_subst_asm.py); lanes >= 40 store nothing
+__device__ __forceinline__ void store_row_40(const double (&a)[40], const unsigned row_addr) {
+    asm volatile(ADMPC_ROWSTORE_ASM_40_A : : RB_IN(a, 0), "v"(row_addr) : "s46", "s47", "memory");
+    asm volatile(ADMPC_ROWSTORE_ASM_40_B : : RB_IN(a, 20), "v"(row_addr) : "s46", "s47", "memory");
+}
+
 // ---- compile-time loop (indices must be immediates of the DPP instructions below)
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -1252,12 +1261,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
             PHASE_STAMP(13);
         });
         // packed lower-triangular rows of H into LDS
-        {
-            int lw = lane; asm volatile("" : "+v"(lw));
-            const int trw = lw * (lw + 1) / 2;
-#pragma unroll
-            for (int i2 = 0; i2 < n; ++i2) Hp[(lw < n && i2 <= lw) ? trw + i2 : NTRI + (NTRI & 1) + lw] = hrow[i2];    // predicated-off lanes: dummy slots in the GT area (dead by now)
-        }
+        static_assert(n == 40, "row store assembly is generated for n = 40");
+        store_row_40(hrow, lds_byte_addr(Hp + (uact ? (lane * (lane + 1)) / 2 : 0)));
         WSYNC();
         stage_in<NTRI>(Hg + (size_t)inst * NTRI, Hp, lane);
         auxg[(size_t)inst * 128 + lane] = g0;

@@ -85,6 +85,19 @@ def rowbuild(n, lo, hi):
     return out
 
 
+def rowstore(n, lo, hi):
+    """Packed lower-triangular row of this lane, columns lo..hi-1, to LDS: lanes c .. n-1 store column c (EXEC mask), one base
+    address + immediate offsets.  Operands: %0..%(hi-lo-1) the row entries, then the lane's row address."""
+    cnt = hi - lo
+    out = ["s_mov_b64 s[%d:%d], exec" % (SAVE, SAVE + 1)]
+    for q in range(cnt):
+        c = lo + q
+        out.append("s_bfm_b64 exec, %d, %d" % (n - c, c))
+        out.append("ds_write_b64 %%%d, %%%d offset:%d" % (cnt, q, 8 * c))
+    out.append("s_mov_b64 exec, s[%d:%d]" % (SAVE, SAVE + 1))
+    return out
+
+
 def emit(name, lines):
     body = " \\\n".join('    "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body)
@@ -96,6 +109,7 @@ def main():
     txt = "// GENERATED by gen_subst_asm.py (n = %d, prefetch depth %d) -- do not edit\n" % (n, D)
     txt += emit("ADMPC_FWD_SUBST_ASM_%d" % n, fwd(n)) + "\n" + emit("ADMPC_BWD_SUBST_ASM_%d" % n, bwd(n)) + "\n"
     txt += emit("ADMPC_ROWBUILD_ASM_%d_A" % n, rowbuild(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWBUILD_ASM_%d_B" % n, rowbuild(n, n // 2, n)) + "\n"
+    txt += emit("ADMPC_ROWSTORE_ASM_%d_A" % n, rowstore(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWSTORE_ASM_%d_B" % n, rowstore(n, n // 2, n)) + "\n"
     txt += "#define ADMPC_SUBST_CLOBBERS %s, \"memory\"\n" % clob
     open(sys.argv[1] if len(sys.argv) > 1 else "subst_asm.inc", "w").write(txt)
 
