@@ -1229,11 +1229,18 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_condense_kernel(const AdmpcConf
                     }
                 }
                 const bool mine = ki == k;
+                // B_k columns: loaded by every lane and pinned by an empty asm -- left alone, hipcc sinks each load into a divergent
+                // "if (mine)" block of its own (branch + ds_read + full wait, six times per stage)
+                double bb[12];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const double b0 = Gk[5 * 6 + r], b1 = Gk[6 * 6 + r];
-                    gn[r] = mine ? (ji ? b1 : b0) : gn[r];
+                for (int r = 0; r < 12; r += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(Gk + 5 * 6 + r);
+                    bb[r] = v.x; bb[r + 1] = v.y;
                 }
+#pragma unroll
+                for (int r = 0; r < 12; ++r) asm volatile("" : "+v"(bb[r]));
+#pragma unroll
+                for (int r = 0; r < 6; ++r) gn[r] = mine ? (ji ? bb[6 + r] : bb[r]) : gn[r];
                 gn[6] = mine ? (ji ? h : 0.0) : gn[6];
             }
             PHASE_STAMP(12);
