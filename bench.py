@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (admpc_solve_batch: shooting + QP + full step for every
-instance) over one batch of synthetic scenarios that is already resident in HBM.  Every step starts
+instance; at N = 20 four kernel launches) over one batch of synthetic scenarios that is already resident in HBM.  Every step starts
 from the same initial iterate (pre-staged copies), so all steps do identical work.  Workload at
 N=1 = BASELINE.json configs[1]: batch 4096 random (x0, curved reference) scenarios, horizon N=20,
 fp64.  With more GPUs every rank solves its own 4096-instance shard (weak scaling, no data-path
@@ -161,7 +161,7 @@ def main():
                        "collective": "RCCL all-gather arg-min (16 B/rank)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "admpc_linearize_kernel + admpc_qp_dense_kernel<20> (one launch pair = one step)", "kernel_ms": kern_ms,
+                         "kernel": "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~70 %) + admpc_expand_kernel<20>" if N == 20 else "one step = admpc_linearize_kernel + admpc_qp_kernel (stage-wise Riccati)", "kernel_ms": kern_ms,
                          "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*mean_ipm_iters per solve (SURVEY 8d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N)},
