@@ -1321,7 +1321,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const int ki = lane >> 1, ji = lane & 1;
     const bool uact = lane < n;
     const bool dact = lane >= 1 && lane < N;
-    const int dummy_off = (int)(sb2 - Lp) + lane;     // = &sb2[lane] relative to Lp: scratch slot for predicated-off stores
     const double Ts = cfg->Ts, h = cfg->Ts;
     const double Rj = Ts * cfg->W[NX + ji];
     const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
@@ -1432,32 +1431,56 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 // a[c] = (c <= lane ? H[lane][c] : 0) + (c odd and this lane is a u1 input ? S_i : 0) + (c == lane ? Dbar : 0);
                 // idle lanes: unit rows (Dbar = 1 on a diagonal that never becomes a pivot, zeros elsewhere)
                 newton_row_40(a, lds_byte_addr(Hp + (uz ? trz : 0)), Dbar, (uz && ji) ? S_i : 0.0);
-                // square-root-free factorisation M = L D L' (unit lower L): column j is replicated into every 16-lane row
-                // (row swaps, no v_readlane) and each rank-1 update is ONE v_fmac_f64 that picks lane jj % 16 of its own row
-                // through DPP.  Columns j >= 31 only touch lanes 32..39, which already hold what they need.
-                static_for<0, n>([&](auto jc) __attribute__((always_inline)) {
+                // Square-root-free right-looking factorisation M = L D L' (unit lower L), row i in the registers of lane i.
+                // Column j (unscaled, w_i = a_i[j]) is published in LDS and read back as "block m in every 16-lane row", the DPP
+                // sources of the rank-1 update: a[jj] -= w_jj * (w_i / D_jj) is ONE v_fmac_f64_dpp per jj.  Look-ahead: the first
+                // update of column j makes column j+1 final; its pivot chain (v_readlane, v_rcp_f64 + Newton, scale, publish,
+                // read back) is started right there and completes under the remaining updates of column j.
+                // Entries on and above the diagonal of a row are never read (lane jj's w_jj is only picked up for jj > j), so the
+                // column is used unmasked; only the store of L is masked (EXEC).
+                const unsigned lrow = lds_byte_addr(Lp + (uz ? trz : 0));
+                double R[3], nl;
+                auto chain = [&](auto jc, double (&Rn)[3], double& nln) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
                     const double dj = rdlane(a[j], j);
                     const double dinv = rcp_nr(dj);                             // 1 / D_jj
-                    const double w = lz > j ? a[j] : 0.0;                       // unscaled strictly-lower column j; 0 on and above the diagonal
-                    const double lu = w * dinv;                                 // L_ij
+                    const double lu = a[j] * dinv;                              // L_ij for the lanes below the diagonal
                     invd[j] = dinv;                                             // uniform value, same address
-                    Lp[(uz && lz > j) ? trz + j : dummy_off] = lu;              // packed strictly-lower factor; branch-free
                     if constexpr (j + 1 < n) {
-                        double R[3];
-                        if constexpr ((j + 1) / 16 == 2) R[2] = w;
-                        else rows_replicate<(j + 1) / 16>(w, R);
-                        const double nl = -lu;
-                        constexpr int j4 = ((j + 1 + 3) / 4) * 4 < n ? ((j + 1 + 3) / 4) * 4 : n;        // first 4-aligned column > j
-                        static_for<j + 1, j4>([&](auto c) __attribute__((always_inline)) {
-                            constexpr int jj = decltype(c)::value;
-                            fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
-                        });
-                        static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
-                            constexpr int jj = 4 * decltype(c)::value;
-                            fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
-                        });
+                        asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
+                                     : : "v"(lrow), "v"(lu), "n"(n - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
+                        nln = -lu;
+                        if constexpr ((j + 1) / 16 == 2) Rn[2] = a[j];          // only lanes 32..39 are still involved: own row
+                        else {
+                            double* const cbuf = (j & 1) ? sb : cb;
+                            cbuf[lane] = a[j];
+#pragma unroll
+                            for (int m = (j + 1) / 16; m < 3; ++m) Rn[m] = cbuf[16 * m + (lane & 15)];
+                        }
                     }
+                };
+                chain(std::integral_constant<int, 0>{}, R, nl);
+                static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr bool own = (j + 1) / 16 == 2;                     // DPP source written by the VALU (hazard pad) or loaded from LDS
+                    double Rn[3], nln;
+                    if constexpr (own) fmac_rowbc<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
+                    else fmac_rowbc_ld<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
+                    chain(std::integral_constant<int, j + 1>{}, Rn, nln);
+                    constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;        // first 4-aligned column >= j + 2
+                    static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
+                        constexpr int jj = decltype(c)::value;
+                        if constexpr (own) fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
+                        else fmac_rowbc_ld<jj % 16>(a[jj], R[jj / 16], nl);
+                    });
+                    static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
+                        constexpr int jj = 4 * decltype(c)::value;
+                        if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+                        else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+                    });
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) R[m] = Rn[m];
+                    nl = nln;
                 });
                 WSYNC();
             }
