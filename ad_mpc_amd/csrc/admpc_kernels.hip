@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         {
             const double r0[4] = { thr - dl_i, thr + duu_i, thr, thr };
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 / t[i]; }
+            for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
         }
         double Dt[2] = {1.0, 1.0}, Dlam[2] = {0.0, 0.0}, Ddl = 0.0, Ddu = 0.0, dx6 = 0.0;
         if (dact) {
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             dx6 = xh6_own;
             const double r0[2] = { dx6 - Ddl, Ddu - dx6 };
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 / Dt[i]; }
+            for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
         }
         WSYNC();
         PK_DL = dl_i; PK_DUU = duu_i; PK_G0 = g0; PK_DDL = Ddl; PK_DDU = Ddu;      // parked in LDS: registers are the scarce resource
@@ -1381,15 +1381,15 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 double musum = 0.0, cmax = 0.0, rmax = 0.0;
                 double G0, G1, G2, G3;
                 {
-                    const double i0 = 1.0 / t[0], i1 = 1.0 / t[1], i2_ = 1.0 / t[2], i3 = 1.0 / t[3];
+                    const double i0 = rcp_nr(t[0]), i1 = rcp_nr(t[1]), i2_ = rcp_nr(t[2]), i3 = rcp_nr(t[3]);
                     G0 = lam[0] * i0; G1 = lam[1] * i1; G2 = lam[2] * i2_; G3 = lam[3] * i3;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const double rci = t[i] * lam[i]; musum += uact ? rci : 0.0; cmax = fmax(cmax, uact ? rci : 0.0); }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) { const double rci = Dt[i] * Dlam[i]; musum += dact ? rci : 0.0; cmax = fmax(cmax, dact ? rci : 0.0); }
-                const double G56 = Dlam[0] / Dt[0] + Dlam[1] / Dt[1];
-                Dbar = uact ? Rj + G0 * G2 / (G0 + G2) + G1 * G3 / (G1 + G3) : 1.0;       // idle lanes: identity rows
+                const double G56 = Dlam[0] * rcp_nr(Dt[0]) + Dlam[1] * rcp_nr(Dt[1]);
+                Dbar = uact ? Rj + G0 * G2 * rcp_nr(G0 + G2) + G1 * G3 * rcp_nr(G1 + G3) : 1.0;       // idle lanes: identity rows
                 // reduced gradient  ru = H du + R du + g0 - lam0 + lam1 + [u1 inputs] h * sum_{k>ki} (lam6_k - lam5_k)
                 cb[lane] = uact ? du : 0.0;
                 const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
@@ -1493,11 +1493,11 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(Dt[i]), "+v"(Dlam[i]));
             double it_[4], il_[4], rc[4], Dit[2], Dil[2], Drc[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { it_[i] = 1.0 / t[i]; il_[i] = 1.0 / lam[i]; rc[i] = t[i] * lam[i]; }
+            for (int i = 0; i < 4; ++i) { it_[i] = rcp_nr(t[i]); il_[i] = rcp_nr(lam[i]); rc[i] = t[i] * lam[i]; }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { Dit[i] = 1.0 / Dt[i]; Dil[i] = 1.0 / Dlam[i]; Drc[i] = Dt[i] * Dlam[i]; }
+            for (int i = 0; i < 2; ++i) { Dit[i] = rcp_nr(Dt[i]); Dil[i] = rcp_nr(Dlam[i]); Drc[i] = Dt[i] * Dlam[i]; }
             const double G0 = lam[0] * it_[0], G1 = lam[1] * it_[1], G2 = lam[2] * it_[2], G3 = lam[3] * it_[3];
-            const double iG02 = 1.0 / (G0 + G2), iG13 = 1.0 / (G1 + G3);
+            const double iG02 = rcp_nr(G0 + G2), iG13 = rcp_nr(G1 + G3);
             const double G5 = Dlam[0] * Dit[0], G6 = Dlam[1] * Dit[1];
             const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
             const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
@@ -1547,7 +1547,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
 #pragma unroll
                 for (int i = 0; i < 2; ++i) rr = fmax(rr, dact ? fmax(-Ddt[i] * Dit[i], -Ddlam[i] * Dil[i]) : 0.0);
                 rr = wave_reduce<OpMax>(rr);
-                const double amax = rr > 1.0 ? 1.0 / rr : 1.0;
+                const double amax = rr > 1.0 ? rcp_nr(rr) : 1.0;
                 if (pass == 0) {
                     double s_aff = 0.0;
 #pragma unroll
@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
 #pragma unroll
                     for (int i = 0; i < 2; ++i) s_aff += dact ? (Dt[i] + amax * Ddt[i]) * (Dlam[i] + amax * Ddlam[i]) : 0.0;
                     mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
-                    double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+                    double sigma = mu_aff * rcp_nr(mu); sigma = sigma * sigma * sigma;
                     const double smu = sigma * mu;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
