@@ -1023,6 +1023,11 @@ __device__ __forceinline__ void newton_row_40(double (&a)[40], const unsigned ro
     asm volatile(ADMPC_ROWBUILD_ASM_40_B : RB_OUT(a, 20) : "v"(row_addr), "v"(dbar), "v"(s_odd) : "s46", "s47", "memory");
 }
 
+// full row `lane` of the symmetric H (packed lower-triangular rows in LDS) for the mat-vec: symrow() in gen_subst_asm.py
+__device__ __forceinline__ void sym_row_40(double (&a)[40], const unsigned row_addr, const unsigned col_addr) {
+    asm volatile(ADMPC_SYMROW_ASM_40_A : RB_OUT(a, 0) : "v"(row_addr), "v"(col_addr) : "memory");
+    asm volatile(ADMPC_SYMROW_ASM_40_B : RB_OUT(a, 20) : "v"(row_addr), "v"(col_addr) : "memory");
+}
 #define RB_IN(a, o) "v"(a[o + 0]), "v"(a[o + 1]), "v"(a[o + 2]), "v"(a[o + 3]), "v"(a[o + 4]), "v"(a[o + 5]), "v"(a[o + 6]), "v"(a[o + 7]), "v"(a[o + 8]), \
                     "v"(a[o + 9]), "v"(a[o + 10]), "v"(a[o + 11]), "v"(a[o + 12]), "v"(a[o + 13]), "v"(a[o + 14]), "v"(a[o + 15]), "v"(a[o + 16]), \
                     "v"(a[o + 17]), "v"(a[o + 18]), "v"(a[o + 19])
@@ -1397,13 +1402,18 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? G56 : 0.0);
                 sb2[lane] = rdlane(Ssuf_incl, 63) - Ssuf_incl;          // lane = stage: sum over stages > lane
                 WSYNC();
+                // H du: the lane's full row of H by EXEC-masked loads (no address arithmetic), du[c] through DPP row broadcasts
                 double hdu = 0.0;
+                {
+                    double Rd3[3];
 #pragma unroll
-                for (int i2 = 0; i2 < n; i2 += 2) {
-                    const double2 dv = *reinterpret_cast<const double2*>(cb + i2);
-                    const int a0 = i2 <= lz ? trz + i2 : (i2 * (i2 + 1)) / 2 + lz;
-                    const int a1 = i2 + 1 <= lz ? trz + i2 + 1 : ((i2 + 1) * (i2 + 2)) / 2 + lz;
-                    hdu += Hp[uz ? a0 : 0] * dv.x + Hp[uz ? a1 : 0] * dv.y;
+                    for (int m = 0; m < 3; ++m) Rd3[m] = cb[16 * m + (lane & 15)];
+                    double hv[n];
+                    sym_row_40(hv, lds_byte_addr(Hp + (uz ? trz : 0)), lds_byte_addr(Hp + (uz ? lz : 0)));
+                    static_for<0, n>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        fmac_rowbc_ld<c % 16>(hdu, Rd3[c / 16], hv[c]);
+                    });
                 }
                 ru = hdu + Rj * du + PK_G0 - lam[0] + lam[1] + (ji ? h * sb[uact ? ki : 0] : 0.0);
                 S_i = h * h * sb2[uact ? ki : 0];                        // lane = input: S_{k_i}

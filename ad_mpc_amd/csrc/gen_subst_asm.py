@@ -98,6 +98,27 @@ def rowstore(n, lo, hi):
     return out
 
 
+def symrow(n, lo, hi):
+    """Row of the symmetric matrix stored as packed lower-triangular rows, columns lo..hi-1, for the mat-vec: lanes >= c read
+    H[lane][c] (row address + 8 c), lanes < c read H[c][lane] (column address + 8 c (c + 1) / 2) -- two EXEC-masked loads per
+    column into the same register, all in flight together.  Operands: %0..%(hi-lo-1) outputs, then row address, column address.
+    Lanes >= n keep 0."""
+    cnt = hi - lo; RA, CA = cnt, cnt + 1
+    out = []
+    for q in range(cnt):
+        out.append("v_mov_b64 %%%d, 0" % q)
+    for q in range(cnt):
+        c = lo + q
+        out.append("s_bfm_b64 exec, %d, %d" % (n - c, c))
+        out.append("ds_read_b64 %%%d, %%%d offset:%d" % (q, RA, 8 * c))
+        if c > 0:
+            out.append("s_bfm_b64 exec, %d, 0" % c)
+            out.append("ds_read_b64 %%%d, %%%d offset:%d" % (q, CA, 8 * (c * (c + 1) // 2)))
+    out.append("s_mov_b64 exec, -1")
+    out.append("s_waitcnt lgkmcnt(0)")
+    return out
+
+
 def emit(name, lines):
     body = " \\\n".join('    "%s\\n\\t"' % l for l in lines)
     return "#define %s \\\n%s\n" % (name, body)
@@ -110,6 +131,7 @@ def main():
     txt += emit("ADMPC_FWD_SUBST_ASM_%d" % n, fwd(n)) + "\n" + emit("ADMPC_BWD_SUBST_ASM_%d" % n, bwd(n)) + "\n"
     txt += emit("ADMPC_ROWBUILD_ASM_%d_A" % n, rowbuild(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWBUILD_ASM_%d_B" % n, rowbuild(n, n // 2, n)) + "\n"
     txt += emit("ADMPC_ROWSTORE_ASM_%d_A" % n, rowstore(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWSTORE_ASM_%d_B" % n, rowstore(n, n // 2, n)) + "\n"
+    txt += emit("ADMPC_SYMROW_ASM_%d_A" % n, symrow(n, 0, n // 2)) + "\n" + emit("ADMPC_SYMROW_ASM_%d_B" % n, symrow(n, n // 2, n)) + "\n"
     txt += "#define ADMPC_SUBST_CLOBBERS %s, \"memory\"\n" % clob
     open(sys.argv[1] if len(sys.argv) > 1 else "subst_asm.inc", "w").write(txt)
 
