@@ -1070,6 +1070,12 @@ __device__ __forceinline__ void fmac_rowbc4_ld(double& a0, double& a1, double& a
         "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(L), "v"(s), "n"(BC), "n"(BC + 1), "n"(BC + 2), "n"(BC + 3));
 }
+// Single update whose result is read by a v_readlane right behind it (the pivot of the next column): pads on both sides.
+// HAZARD (measured, scripts/probes/subst_probe.hip): a v_readlane of a VGPR needs one wait state after the VALU write.
+template <int BC>
+__device__ __forceinline__ void fmac_rowbc_then_readlane(double& acc, const double L, const double s) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
+}
 // Copies of 16-lane row r of v in all four rows, r = 0..2 (row 3 is idle in the 40-row factorisation): gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
 //   swap16(X, X) -> (R0,R0,R2,R2), (R1,R1,R3,R3);  swap32(E, E) -> (R0 x4), (R2 x4);  swap32(O, O) -> (R1 x4), (R3 x4)
@@ -1474,8 +1480,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     constexpr int j = decltype(jc)::value;
                     constexpr bool own = (j + 1) / 16 == 2;                     // DPP source written by the VALU (hazard pad) or loaded from LDS
                     double Rn[3], nln;
-                    if constexpr (own) fmac_rowbc<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
-                    else fmac_rowbc_ld<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
+                    fmac_rowbc_then_readlane<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
                     chain(std::integral_constant<int, j + 1>{}, Rn, nln);
                     constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;        // first 4-aligned column >= j + 2
                     static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {

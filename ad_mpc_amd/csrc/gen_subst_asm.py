@@ -18,46 +18,42 @@ D = 8
 Y, ADDR, RING, SB, SAVE = 100, 102, 104, 40, 46
 
 
-def fwd(n):
-    """L z = y, unit lower L: lane i reads L[i][j] at base_i + 8 j (base_i = &Lp[i(i+1)/2]); lanes j+1 .. n-1 take part in step j."""
-    steps = list(range(n - 1))
+def _subst(n, steps, offset_of, exec_of):
+    """Common schedule of both substitutions.  Ring slot s % D holds the factor entries of step s and is refilled (for step
+    s + D) one step later.  HAZARD (measured on MI355X, scripts/probes/subst_probe.hip: wrong and non-repeatable results
+    without it): the v_readlane_b32 pair of the next step reads the register the v_fma_f64 has just written; one wait state
+    is required between them and an LDS instruction does NOT count as one -- hence the s_nop 0 closing every step.  (The
+    assembler cannot check hazards inside inline assembly; hipcc's own recogniser never sees these instructions.)"""
     out = ["s_mov_b64 s[%d:%d], exec" % (SAVE, SAVE + 1)]
-    for q in range(min(D, len(steps))):
-        out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (RING + 2 * q, RING + 2 * q + 1, ADDR, 8 * steps[q]))
-    issued = min(D, len(steps))
+    issued = []                                   # step indices in issue order
+    def load(s):
+        t = RING + 2 * (s % D)
+        out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, offset_of(steps[s])))
+        issued.append(s)
+    for s in range(min(D, len(steps))):
+        load(s)
     for s, j in enumerate(steps):
         sp = SB + 2 * (s & 1); t = RING + 2 * (s % D)
         out.append("v_readlane_b32 s%d, v%d, %d" % (sp, Y, j))
         out.append("v_readlane_b32 s%d, v%d, %d" % (sp + 1, Y + 1, j))
-        out.append("s_bfm_b64 exec, %d, %d" % (n - 1 - j, j + 1))
-        out.append("s_waitcnt lgkmcnt(%d)" % (issued - 1 - s))
+        out.append(exec_of(j))
+        out.append("s_waitcnt lgkmcnt(%d)" % (len(issued) - 1 - issued.index(s)))
         out.append("v_fma_f64 v[%d:%d], -s[%d:%d], v[%d:%d], v[%d:%d]" % (Y, Y + 1, sp, sp + 1, t, t + 1, Y, Y + 1))
-        if issued < len(steps):
-            out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, 8 * steps[issued])); issued += 1
+        if s >= 1 and s - 1 + D < len(steps):
+            load(s - 1 + D)                       # refill the slot of the previous step
+        out.append("s_nop 0")                     # hazard pad: v_fma_f64 result -> v_readlane of it (see _subst.__doc__)
     out.append("s_mov_b64 exec, s[%d:%d]" % (SAVE, SAVE + 1))
     return out
+
+
+def fwd(n):
+    """L z = y, unit lower L: lane i reads L[i][j] at base_i + 8 j (base_i = &Lp[i(i+1)/2]); lanes j+1 .. n-1 take part in step j."""
+    return _subst(n, list(range(n - 1)), lambda j: 8 * j, lambda j: "s_bfm_b64 exec, %d, %d" % (n - 1 - j, j + 1))
 
 
 def bwd(n):
     """L' x = z: lane i reads L[j][i] at base_i + 8 j(j+1)/2 (base_i = &Lp[i]); lanes 0 .. j-1 take part in step j = n-1 .. 1."""
-    steps = list(range(n - 1, 0, -1))
-    out = ["s_mov_b64 s[%d:%d], exec" % (SAVE, SAVE + 1)]
-    for q in range(min(D, len(steps))):
-        j = steps[q]
-        out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (RING + 2 * q, RING + 2 * q + 1, ADDR, 8 * (j * (j + 1) // 2)))
-    issued = min(D, len(steps))
-    for s, j in enumerate(steps):
-        sp = SB + 2 * (s & 1); t = RING + 2 * (s % D)
-        out.append("v_readlane_b32 s%d, v%d, %d" % (sp, Y, j))
-        out.append("v_readlane_b32 s%d, v%d, %d" % (sp + 1, Y + 1, j))
-        out.append("s_bfm_b64 exec, %d, 0" % j)
-        out.append("s_waitcnt lgkmcnt(%d)" % (issued - 1 - s))
-        out.append("v_fma_f64 v[%d:%d], -s[%d:%d], v[%d:%d], v[%d:%d]" % (Y, Y + 1, sp, sp + 1, t, t + 1, Y, Y + 1))
-        if issued < len(steps):
-            jn = steps[issued]
-            out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, 8 * (jn * (jn + 1) // 2))); issued += 1
-    out.append("s_mov_b64 exec, s[%d:%d]" % (SAVE, SAVE + 1))
-    return out
+    return _subst(n, list(range(n - 1, 0, -1)), lambda j: 8 * (j * (j + 1) // 2), lambda j: "s_bfm_b64 exec, %d, 0" % j)
 
 
 def rowbuild(n, lo, hi):

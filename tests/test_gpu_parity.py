@@ -94,6 +94,22 @@ def test_all_state_weights_nonzero(gpu_engine_factory, oracle):
         _assert_parity(g, o)
 
 
+def test_bitwise_repeatability(gpu_engine_factory):
+    """Instances are independent and every wave's arithmetic is fixed, so repeated solves must agree bit for bit -- for any
+    batch size and whatever the scheduler's draw order.  Small batches matter: a wave that is alone on its SIMD gets no
+    accidental wait states from a neighbour, which is how an instruction hazard inside the hand-written assembly (a v_readlane
+    directly behind the v_fma_f64 that writes its source) once showed up as 1e-15 run-to-run noise."""
+    cfg = default_config(N=20)
+    for B, seed in ((6, 3), (40, 5), (700, 7)):
+        s = random_scenarios(B, N=20, seed=seed, blend=(3.0, 5.0))
+        eng = gpu_engine_factory(cfg)
+        ref = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        for _ in range(25):
+            g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+            for a, b in zip(g, ref):
+                np.testing.assert_array_equal(a, b)
+
+
 def test_full_size_batch_4096(gpu_engine_factory, oracle):
     """BASELINE configs[1] at full size: direct parity for every instance plus size-independent properties."""
     cfg = default_config(N=20)
