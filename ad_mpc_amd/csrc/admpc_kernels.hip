@@ -204,20 +204,21 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
 #define GTS 42           // doubles per stage of the packed linearisation
 #define PKS 28           // packed symmetric 7x7
 #define KLS 17           // K0[7] K1[7] i00 i01 i11
+#define LIN_BLOCK 64     // threads per block of the linearisation kernel: single waves balance best over the CUs (256 registers each)
 // work scheduler of the condensed path (int array): [0] ticket counter, [64 + q] number of instances in effort bucket q,
 // [SCHED_HDR + q * cap + j] j-th instance of bucket q.  Zeroed by the linearisation kernel, filled by the condensing kernel,
 // drained (highest bucket first) by the persistent interior-point waves.
 #define SCHED_NB 64
 #define SCHED_HDR 128
 
-__global__ __launch_bounds__(256) void admpc_linearize_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+__global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                               const double* __restrict__ xbarg, const double* __restrict__ ubarg,
                                                               const double* __restrict__ pg, const int32_t* __restrict__ skip,
                                                               double* __restrict__ GTg, double* __restrict__ blg, int* __restrict__ sched)
 {
     const int N = cfg->N;
     const long total = (long)B * N * 3;
-    if (sched && blockIdx.x == 0 && threadIdx.x < SCHED_HDR) sched[threadIdx.x] = 0;     // ticket counter + bucket counts of this step
+    if (sched && blockIdx.x == 0) for (int i = threadIdx.x; i < SCHED_HDR; i += blockDim.x) sched[i] = 0;     // ticket counter + bucket counts of this step
     for (long tsk = (long)blockIdx.x * blockDim.x + threadIdx.x; tsk < total; tsk += (long)gridDim.x * blockDim.x) {
         const long sk = tsk / 3; const int g = (int)(tsk % 3);
         const long inst = sk / N; const int k = (int)(sk % N);
@@ -2095,12 +2096,12 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     int gridB = s->num_cu * s->blocks_per_cu;
     if (gridB > B) gridB = B;
     const long totalA = (long)B * N * 3;
-    int gridA = (int)((totalA + 255) / 256);
-    if (gridA > s->num_cu * 16) gridA = s->num_cu * 16;
+    int gridA = (int)((totalA + LIN_BLOCK - 1) / LIN_BLOCK);
+    if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     for (int sq = 0; sq < nsqp; ++sq) {
         const int first = sq == 0 ? 1 : 0;
-        hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(256), 0, st, s->d_cfg, B, xbar, ubar, p,
+        hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->use_dense ? s->d_sched : (int*)nullptr);
 #define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
                            (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
