@@ -1,0 +1,133 @@
+"""Loader of the reference's fitted GP models.
+
+On-disk format (reference ``src/model_fitting/gp.py:489-516``, ``GPRegressor.save``): one ``joblib`` pickle per regressor
+holding a dict with the keys ``kernel_params`` ({'l', 'sigma_f'}), ``kernel_type`` ('squared_exponential'), ``x_train``,
+``y_train``, ``k_inv_y``, ``k_inv``, ``sigma_n``, ``reg_dim``, ``x_features``, ``u_features``, ``mean``, ``y_mean``.
+Directory scheme (``src/utils/utils.py:175-236``): ``<save_dir>/<git>/<model_name>/<file_name>*.pkl`` with
+``file_name = '__'.join(('' if v else 'no_') + k for k, v in sorted(params.items()))``.
+
+The engine evaluates the GP mean  mu(z) = sum_i k(z, x_train_i) k_inv_y_i + y_mean  with  k = sigma_f exp(-|z - x|^2 / (2 l^2))
+(sigma_f is NOT squared in the reference, ``gp.py:81-138``) inside the dynamics (``ad_mpc_amd.config.set_gp``).  Device limits:
+1-D feature per regressor, at most 4 regressors and 32 training points each; anything else raises ``ValueError`` (the reference's
+ensembles / clusters, ``gp.py:738-770``, are not on the device path).
+"""
+import os
+
+import numpy as np
+
+from .config import GP_MAX, GP_MAX_POINTS, NX, NU, set_gp
+
+SAVED_KEYS = ("kernel_params", "kernel_type", "x_train", "y_train", "k_inv_y", "k_inv", "sigma_n", "reg_dim", "x_features",
+              "u_features", "mean", "y_mean")
+
+
+def get_model_dir_and_file(model_options, save_dir):
+    """utils.py:175-188 with the save directory passed in instead of read from ``GPConfig.SAVE_DIR``."""
+    directory = os.path.join(save_dir, str(model_options["git"]), str(model_options["model_name"]))
+    params = model_options["params"]
+    parts = [("" if params[k] else "no_") + k for k in sorted(params.keys())]
+    return directory, "__".join(parts)
+
+
+def load_pickled_models(directory="", file_name="", model_options=None, save_dir=None):
+    """utils.py:191-236: ``{"models": [dict, ...]}`` for every ``<file_name>*.pkl`` in ``directory`` (``feats.csv`` is skipped
+    as in the reference), ``None`` when the directory or a matching file is missing."""
+    import joblib
+    if model_options is not None:
+        directory, file_name = get_model_dir_and_file(model_options, save_dir if save_dir is not None else "")
+    try:
+        files = sorted(os.listdir(directory))
+    except FileNotFoundError:
+        return None
+    models = []
+    for f in files:
+        if not f.startswith(file_name) and f != "feats.csv":
+            continue
+        if ".pkl" not in f:
+            continue
+        path = os.path.join(directory, f)
+        if os.path.isdir(path):
+            raise FileNotFoundError("Tried to load file from directory %s, but it was not found." % directory)
+        models.append(joblib.load(path))
+    return {"models": models} if models else None
+
+
+def gp_entry_from_saved(d):
+    """One saved regressor dict -> the dict ``set_gp`` takes (feat, out, Z, alpha, length_scale, sigma_f, ymean)."""
+    missing = [k for k in ("kernel_params", "kernel_type", "x_train", "k_inv_y", "reg_dim", "x_features", "u_features") if k not in d]
+    if missing:
+        raise ValueError("not a saved GPRegressor: missing %s" % missing)
+    if d["kernel_type"] != "squared_exponential":
+        raise ValueError("only the squared_exponential kernel is supported (gp.py:60)")
+    xf = [int(i) for i in np.atleast_1d(d["x_features"]).reshape(-1)] if d["x_features"] is not None else []
+    uf = [int(i) for i in np.atleast_1d(d["u_features"]).reshape(-1)] if d["u_features"] is not None else []
+    if len(xf) + len(uf) != 1:
+        raise ValueError("device GPs take ONE feature; this regressor has x_features=%s u_features=%s" % (xf, uf))
+    feat = xf[0] if xf else NX + uf[0]
+    if not (0 <= feat < NX + NU):
+        raise ValueError("feature index %d outside [x(7); u(2)]" % feat)
+    Z = np.asarray(d["x_train"], dtype=np.float64)
+    Z = Z.reshape(Z.shape[0], -1)
+    if Z.shape[1] != 1:
+        raise ValueError("x_train must be n x 1 for a one-feature regressor, got %s" % (Z.shape,))
+    alpha = np.asarray(d["k_inv_y"], dtype=np.float64).reshape(-1)
+    if alpha.size != Z.shape[0]:
+        raise ValueError("k_inv_y has %d entries for %d training points" % (alpha.size, Z.shape[0]))
+    if Z.shape[0] > GP_MAX_POINTS:
+        raise ValueError("%d training points; the device holds at most %d" % (Z.shape[0], GP_MAX_POINTS))
+    kp = d["kernel_params"]
+    ell = float(np.squeeze(kp["l"])) if "l" in kp else 1.0
+    out = int(np.squeeze(d["reg_dim"]))
+    if not (0 <= out < NX):
+        raise ValueError("reg_dim %d outside the state" % out)
+    ymean = float(np.squeeze(d["y_mean"])) if d.get("y_mean") is not None else 0.0
+    return dict(feat=feat, out=out, Z=Z[:, 0], alpha=alpha, length_scale=ell, sigma_f=float(kp.get("sigma_f", 1.0)), ymean=ymean)
+
+
+def gps_from_pickled(pre_trained_models):
+    """``{"models": [...]}`` (or a plain list of saved dicts) -> list for ``set_gp``.  Several regressors for the same output
+    dimension are the reference's per-cluster ensembles: rejected."""
+    models = pre_trained_models["models"] if isinstance(pre_trained_models, dict) else list(pre_trained_models)
+    if len(models) > GP_MAX:
+        raise ValueError("%d regressors; the device holds at most %d" % (len(models), GP_MAX))
+    gps = [gp_entry_from_saved(m) for m in models]
+    outs = [g["out"] for g in gps]
+    if len(set(outs)) != len(outs):
+        raise ValueError("several regressors for one output dimension (a clustered ensemble) are not supported on the device")
+    return sorted(gps, key=lambda g: g["out"])
+
+
+def install_from_directory(cfg, directory="", file_name="", model_options=None, save_dir=None):
+    """Load the pickles and install them into ``cfg``; returns the number of regressors (0 when nothing was found)."""
+    pm = load_pickled_models(directory, file_name, model_options, save_dir)
+    if pm is None:
+        return 0
+    gps = gps_from_pickled(pm)
+    set_gp(cfg, gps)
+    return len(gps)
+
+
+def save_regressor(path, entry, sigma_n=1e-3):
+    """Write one regressor in the reference's format (used by tests and for hand-made models): ``entry`` as for ``set_gp``
+    plus optional ``y_train``.  The key set and value shapes follow ``GPRegressor.save`` (gp.py:495-508)."""
+    import joblib
+    Z = np.asarray(entry["Z"], dtype=np.float64).reshape(-1, 1)
+    feat = int(entry["feat"])
+    d = {
+        "kernel_params": {"l": np.array([float(entry["length_scale"])]), "sigma_f": float(entry.get("sigma_f", 1.0))},
+        "kernel_type": "squared_exponential",
+        "x_train": Z,
+        "y_train": np.asarray(entry.get("y_train", np.zeros(Z.shape[0])), dtype=np.float64).reshape(-1, 1),
+        "k_inv_y": np.asarray(entry["alpha"], dtype=np.float64).reshape(-1, 1),
+        "k_inv": np.eye(Z.shape[0]),
+        "sigma_n": float(sigma_n),
+        "reg_dim": int(entry["out"]),
+        "x_features": [feat] if feat < NX else [],
+        "u_features": [feat - NX] if feat >= NX else [],
+        "mean": np.zeros(1),
+        "y_mean": np.array(float(entry.get("ymean", 0.0))),
+    }
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        joblib.dump(d, f)
+    return d
