@@ -48,6 +48,24 @@ def algorithmic_flops_per_solve(N, mean_ipm_iters):
     return N * 4360.0 + N * 1900.0 * mean_ipm_iters
 
 
+def measured_traffic(N, B):
+    """HBM bytes of one step from the committed PMC passes (profiles/*/..._pmc_summary.json, written by scripts/profile.sh on
+    the same workload: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as the microarchitecture guide
+    prescribes for gfx950).  Counters cannot be read inside this process; None unless the profile matches this workload."""
+    if N != 20 or B != 4096:
+        return None
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json"))):
+        try:
+            t = json.load(open(f)).get("_step_traffic")
+        except Exception:
+            t = None
+        if t:
+            best = {"bytes": t["bytes"], "source": os.path.relpath(f, ROOT)}
+    return best
+
+
 def cpu_baseline(cfg, scen, target_seconds=12.0):
     """Time the CPU oracle (OpenMP build of oracle/admpc_oracle.c) on the same workload, bounded sample."""
     from oracle.oracle import Oracle, build
@@ -149,6 +167,7 @@ def main():
         value = total / elapsed
         flops = algorithmic_flops_per_solve(N, mean_iters) * B
         byts = algorithmic_bytes_per_solve(N) * B
+        traffic = None if (args.gp or args.dynamic) else measured_traffic(N, B)
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
         out = {
@@ -160,7 +179,8 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "seed": 1234,
                        "collective": "RCCL all-gather arg-min (16 B/rank)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": (traffic or {}).get("bytes"),
+                         "traffic_source": (traffic or {}).get("source"),
                          "kernel": "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~70 %) + admpc_expand_kernel<20>" if N == 20 else "one step = admpc_linearize_kernel + admpc_qp_kernel (stage-wise Riccati)", "kernel_ms": kern_ms,
                          "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*mean_ipm_iters per solve (SURVEY 8d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
