@@ -191,6 +191,30 @@ def test_failure_status_and_untouched_iterate(gpu_engine_factory, oracle):
     np.testing.assert_array_equal(g[0][bad], s["xbar"][bad]); np.testing.assert_array_equal(g[1][bad], s["ubar"][bad])
 
 
+def test_odd_batch_sizes_and_mixed_failures_over_sqp_iterations(gpu_engine_factory, oracle):
+    """Batch sizes around the wave / persistent-grid boundaries (1, 63..65, just above 2048 = one instance per resident wave),
+    and a three-step SQP in which some instances fail in the first step: they must be skipped by every later kernel
+    (linearise, condense, interior point, expand), keep status 4 / cost inf / their iterate, and not disturb the others."""
+    cfg = default_config(N=20)
+    for B in (1, 63, 64, 65, 2049, 2500):
+        s = random_scenarios(B, N=20, seed=100 + B, blend=(3.0, 5.0))
+        g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+        assert (g[3] == 0).all()
+        _assert_parity(g, o)
+    cfg3 = default_config(N=20, sqp_iters=3)
+    good = random_scenarios(40, N=20, seed=11, blend=(3.0, 5.0))
+    bad = random_scenarios(8, N=20, seed=3, blend=(3.0, 5.0), init="zeros")            # zeros iterate with p > 0: non-finite model
+    s = {k: np.concatenate([good[k][:20], bad[k], good[k][20:]]) for k in good}
+    g, o = _solve_both(gpu_engine_factory(cfg3), oracle, cfg3, s)
+    np.testing.assert_array_equal(g[3], o[3])
+    failed = g[3] != 0
+    assert failed.any() and (~failed).sum() >= 40
+    assert np.isinf(g[2][failed]).all()
+    np.testing.assert_array_equal(g[0][failed], s["xbar"][failed]); np.testing.assert_array_equal(g[1][failed], s["ubar"][failed])
+    ok = ~failed
+    assert np.abs(g[1][ok] - o[1][ok]).max() <= 1e-7 and np.abs(g[0][ok] - o[0][ok]).max() <= 1e-7
+
+
 def test_empty_batch_and_argument_errors(gpu_engine_factory):
     import torch
     from ad_mpc_amd import _lib
