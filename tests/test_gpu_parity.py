@@ -215,6 +215,38 @@ def test_odd_batch_sizes_and_mixed_failures_over_sqp_iterations(gpu_engine_facto
     assert np.abs(g[1][ok] - o[1][ok]).max() <= 1e-7 and np.abs(g[0][ok] - o[0][ok]).max() <= 1e-7
 
 
+def test_solve_is_capturable_in_a_hip_graph(gpu_engine_factory):
+    """admpc_solve_batch is launches only (no allocation, no copy, no synchronisation after admpc_reserve): it can be
+    captured into a hipGraph on the caller's stream and replayed; the replay reproduces the eager result bit for bit."""
+    import torch
+    cfg = default_config(N=20)
+    s = random_scenarios(300, N=20, seed=21, blend=(3.0, 5.0))
+    eng = gpu_engine_factory(cfg)
+    d = eng.to_device
+    x0, yref, yref_e, p = d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"])
+    xb0, ub0 = d(s["xbar"]), d(s["ubar"])
+    xb, ub = xb0.clone(), ub0.clone()
+    cost = torch.empty(300, dtype=torch.float64, device=eng.device)
+    st = torch.empty(300, dtype=torch.int32, device=eng.device); it = torch.empty_like(st)
+    eng.solve(x0, yref, yref_e, p, xb, ub, cost, st, it)              # eager (also reserves the workspace)
+    torch.cuda.synchronize()
+    ref = (xb.clone(), ub.clone(), cost.clone(), st.clone(), it.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    xb.copy_(xb0); ub.copy_(ub0)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            eng.solve(x0, yref, yref_e, p, xb, ub, cost, st, it)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        xb.copy_(xb0); ub.copy_(ub0); cost.zero_(); st.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip((xb, ub, cost, st, it), ref):
+            assert torch.equal(a, b)
+
+
 def test_empty_batch_and_argument_errors(gpu_engine_factory):
     import torch
     from ad_mpc_amd import _lib
