@@ -1339,7 +1339,78 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
     const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
     const int itmax = cfg->ipm_iter_max;
+    const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
+    // Factorisation of the Newton matrix M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) into L D L' (LDS: Lp, invd).
+    // Used twice per instance at most: once without barrier terms (the unconstrained trial) and once per interior-point iteration.
+    auto factorise = [&](const double dbar_, const double sodd_, const int lz_) __attribute__((always_inline)) {
+        const int trz_ = lz_ * (lz_ + 1) / 2;
+        const bool uz_ = lz_ < n;
+        double a[n];
+        // a[c] = (c <= lane ? H[lane][c] : 0) + (c odd and this lane is a u1 input ? S_i : 0) + (c == lane ? Dbar : 0);
+        // idle lanes: unit rows (Dbar = 1 on a diagonal that never becomes a pivot, zeros elsewhere)
+        newton_row_40(a, lds_byte_addr(Hp + (uz_ ? trz_ : 0)), dbar_, sodd_);
+        // Square-root-free right-looking factorisation M = L D L' (unit lower L), row i in the registers of lane i.
+        // Column j (unscaled, w_i = a_i[j]) is published in LDS and read back as "block m in every 16-lane row", the DPP
+        // sources of the rank-1 update: a[jj] -= w_jj * (w_i / D_jj) is ONE v_fmac_f64_dpp per jj.  Look-ahead: the first
+        // update of column j makes column j+1 final; its pivot chain (v_readlane, v_rcp_f64 + Newton, scale, publish,
+        // read back) is started right there and completes under the remaining updates of column j.
+        // Entries on and above the diagonal of a row are never read (lane jj's w_jj is only picked up for jj > j), so the
+        // column is used unmasked; only the store of L is masked (EXEC).
+        const unsigned lrow = lds_byte_addr(Lp + (uz_ ? trz_ : 0));
+        double R[3], nl;
+        auto chain = [&](auto jc, double (&Rn)[3], double& nln) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const double dj = rdlane(a[j], j);
+            const double dinv = rcp_nr(dj);                             // 1 / D_jj
+            const double lu = a[j] * dinv;                              // L_ij for the lanes below the diagonal
+            invd[j] = dinv;                                             // uniform value, same address
+            if constexpr (j + 1 < n) {
+                asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
+                             : : "v"(lrow), "v"(lu), "n"(n - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
+                nln = -lu;
+                if constexpr ((j + 1) / 16 == 2) Rn[2] = a[j];          // only lanes 32..39 are still involved: own row
+                else {
+                    double* const cbuf = (j & 1) ? sb : cb;
+                    cbuf[lane] = a[j];
+#pragma unroll
+                    for (int m = (j + 1) / 16; m < 3; ++m) Rn[m] = cbuf[16 * m + (lane & 15)];
+                }
+            }
+        };
+        chain(std::integral_constant<int, 0>{}, R, nl);
+        static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr bool own = (j + 1) / 16 == 2;                     // DPP source written by the VALU (hazard pad) or loaded from LDS
+            double Rn[3], nln;
+            fmac_rowbc_then_readlane<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
+            chain(std::integral_constant<int, j + 1>{}, Rn, nln);
+            constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;        // first 4-aligned column >= j + 2
+            static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
+                constexpr int jj = decltype(c)::value;
+                if constexpr (own) fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
+                else fmac_rowbc_ld<jj % 16>(a[jj], R[jj / 16], nl);
+            });
+            static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
+                constexpr int jj = 4 * decltype(c)::value;
+                if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+                else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+            });
+#pragma unroll
+            for (int m = 0; m < 3; ++m) R[m] = Rn[m];
+            nl = nln;
+        });
+        WSYNC();
+    };
+    // M x = y through the factor: L z = y, z *= D^-1, L' x = z (assembly, see gen_subst_asm.py)
+    auto ldl_solve = [&](double y, const int lz_) __attribute__((always_inline)) -> double {
+        static_assert(n == 40, "the substitution assembly is generated for n = 40");
+        const bool uz_ = lz_ < n;
+        fwd_subst_40(y, lds_byte_addr(Lp + (uz_ ? lz_ * (lz_ + 1) / 2 : 0)));           // idle lanes: a harmless in-bounds row
+        double x = y * invd[uz_ ? lz_ : 0];
+        bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)));
+        return x;
+    };
 
     // Instances need 4 .. 15+ interior-point iterations each: a static instance -> wave map leaves most of the chip idle while
     // the unlucky waves finish.  The waves draw instances from the scheduler, predicted-expensive ones first.
@@ -1380,6 +1451,27 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
         int it = 0;
         PHASE_STAMP(0);
+        // ---------------- trial: the QP without its inequalities ----------------
+        // (H + R) du = -g0 is one factorisation and one solve (about 0.6 of an interior-point iteration).  If that minimiser
+        // respects the input box and the steering box it is the solution of the full QP -- no bound is active, the slacks are
+        // zero -- and the interior point is skipped (iters = 0).  True for 55 % of the config-2 scenarios; the oracle does the same.
+        bool solved = false;
+        if (try_unc) {
+            int lt = lane; asm volatile("" : "+v"(lt));
+            factorise(uact ? Rj : 1.0, 0.0, lt);
+            const double xt = ldl_solve(uact ? -g0 : 0.0, lt);
+            const double duc = uact ? xt : 0.0;
+            cb[lane] = duc;
+            WSYNC();
+            const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
+            const double pre = wave_scan_incl<OpSum>(du1_stage);
+            const double dx6c = xh6_own + h * (pre - du1_stage);
+            const bool ok = (!uact || (duc >= dl_i && duc <= duu_i)) && (!dact || (dx6c >= Ddl && dx6c <= Ddu));
+            WSYNC();
+            if (__all(ok)) { du = duc; solved = true; }
+        }
+        PHASE_STAMP(8);
+        if (!solved)
         for (; it < itmax; ++it) {
             int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
             asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops (hipcc parked ~200 of them in scratch)
@@ -1443,63 +1535,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             }
             PHASE_STAMP(1);
             // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block, then its factorisation
-            {
-                double a[n];
-                // a[c] = (c <= lane ? H[lane][c] : 0) + (c odd and this lane is a u1 input ? S_i : 0) + (c == lane ? Dbar : 0);
-                // idle lanes: unit rows (Dbar = 1 on a diagonal that never becomes a pivot, zeros elsewhere)
-                newton_row_40(a, lds_byte_addr(Hp + (uz ? trz : 0)), Dbar, (uz && ji) ? S_i : 0.0);
-                // Square-root-free right-looking factorisation M = L D L' (unit lower L), row i in the registers of lane i.
-                // Column j (unscaled, w_i = a_i[j]) is published in LDS and read back as "block m in every 16-lane row", the DPP
-                // sources of the rank-1 update: a[jj] -= w_jj * (w_i / D_jj) is ONE v_fmac_f64_dpp per jj.  Look-ahead: the first
-                // update of column j makes column j+1 final; its pivot chain (v_readlane, v_rcp_f64 + Newton, scale, publish,
-                // read back) is started right there and completes under the remaining updates of column j.
-                // Entries on and above the diagonal of a row are never read (lane jj's w_jj is only picked up for jj > j), so the
-                // column is used unmasked; only the store of L is masked (EXEC).
-                const unsigned lrow = lds_byte_addr(Lp + (uz ? trz : 0));
-                double R[3], nl;
-                auto chain = [&](auto jc, double (&Rn)[3], double& nln) __attribute__((always_inline)) {
-                    constexpr int j = decltype(jc)::value;
-                    const double dj = rdlane(a[j], j);
-                    const double dinv = rcp_nr(dj);                             // 1 / D_jj
-                    const double lu = a[j] * dinv;                              // L_ij for the lanes below the diagonal
-                    invd[j] = dinv;                                             // uniform value, same address
-                    if constexpr (j + 1 < n) {
-                        asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
-                                     : : "v"(lrow), "v"(lu), "n"(n - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
-                        nln = -lu;
-                        if constexpr ((j + 1) / 16 == 2) Rn[2] = a[j];          // only lanes 32..39 are still involved: own row
-                        else {
-                            double* const cbuf = (j & 1) ? sb : cb;
-                            cbuf[lane] = a[j];
-#pragma unroll
-                            for (int m = (j + 1) / 16; m < 3; ++m) Rn[m] = cbuf[16 * m + (lane & 15)];
-                        }
-                    }
-                };
-                chain(std::integral_constant<int, 0>{}, R, nl);
-                static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr bool own = (j + 1) / 16 == 2;                     // DPP source written by the VALU (hazard pad) or loaded from LDS
-                    double Rn[3], nln;
-                    fmac_rowbc_then_readlane<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
-                    chain(std::integral_constant<int, j + 1>{}, Rn, nln);
-                    constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;        // first 4-aligned column >= j + 2
-                    static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
-                        constexpr int jj = decltype(c)::value;
-                        if constexpr (own) fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
-                        else fmac_rowbc_ld<jj % 16>(a[jj], R[jj / 16], nl);
-                    });
-                    static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
-                        constexpr int jj = 4 * decltype(c)::value;
-                        if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
-                        else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
-                    });
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) R[m] = Rn[m];
-                    nl = nln;
-                });
-                WSYNC();
-            }
+            factorise(Dbar, (uz && ji) ? S_i : 0.0, lz);
             PHASE_STAMP(2);
             // ---- phase C: re-derive the barrier quantities from (t, lam).  The asm statements make the compiler forget what
             //      it computed in phase A so that nothing but the state itself stays live across the factorisation.
@@ -1535,10 +1571,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
                 PHASE_STAMP(pass == 0 ? 3 : 5);
                 // ---- L z = y, z *= D^-1, L' x = z  (unit lower L packed by rows in LDS; assembly, see gen_subst_asm.py)
-                static_assert(n == 40, "the substitution assembly is generated for n = 40");
-                fwd_subst_40(y, lds_byte_addr(Lp + (uz ? trz : 0)));           // idle lanes: a harmless in-bounds row
-                double x = y * invd[uact ? lane : 0];
-                bwd_subst_40(x, lds_byte_addr(Lp + (uz ? lz : 0)));
+                const double x = ldl_solve(y, lz);
                 PHASE_STAMP(4);
                 ddu = uact ? x : 0.0;
                 // ---- delta rows: ddx6_k = h * sum_{k'<k} ddu_{(k',1)}
@@ -1969,6 +2002,7 @@ int admpc_default_config(AdmpcConfig* c, int N, double Ts)
     c->Iz = c->L_F * c->L_R * (r_mass + f_mass);
     c->Cf = f_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195; c->Cr = r_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195;
     c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9; c->ipm_tol_step = 1e-6;
+    c->ipm_try_unconstrained = N == 20 ? 1.0 : 0.0;
     return ADMPC_OK;
 }
 
@@ -2037,11 +2071,11 @@ void admpc_destroy(AdmpcSolver* s)
         unsigned long long h[16] = {0};
         (void)hipDeviceSynchronize();
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_ticks), sizeof h) == hipSuccess) {
-            static const char* nm[16] = {"ipm staging", "ipm phase A", "ipm factorisation", "ipm phase C", "ipm substitutions", "ipm expand/step", "ipm hand-over", "ipm scheduler draw", "-", "-",
+            static const char* nm[16] = {"ipm staging", "ipm phase A", "ipm factorisation", "ipm phase C", "ipm substitutions", "ipm expand/step", "ipm hand-over", "ipm scheduler draw", "ipm unconstrained trial", "-",
                                          "cond staging", "cond H accumulate", "cond propagate", "cond store+bin", "-", "-"};
             unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += h[i];
             unsigned long long totc = 0; for (int i = 10; i < 16; ++i) totc += h[i];
-            for (int i = 0; i < 14; ++i) if (i < 8 || i >= 10) fprintf(stderr, "[admpc phase] %-18s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)((i < 10 ? tot : totc) ? (i < 10 ? tot : totc) : 1));
+            for (int i = 0; i < 14; ++i) if (i < 9 || i >= 10) fprintf(stderr, "[admpc phase] %-18s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)((i < 10 ? tot : totc) ? (i < 10 ? tot : totc) : 1));
         }
     }
 #endif

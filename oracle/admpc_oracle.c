@@ -448,6 +448,33 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             for (int i = 0; i < 2; ++i) { s->td[k][i] = r0[i] > thr ? r0[i] : thr; s->lamd[k][i] = mu0 / s->td[k][i]; }
         }
     }
+    if (c->ipm_try_unconstrained != 0) {
+        /* Newton step of the QP WITHOUT its inequalities from the start point (du = 0, rolled-out dx, pi = 0): the exact
+         * minimiser of the equality-constrained QP.  If it respects the input box and the delta box it is the solution of
+         * the full QP (no bound active, slacks zero, L1 penalty idle) and the interior point is not needed (iters = 0). */
+        for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i)
+            w->gx[k][i] = (k == 0) ? 0 : ((k < N ? qp->Qd[i] : qp->Qe[i]) * s->dx[k][i] + qp->q[k][i]);
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < NU; ++j) { w->gu[k][j] = qp->r[k][j]; w->Rt[k][j] = qp->Rd[j]; }
+            w->Qt66[k] = qp->Qd[6];
+            for (int i = 0; i < NX; ++i) w->req[k][i] = 0;
+        }
+        riccati_factor(qp, (const real (*)[NU])w->Rt, w->Qt66, F);
+        riccati_solve(qp, F, (const real (*)[NX])w->gx, (const real (*)[NU])w->gu, (const real (*)[NX])w->req, w->ddu, w->ddx, w->dpi);
+        int ok = 1;
+        for (int k = 0; k < N && ok; ++k) {
+            for (int j = 0; j < NU; ++j) { real v = w->ddu[k][j]; if (!(v >= qp->dlu[k][j] && v <= qp->duu[k][j])) ok = 0; }
+            if (k >= 1) { real v = s->dx[k][6] + w->ddx[k][6]; if (!(v >= qp->dld[k] && v <= qp->dud[k])) ok = 0; }
+        }
+        if (ok) {
+            for (int k = 0; k < N; ++k) {
+                for (int j = 0; j < NU; ++j) { s->du[k][j] = w->ddu[k][j]; s->sl[k][j] = s->su[k][j] = 0; for (int i = 0; i < 4; ++i) s->lam[k][j][i] = 0; }
+                for (int i = 0; i < NX; ++i) { s->dx[k + 1][i] += w->ddx[k + 1][i]; s->pi[k][i] = w->dpi[k][i]; }
+                s->lamd[k][0] = s->lamd[k][1] = 0;
+            }
+            return 0;
+        }
+    }
     int it;
     real rmax_prev = 0, step = 1e300;   /* step: max-norm of the last applied input step */
     for (it = 0; it < c->ipm_iter_max; ++it) {

@@ -75,12 +75,29 @@ def test_both_qp_kernels_agree_at_n20(gpu_engine_factory, oracle, monkeypatch):
     s = random_scenarios(512, N=20, seed=77, blend=(3.0, 5.0))
     o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
     g_dense = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    # the Riccati kernel has no unconstrained trial (cfg.ipm_try_unconstrained is a condensed-path / oracle feature)
+    cfg_r = cfg.copy(); cfg_r.ipm_try_unconstrained = 0.0
+    o_r = oracle.solve_batch(cfg_r, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
     monkeypatch.setenv("ADMPC_QP", "riccati")
-    g_ric = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    g_ric = gpu_engine_factory(cfg_r).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
     monkeypatch.delenv("ADMPC_QP")
     _assert_parity(g_dense, o)
-    _assert_parity(g_ric, o)
+    _assert_parity(g_ric, o_r)
     assert np.abs(g_dense[1] - g_ric[1]).max() <= TOL
+
+
+def test_unconstrained_trial_on_and_off(gpu_engine_factory, oracle):
+    """cfg.ipm_try_unconstrained: instances whose inequality-free minimiser is feasible skip the interior point (iters = 0).
+    Both settings return the same solution; the skip set is the oracle's; it is a majority of the config-2 scenarios."""
+    s = random_scenarios(1024, N=20, seed=1234)
+    on = default_config(N=20); off = on.copy(); off.ipm_try_unconstrained = 0.0
+    assert on.ipm_try_unconstrained == 1.0
+    g_on, o_on = _solve_both(gpu_engine_factory(on), oracle, on, s)
+    g_off, o_off = _solve_both(gpu_engine_factory(off), oracle, off, s)
+    _assert_parity(g_on, o_on); _assert_parity(g_off, o_off)
+    np.testing.assert_array_equal(g_on[4] == 0, o_on[4] == 0)
+    assert (g_on[4] == 0).mean() > 0.4 and (g_off[4] >= 4).all()
+    assert np.abs(g_on[1] - g_off[1]).max() <= 1e-9 and np.abs(g_on[0] - g_off[0]).max() <= 1e-9
 
 
 def test_all_state_weights_nonzero(gpu_engine_factory, oracle):
