@@ -43,9 +43,10 @@ def algorithmic_bytes_per_solve(N):
     return 8 * (n_in + n_out) + 4
 
 
-def algorithmic_flops_per_solve(N, mean_ipm_iters):
-    """shooting N*4360 + N*1900 per interior-point iteration (measured mean iterations)."""
-    return N * 4360.0 + N * 1900.0 * mean_ipm_iters
+def algorithmic_flops_per_solve(N, mean_ipm_iters, trial):
+    """shooting N*4360 + N*1900 per interior-point iteration (measured mean iterations).  With the unconstrained
+    trial (cfg.ipm_try_unconstrained) every instance also pays one factorisation + one solve = 0.7 of an iteration's count."""
+    return N * 4360.0 + N * 1900.0 * (mean_ipm_iters + (0.7 if trial else 0.0))
 
 
 def measured_traffic(N, B):
@@ -165,7 +166,8 @@ def main():
     if rank == 0:
         total = world * B * K
         value = total / elapsed
-        flops = algorithmic_flops_per_solve(N, mean_iters) * B
+        trial = cfg.ipm_try_unconstrained != 0.0
+        flops = algorithmic_flops_per_solve(N, mean_iters, trial) * B
         byts = algorithmic_bytes_per_solve(N) * B
         traffic = None if (args.gp or args.dynamic) else measured_traffic(N, B)
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
@@ -182,10 +184,11 @@ def main():
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~70 %) + admpc_expand_kernel<20>" if N == 20 else "one step = admpc_linearize_kernel + admpc_qp_kernel (stage-wise Riccati)", "kernel_ms": kern_ms,
-                         "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*mean_ipm_iters per solve (SURVEY 8d)"},
+                         "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N)},
             "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
+            "unconstrained_trial": {"enabled": bool(trial), "fraction_solved_without_interior_point": float((it_host == 0).mean())},
         }
         if best is not None:
             out["argmin"] = {"cost": float(best[0].item()), "index": int(best[1].item())}

@@ -468,7 +468,13 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         }
         if (ok) {
             for (int k = 0; k < N; ++k) {
-                for (int j = 0; j < NU; ++j) { s->du[k][j] = w->ddu[k][j]; s->sl[k][j] = s->su[k][j] = 0; for (int i = 0; i < 4; ++i) s->lam[k][j][i] = 0; }
+                for (int j = 0; j < NU; ++j) {
+                    s->du[k][j] = w->ddu[k][j]; s->sl[k][j] = s->su[k][j] = 0;
+                    s->lam[k][j][0] = s->lam[k][j][1] = 0;                     /* box multipliers: inactive              */
+                    s->lam[k][j][2] = qp->rho_l; s->lam[k][j][3] = qp->rho_u;  /* sl, su >= 0 hold the L1 penalty weight */
+                    s->t[k][j][0] = s->du[k][j] - qp->dlu[k][j]; s->t[k][j][1] = qp->duu[k][j] - s->du[k][j];
+                    s->t[k][j][2] = s->t[k][j][3] = 0;
+                }
                 for (int i = 0; i < NX; ++i) { s->dx[k + 1][i] += w->ddx[k + 1][i]; s->pi[k][i] = w->dpi[k][i]; }
                 s->lamd[k][0] = s->lamd[k][1] = 0;
             }
