@@ -1006,13 +1006,14 @@ __device__ __forceinline__ void stage_dq(double* __restrict__ dq, const double* 
 __device__ __forceinline__ unsigned lds_byte_addr(const double* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const double*)p;
 }
-// L z = y in place (unit lower-triangular L, rows packed at Lp[i (i + 1) / 2 + j]); row_addr = &Lp[row start of this lane]
-__device__ __forceinline__ void fwd_subst_40(double& y, const unsigned row_addr) {
-    asm volatile(ADMPC_FWD_SUBST_ASM_40 : "+{v[100:101]}"(y) : "{v102}"(row_addr) : ADMPC_SUBST_CLOBBERS);
+// L z = y in place (unit lower-triangular L, rows packed at Lp[i (i + 1) / 2 + j], the diagonal slots hold 0.0);
+// row_addr = &Lp[row start of this lane], pub_addr = &buffer[lane % 16] of a 64-double LDS exchange buffer
+__device__ __forceinline__ void fwd_subst_40(double& y, const unsigned row_addr, const unsigned pub_addr) {
+    asm volatile(ADMPC_FWD_SUBST_ASM_40 : "+{v[100:101]}"(y) : "{v102}"(row_addr), "{v103}"(pub_addr) : ADMPC_SUBST_CLOBBERS);
 }
 // L' x = z in place; col_addr = &Lp[lane]
-__device__ __forceinline__ void bwd_subst_40(double& x, const unsigned col_addr) {
-    asm volatile(ADMPC_BWD_SUBST_ASM_40 : "+{v[100:101]}"(x) : "{v102}"(col_addr) : ADMPC_SUBST_CLOBBERS);
+__device__ __forceinline__ void bwd_subst_40(double& x, const unsigned col_addr, const unsigned pub_addr) {
+    asm volatile(ADMPC_BWD_SUBST_ASM_40 : "+{v[100:101]}"(x) : "{v102}"(col_addr), "{v103}"(pub_addr) : ADMPC_SUBST_CLOBBERS);
 }
 
 // Newton-matrix row of this lane (see rowbuild() in gen_subst_asm.py): 20 columns per statement (operand limit of inline assembly)
@@ -1406,15 +1407,20 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     auto ldl_solve = [&](double y, const int lz_) __attribute__((always_inline)) -> double {
         static_assert(n == 40, "the substitution assembly is generated for n = 40");
         const bool uz_ = lz_ < n;
-        fwd_subst_40(y, lds_byte_addr(Lp + (uz_ ? lz_ * (lz_ + 1) / 2 : 0)));           // idle lanes: a harmless in-bounds row
+        const unsigned pub = lds_byte_addr(cb + (lz_ & 15));                              // cb is free while a system is being solved
+        fwd_subst_40(y, lds_byte_addr(Lp + (uz_ ? lz_ * (lz_ + 1) / 2 : 0)), pub);      // idle lanes never take part (EXEC masks)
         double x = y * invd[uz_ ? lz_ : 0];
-        bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)));
+        bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)), pub);
         return x;
     };
 
     // Instances need 4 .. 15+ interior-point iterations each: a static instance -> wave map leaves most of the chip idle while
     // the unlucky waves finish.  The waves draw instances from the scheduler, predicted-expensive ones first.
     // (Instances that failed in an earlier SQP iteration were not queued by the condensing kernel.)
+    // diagonal slots of the packed factor: 0.0, never overwritten (the factorisation stores the strictly-lower part only).  The
+    // substitution assembly lets the source lane of a step take part with this multiplier.
+    if (uact) Lp[(lane * (lane + 1)) / 2 + lane] = 0.0;
+    WSYNC();
     PHASE_DECL();
     for (int inst = sched_next(sched, cap, true); inst >= 0; inst = sched_next(sched, cap, false)) {
         PHASE_STAMP(7);

@@ -9,8 +9,9 @@ addresses are one base register + immediate offsets, and the "lanes below / abov
 written by one SALU instruction (s_bfm_b64) -- no per-step VALU work besides the two v_readlane and the FMA.
 
 Register contract (fixed physical registers, see fwd_subst / bwd_subst in admpc_kernels.hip):
-  v[100:101] y (in/out)   v102 LDS byte address (per lane)   v[104 : 104+2D) prefetch ring   s[40:43] broadcast values
-  s[46:47] saved EXEC
+  v[100:101] y (in/out)   v102 LDS byte address of the lane's row (forward) / column (backward) of the packed factor
+  v103 LDS byte address of publish buffer + 8 (lane % 16)   v[104:120) in-block ring   v[120:136) cross-block ring
+  v[136:137] published block   s[46:47] saved EXEC
 """
 import sys
 
@@ -18,42 +19,94 @@ D = 8
 Y, ADDR, RING, SB, SAVE = 100, 102, 104, 40, 46
 
 
-def _subst(n, steps, offset_of, exec_of):
-    """Common schedule of both substitutions.  Ring slot s % D holds the factor entries of step s and is refilled (for step
-    s + D) one step later.  HAZARD (measured on MI355X, scripts/probes/subst_probe.hip: wrong and non-repeatable results
-    without it): the v_readlane_b32 pair of the next step reads the register the v_fma_f64 has just written; one wait state
-    is required between them and an LDS instruction does NOT count as one -- hence the s_nop 0 closing every step.  (The
-    assembler cannot check hazards inside inline assembly; hipcc's own recogniser never sees these instructions.)"""
+PUB, RING2, ZB = 103, 120, 136
+
+
+def _rows(n):
+    return [(16 * r, min(16 * r + 15, n - 1)) for r in range((n + 15) // 16)]
+
+
+def _subst_blocked(n, forward):
+    """Blocked triangular substitution without v_readlane (see the module docstring for the register contract).
+
+    The wave's 16-lane rows are the blocks.  Inside a block a step is ONE instruction: the multiplier y_j reaches the lanes of
+    its own row through DPP (v_fmac_f64_dpp y, y, -L row_newbcast:j%16), a plain VALU -> VALU dependency (measured with
+    scripts/probes/dppchain_probe.hip: no wait state needed) instead of the v_readlane -> SGPR -> v_fma round trip that cost a
+    lone wave ~54 cycles per step.  The DPP source lane must be enabled (no fetch-inactive on this DPP), so lane j takes part
+    with the multiplier 0.0 that the packed factor keeps in its (otherwise unused) diagonal slot.  After a block its 16 finished
+    values are published in LDS, read back into every row (ZB) and applied to the lanes of the remaining rows, again one DPP
+    FMAC per column.  Factor entries: ring of D ds_read_b64 for the in-block steps, a second ring for the cross-block updates,
+    EXEC masks (s_bfm_b64) as predicates, immediate offsets off one base register.
+      forward : L z = y   (unit lower L, lane i reads L[i][j] at row base + 8 j)
+      backward: L' x = z  (lane i reads L[j][i] at column base + 8 j (j + 1) / 2)"""
+    rows = _rows(n)
+    off = (lambda j: 8 * j) if forward else (lambda j: 8 * (j * (j + 1) // 2))
     out = ["s_mov_b64 s[%d:%d], exec" % (SAVE, SAVE + 1)]
-    issued = []                                   # step indices in issue order
-    def load(s):
+    order = rows if forward else rows[::-1]
+    # in-block steps, in execution order: (j, lo, hi) with lanes lo..hi enabled (targets + the source lane j)
+    inblk = []
+    for (r0, r1) in order:
+        js = range(r0, r1) if forward else range(r1, r0, -1)
+        for j in js:
+            inblk.append((j, j, r1) if forward else (j, r0, j))
+    issued = []
+    def load_in(s):
+        j, lo, hi = inblk[s]
         t = RING + 2 * (s % D)
-        out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, offset_of(steps[s])))
-        issued.append(s)
-    for s in range(min(D, len(steps))):
-        load(s)
-    for s, j in enumerate(steps):
-        sp = SB + 2 * (s & 1); t = RING + 2 * (s % D)
-        out.append("v_readlane_b32 s%d, v%d, %d" % (sp, Y, j))
-        out.append("v_readlane_b32 s%d, v%d, %d" % (sp + 1, Y + 1, j))
-        out.append(exec_of(j))
-        out.append("s_waitcnt lgkmcnt(%d)" % (len(issued) - 1 - issued.index(s)))
-        out.append("v_fma_f64 v[%d:%d], -s[%d:%d], v[%d:%d], v[%d:%d]" % (Y, Y + 1, sp, sp + 1, t, t + 1, Y, Y + 1))
-        if s >= 1 and s - 1 + D < len(steps):
-            load(s - 1 + D)                       # refill the slot of the previous step
-        out.append("s_nop 0")                     # hazard pad: v_fma_f64 result -> v_readlane of it (see _subst.__doc__)
+        out.append("s_bfm_b64 exec, %d, %d" % (hi - lo + 1, lo))
+        out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, off(j)))
+        issued.append(("in", s))
+    for s in range(min(D, len(inblk))):
+        load_in(s)
+    def wait_for(tag):
+        out.append("s_waitcnt lgkmcnt(%d)" % min(15, len(issued) - 1 - issued.index(tag)))      # the counter is 4 bits wide
+    s = 0
+    for bi, (r0, r1) in enumerate(order):
+        nsteps = (r1 - r0)
+        for _ in range(nsteps):
+            j, lo, hi = inblk[s]
+            t = RING + 2 * (s % D)
+            wait_for(("in", s))
+            out.append("s_bfm_b64 exec, %d, %d" % (hi - lo + 1, lo))
+            out.append("v_fmac_f64_dpp v[%d:%d], v[%d:%d], -v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf" % (Y, Y + 1, Y, Y + 1, t, t + 1, j % 16))
+            if s + D < len(inblk):
+                load_in(s + D)
+            s += 1
+        rest = order[bi + 1:]
+        if not rest:
+            break
+        # publish the block, read it back into every row, update the remaining rows
+        tlo, thi = min(r[0] for r in rest), max(r[0] for r in rest) + 15      # WHOLE rows: a DPP source lane must be enabled, also beyond n
+        cols = list(range(r0, r1 + 1)) if forward else list(range(r1, r0 - 1, -1))
+        out.append("s_bfm_b64 exec, %d, %d" % (r1 - r0 + 1, r0))
+        out.append("s_nop 0")
+        out.append("ds_write_b64 v%d, v[%d:%d] offset:%d" % (PUB, Y, Y + 1, 8 * r0))
+        out.append("s_bfm_b64 exec, %d, %d" % (thi - tlo + 1, tlo))
+        out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (ZB, ZB + 1, PUB, 8 * r0))
+        issued.append(("zb", bi))
+        def load_x(q):
+            t = RING2 + 2 * (q % D)
+            out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, off(cols[q])))
+            issued.append(("x", bi, q))
+        for q in range(min(D, len(cols))):
+            load_x(q)
+        for q, j in enumerate(cols):
+            t = RING2 + 2 * (q % D)
+            wait_for(("x", bi, q))       # in-order returns: the ZB read was issued earlier and is complete as well
+            out.append("v_fmac_f64_dpp v[%d:%d], v[%d:%d], -v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf" % (Y, Y + 1, ZB, ZB + 1, t, t + 1, j % 16))
+            if q + D < len(cols):
+                load_x(q + D)
+    out.append("s_waitcnt lgkmcnt(0)")
     out.append("s_mov_b64 exec, s[%d:%d]" % (SAVE, SAVE + 1))
     return out
 
 
 def fwd(n):
-    """L z = y, unit lower L: lane i reads L[i][j] at base_i + 8 j (base_i = &Lp[i(i+1)/2]); lanes j+1 .. n-1 take part in step j."""
-    return _subst(n, list(range(n - 1)), lambda j: 8 * j, lambda j: "s_bfm_b64 exec, %d, %d" % (n - 1 - j, j + 1))
+    return _subst_blocked(n, True)
 
 
 def bwd(n):
-    """L' x = z: lane i reads L[j][i] at base_i + 8 j(j+1)/2 (base_i = &Lp[i]); lanes 0 .. j-1 take part in step j = n-1 .. 1."""
-    return _subst(n, list(range(n - 1, 0, -1)), lambda j: 8 * (j * (j + 1) // 2), lambda j: "s_bfm_b64 exec, %d, 0" % j)
+    return _subst_blocked(n, False)
 
 
 def rowbuild(n, lo, hi):
@@ -122,7 +175,7 @@ def emit(name, lines):
 
 def main():
     n = 40
-    clob = ", ".join('"v%d"' % r for r in range(RING, RING + 2 * D)) + ", " + ", ".join('"s%d"' % r for r in (40, 41, 42, 43, 46, 47))
+    clob = ", ".join('"v%d"' % r for r in list(range(RING, RING + 2 * D)) + list(range(RING2, RING2 + 2 * D)) + [ZB, ZB + 1]) + ", " + ", ".join('"s%d"' % r for r in (46, 47))
     txt = "// GENERATED by gen_subst_asm.py (n = %d, prefetch depth %d) -- do not edit\n" % (n, D)
     txt += emit("ADMPC_FWD_SUBST_ASM_%d" % n, fwd(n)) + "\n" + emit("ADMPC_BWD_SUBST_ASM_%d" % n, bwd(n)) + "\n"
     txt += emit("ADMPC_ROWBUILD_ASM_%d_A" % n, rowbuild(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWBUILD_ASM_%d_B" % n, rowbuild(n, n // 2, n)) + "\n"

@@ -12,6 +12,9 @@ if True:
     from ad_mpc_amd.scenarios import random_scenarios
     cfg = default_config(N=20, Ts=0.05)
     sc = random_scenarios(4096, N=20, Ts=0.05, seed=1234, start=0, blend=(100.0, 110.0))
+    if len(sys.argv) > 1:          # e.g. "1920,4063,2920": only these instances (waves alone on their SIMDs)
+        idx = [int(v) for v in sys.argv[1].split(",")]
+        sc = {k: v[idx] for k, v in sc.items()}
     eng = BatchSolver(cfg, device=0)
     d = eng.to_device
     for _ in range(3):
