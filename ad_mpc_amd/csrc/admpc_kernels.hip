@@ -1362,6 +1362,18 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         double R[3], nl;
         auto chain = [&](auto jc, double (&Rn)[3], double& nln) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
+            // The (unscaled) column goes out first: its LDS round trip is the longest latency of the column and must not queue
+            // behind the reciprocal chain (the factor store below is a volatile asm with a memory clobber: nothing after it in
+            // program order may be issued before it).
+            if constexpr (j + 1 < n) {
+                if constexpr ((j + 1) / 16 == 2) Rn[2] = a[j];          // only lanes 32..39 are still involved: own row
+                else {
+                    double* const cbuf = (j & 1) ? sb : cb;
+                    cbuf[lane] = a[j];
+#pragma unroll
+                    for (int m = (j + 1) / 16; m < 3; ++m) Rn[m] = cbuf[16 * m + (lane & 15)];
+                }
+            }
             const double dj = rdlane(a[j], j);
             const double dinv = rcp_nr(dj);                             // 1 / D_jj
             const double lu = a[j] * dinv;                              // L_ij for the lanes below the diagonal
@@ -1370,13 +1382,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
                              : : "v"(lrow), "v"(lu), "n"(n - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
                 nln = -lu;
-                if constexpr ((j + 1) / 16 == 2) Rn[2] = a[j];          // only lanes 32..39 are still involved: own row
-                else {
-                    double* const cbuf = (j & 1) ? sb : cb;
-                    cbuf[lane] = a[j];
-#pragma unroll
-                    for (int m = (j + 1) / 16; m < 3; ++m) Rn[m] = cbuf[16 * m + (lane & 15)];
-                }
             }
         };
         chain(std::integral_constant<int, 0>{}, R, nl);
