@@ -1078,6 +1078,33 @@ template <int BC>
 __device__ __forceinline__ void fmac_rowbc_then_readlane(double& acc, const double L, const double s) {
     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
 }
+// Head of a factorisation column, one assembly statement so that hipcc cannot sink its LDS reads down to their first use:
+//   wait for the previous column's block reads (R) -> first update acc += R[J1/16][J1%16] * nl (makes column J1 final) -> pad for
+//   the v_readlane of the pivot that follows -> publish the finished column J1 in LDS -> start reading it back as "block m in
+//   every 16-lane row" (Rn[m], m = MLO..2) WITHOUT waiting: the reads land under the reciprocal chain and the remaining updates
+//   of the previous column.  The wait is lgkmcnt(2): the two LDS stores of the previous pivot chain (1/D and the factor column)
+//   are younger than the reads and need not have retired.  R and nl are in/out operands only to order their later users
+//   behind the wait.  PUBLISH = false (columns whose remaining rows all sit in the last 16-lane block): no LDS traffic.
+template <int J1, int MLO, bool PUBLISH, bool PAD>
+__device__ __forceinline__ void col_head(double& acc, double (&R)[3], double& nl, double (&Rn)[3], const unsigned wr_addr, const unsigned rd_addr) {
+    constexpr int BO = (J1 & 1) * 1024;            // alternate exchange buffers cb / sb (sb = cb + 128 doubles)
+    if constexpr (!PUBLISH) {
+        if constexpr (PAD) asm volatile("s_waitcnt lgkmcnt(2)\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+                                        : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3]) : "n"(J1 % 16));
+        else asm volatile("s_waitcnt lgkmcnt(2)\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+                          : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3]) : "n"(J1 % 16));
+    } else if constexpr (MLO == 0) {
+        asm volatile("s_waitcnt lgkmcnt(2)\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                     "ds_write_b64 %8, %0 offset:%11\n\tds_read_b64 %3, %9 offset:%11\n\tds_read_b64 %4, %9 offset:%12\n\tds_read_b64 %5, %9 offset:%13"
+                     : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "=&v"(Rn[0]), "=&v"(Rn[1]), "=&v"(Rn[2]), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3])
+                     : "v"(wr_addr), "v"(rd_addr), "n"(J1 % 16), "n"(BO), "n"(BO + 128), "n"(BO + 256) : "memory");
+    } else if constexpr (MLO == 1) {
+        asm volatile("s_waitcnt lgkmcnt(2)\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                     "ds_write_b64 %7, %0 offset:%10\n\tds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12"
+                     : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "=&v"(Rn[1]), "=&v"(Rn[2]), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3])
+                     : "v"(wr_addr), "v"(rd_addr), "n"(J1 % 16), "n"(BO), "n"(BO + 128), "n"(BO + 256) : "memory");
+    }
+}
 // Copies of 16-lane row r of v in all four rows, r = 0..2 (row 3 is idle in the 40-row factorisation): gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
 //   swap16(X, X) -> (R0,R0,R2,R2), (R1,R1,R3,R3);  swap32(E, E) -> (R0 x4), (R2 x4);  swap32(O, O) -> (R1 x4), (R3 x4)
@@ -1359,21 +1386,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         // Entries on and above the diagonal of a row are never read (lane jj's w_jj is only picked up for jj > j), so the
         // column is used unmasked; only the store of L is masked (EXEC).
         const unsigned lrow = lds_byte_addr(Lp + (uz_ ? trz_ : 0));
-        double R[3], nl;
-        auto chain = [&](auto jc, double (&Rn)[3], double& nln) __attribute__((always_inline)) {
+        const unsigned pub_wr = lds_byte_addr(cb + lane), pub_rd = lds_byte_addr(cb + (lane & 15));
+        // pivot chain of column j: reciprocal of the pivot, scaled column (the factor's entries), its masked store
+        auto chain = [&](auto jc, double& nln) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            // The (unscaled) column goes out first: its LDS round trip is the longest latency of the column and must not queue
-            // behind the reciprocal chain (the factor store below is a volatile asm with a memory clobber: nothing after it in
-            // program order may be issued before it).
-            if constexpr (j + 1 < n) {
-                if constexpr ((j + 1) / 16 == 2) Rn[2] = a[j];          // only lanes 32..39 are still involved: own row
-                else {
-                    double* const cbuf = (j & 1) ? sb : cb;
-                    cbuf[lane] = a[j];
-#pragma unroll
-                    for (int m = (j + 1) / 16; m < 3; ++m) Rn[m] = cbuf[16 * m + (lane & 15)];
-                }
-            }
             const double dj = rdlane(a[j], j);
             const double dinv = rcp_nr(dj);                             // 1 / D_jj
             const double lu = a[j] * dinv;                              // L_ij for the lanes below the diagonal
@@ -1384,13 +1400,24 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 nln = -lu;
             }
         };
-        chain(std::integral_constant<int, 0>{}, R, nl);
+        // column 0: published by plain code (nothing to overlap with yet).  The block registers ping-pong between two sets so that
+        // no copy ever reads a register whose LDS load is still in flight.
+        double Rb[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, nlb[2] = {0.0, 0.0};
+        cb[lane] = a[0];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) Rb[0][m] = cb[16 * m + (lane & 15)];
+        chain(std::integral_constant<int, 0>{}, nlb[0]);
         static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            constexpr bool own = (j + 1) / 16 == 2;                     // DPP source written by the VALU (hazard pad) or loaded from LDS
-            double Rn[3], nln;
-            fmac_rowbc_then_readlane<(j + 1) % 16>(a[j + 1], R[(j + 1) / 16], nl);
-            chain(std::integral_constant<int, j + 1>{}, Rn, nln);
+            constexpr bool own = (j + 1) / 16 == 2;                     // column j: DPP sources are the lanes' own registers (VALU-written)
+            constexpr bool pub = j + 2 < n && (j + 2) / 16 < 2;         // column j + 1 still needs its blocks in other rows
+            double (&R)[3] = Rb[j & 1];
+            double (&Rn)[3] = Rb[(j + 1) & 1];
+            double& nl = nlb[j & 1];
+            double& nln = nlb[(j + 1) & 1];
+            col_head<j + 1, (j + 2) / 16, pub, own>(a[j + 1], R, nl, Rn, pub_wr, pub_rd);
+            if constexpr (!pub) Rn[2] = a[j + 1];                       // only lanes 32..39 are still involved: own row
+            chain(std::integral_constant<int, j + 1>{}, nln);
             constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;        // first 4-aligned column >= j + 2
             static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
                 constexpr int jj = decltype(c)::value;
@@ -1402,9 +1429,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
                 else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
             });
-#pragma unroll
-            for (int m = 0; m < 3; ++m) R[m] = Rn[m];
-            nl = nln;
         });
         WSYNC();
     };

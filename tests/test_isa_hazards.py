@@ -20,3 +20,5 @@ def test_no_readlane_or_dpp_hazard_in_compiled_kernels(tmp_path):
     import check_dpp_hazard
     counts = check_dpp_hazard.count_hazards(out)
     assert counts[2] == 0, "VALU write -> v_readlane without a wait state: %r" % (counts,)
+    import check_inflight
+    assert check_inflight.count(out) == 0, "a register is read while its un-waited ds_read (column-head assembly) is still in flight"
