@@ -57,7 +57,11 @@ def measured_traffic(N, B):
         return None
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json"))):
+    import re
+    def order(f):            # profiles/rN/vM_...: newest round, then newest build
+        m = re.search(r"r(\d+)[/\\]v(\d+)_", f)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json")), key=order):
         try:
             t = json.load(open(f)).get("_step_traffic")
         except Exception:
