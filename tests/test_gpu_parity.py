@@ -26,13 +26,19 @@ def _solve_both(eng, oracle, cfg, s):
 
 
 def _assert_parity(g, o, tol=TOL):
+    """Same algorithm on both sides: instances that take the same number of interior-point iterations must agree to `tol`
+    (measured: 1e-11); an instance whose stopping test is borderline may take one iteration more or less on one side, and then
+    the two answers differ by the size of that last step, which the stopping rule bounds by cfg.ipm_tol_step = 1e-6."""
     x, u, cost, st, it = g; xo, uo, co, so, io = o
     np.testing.assert_array_equal(st, so)
-    ok = so == 0
+    assert np.abs(it - io).max(initial=0) <= 1          # at most one borderline extra iteration
+    ok = (so == 0) & (it == io)
     assert np.abs(u[ok] - uo[ok]).max(initial=0.0) <= tol, np.abs(u[ok] - uo[ok]).max()
     assert np.abs(x[ok] - xo[ok]).max(initial=0.0) <= tol, np.abs(x[ok] - xo[ok]).max()
     np.testing.assert_allclose(cost[ok], co[ok], rtol=1e-9, atol=1e-9)
-    assert np.abs(it - io).max(initial=0) <= 1          # same algorithm: at most one borderline extra iteration
+    flip = (so == 0) & (it != io)
+    assert flip.mean() <= 0.01
+    assert np.abs(u[flip] - uo[flip]).max(initial=0.0) <= 1e-6 and np.abs(x[flip] - xo[flip]).max(initial=0.0) <= 1e-6
 
 
 def test_shooting_against_reference_golden_vectors(gpu_engine_factory, golden_shooting):
