@@ -50,10 +50,18 @@ def _subst_blocked(n, forward):
         for j in js:
             inblk.append((j, j, r1) if forward else (j, r0, j))
     issued = []
+    cur_exec = [None]
+    def set_exec(lo, hi):
+        if cur_exec[0] != (lo, hi):
+            out.append("s_bfm_b64 exec, %d, %d" % (hi - lo + 1, lo)); cur_exec[0] = (lo, hi)
+    def covers(lo, hi):
+        return cur_exec[0] is not None and cur_exec[0][0] <= lo and hi <= cur_exec[0][1]
     def load_in(s):
+        # a load needs its lanes enabled, extra enabled lanes only fetch values nobody uses: keep the current mask when it covers
         j, lo, hi = inblk[s]
         t = RING + 2 * (s % D)
-        out.append("s_bfm_b64 exec, %d, %d" % (hi - lo + 1, lo))
+        if not covers(lo, hi):
+            set_exec(lo, hi)
         out.append("ds_read_b64 v[%d:%d], v%d offset:%d" % (t, t + 1, ADDR, off(j)))
         issued.append(("in", s))
     for s in range(min(D, len(inblk))):
@@ -61,13 +69,19 @@ def _subst_blocked(n, forward):
     def wait_for(tag):
         out.append("s_waitcnt lgkmcnt(%d)" % min(15, len(issued) - 1 - issued.index(tag)))      # the counter is 4 bits wide
     s = 0
+    WAIT_EVERY = 4
     for bi, (r0, r1) in enumerate(order):
         nsteps = (r1 - r0)
+        waited_through = s - 1
         for _ in range(nsteps):
             j, lo, hi = inblk[s]
             t = RING + 2 * (s % D)
-            wait_for(("in", s))
-            out.append("s_bfm_b64 exec, %d, %d" % (hi - lo + 1, lo))
+            if s > waited_through:                               # one wait covers the next WAIT_EVERY steps (their loads are older than D steps)
+                upto = s
+                while upto + 1 < len(inblk) and upto + 1 < s + WAIT_EVERY and ("in", upto + 1) in issued:
+                    upto += 1
+                wait_for(("in", upto)); waited_through = upto
+            set_exec(lo, hi)
             out.append("v_fmac_f64_dpp v[%d:%d], v[%d:%d], -v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf" % (Y, Y + 1, Y, Y + 1, t, t + 1, j % 16))
             if s + D < len(inblk):
                 load_in(s + D)
