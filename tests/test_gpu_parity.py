@@ -238,6 +238,18 @@ def test_odd_batch_sizes_and_mixed_failures_over_sqp_iterations(gpu_engine_facto
     assert np.abs(g[1][ok] - o[1][ok]).max() <= 1e-7 and np.abs(g[0][ok] - o[0][ok]).max() <= 1e-7
 
 
+def test_one_engine_growing_and_shrinking_batches(gpu_engine_factory, oracle):
+    """The workspace (linearisation, Hessians, scheduler lists) is sized by the largest batch seen; a solver handle must give
+    the same answers when batches grow and shrink between calls."""
+    cfg = default_config(N=20)
+    eng = gpu_engine_factory(cfg)
+    for B in (40, 3000, 7, 4500, 300):
+        s = random_scenarios(B, N=20, seed=500 + B, blend=(3.0, 5.0))
+        g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        _assert_parity(g, o)
+
+
 def test_solve_is_capturable_in_a_hip_graph(gpu_engine_factory):
     """admpc_solve_batch is launches only (no allocation, no copy, no synchronisation after admpc_reserve): it can be
     captured into a hipGraph on the caller's stream and replayed; the replay reproduces the eager result bit for bit."""
