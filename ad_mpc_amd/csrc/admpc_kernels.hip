@@ -68,16 +68,36 @@ __device__ __forceinline__ void sincos_small(const double x, double* sn, double*
     *cs = ((q + 1) & 2) ? -cq : cq;
 }
 
+// exp(x) for x <= 0 (the squared-exponential kernel): x = k ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (remainder
+// < 4e-18), v_ldexp_f64.  ~20 instructions; underflows to 0 like libm.
+__device__ __forceinline__ double exp_nonpos(const double x) {
+    const double k = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                                      // 1 / 13!
+    p = fma(p, r, 2.08767569878681e-09);  p = fma(p, r, 2.505210838544172e-08); p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06); p = fma(p, r, 2.48015873015873e-05);  p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.3888888888888889e-03); p = fma(p, r, 8.333333333333333e-03); p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01); p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    return ldexp(p, (int)fmax(k, -1100.0));
+}
+
+// Mean and derivative of one 1-D squared-exponential GP.  The three threads of a stage (adjacent lanes 3m, 3m+1, 3m+2: the
+// kernel maps 63 tasks to a wave) integrate the same state, so they evaluate the same GP: each takes every third training
+// point and the partial sums are combined by lane shuffles, in the same order on all three lanes (identical results).
 __device__ __forceinline__ void gp_eval(const AdmpcGp& g, double z, double& mu, double& dmu) {
     double m = 0.0, d = 0.0;
     const int n = g.n_points;
-    for (int i = 0; i < n; ++i) {
-        double dz = z - g.Z[i];
-        double k = g.sigma_f * exp(-0.5 * dz * dz * g.inv_l2);
+    const int lane = threadIdx.x & 63, sub = lane % 3, base = lane - sub;
+    for (int i = sub; i < n; i += 3) {
+        const double dz = z - g.Z[i];
+        const double k = g.sigma_f * exp_nonpos(-0.5 * dz * dz * g.inv_l2);
         m += k * g.alpha[i];
         d -= k * dz * g.inv_l2 * g.alpha[i];
     }
-    mu = m + g.ymean; dmu = d;
+    const double m0 = __shfl(m, base), m1 = __shfl(m, base + 1), m2 = __shfl(m, base + 2);
+    const double d0 = __shfl(d, base), d1 = __shfl(d, base + 1), d2 = __shfl(d, base + 2);
+    mu = (m0 + m1) + m2 + g.ymean; dmu = (d0 + d1) + d2;
 }
 
 __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, const double* x, const double* u, double p, ModelEval& e)
@@ -228,6 +248,7 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
 #define PKS 28           // packed symmetric 7x7
 #define KLS 17           // K0[7] K1[7] i00 i01 i11
 #define LIN_BLOCK 64     // threads per block of the linearisation kernel: single waves balance best over the CUs (256 registers each)
+#define LIN_TASKS 63     // tasks per block (multiple of 3)
 // work scheduler of the condensed path (int array): [0] ticket counter, [64 + q] number of instances in effort bucket q,
 // [SCHED_HDR + q * cap + j] j-th instance of bucket q.  Zeroed by the linearisation kernel, filled by the condensing kernel,
 // drained (highest bucket first) by the persistent interior-point waves.
@@ -242,7 +263,9 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
     const int N = cfg->N;
     const long total = (long)B * N * 3;
     if (sched && blockIdx.x == 0) for (int i = threadIdx.x; i < SCHED_HDR; i += blockDim.x) sched[i] = 0;     // ticket counter + bucket counts of this step
-    for (long tsk = (long)blockIdx.x * blockDim.x + threadIdx.x; tsk < total; tsk += (long)gridDim.x * blockDim.x) {
+    // 63 tasks per 64-lane block: the three threads of a stage sit in adjacent lanes of one wave (gp_eval shares work among them)
+    if (threadIdx.x >= LIN_TASKS) return;
+    for (long tsk = (long)blockIdx.x * LIN_TASKS + threadIdx.x; tsk < total; tsk += (long)gridDim.x * LIN_TASKS) {
         const long sk = tsk / 3; const int g = (int)(tsk % 3);
         const long inst = sk / N; const int k = (int)(sk % N);
         if (skip && skip[inst] != 0) continue;
@@ -1928,7 +1951,8 @@ __global__ __launch_bounds__(WAVE) void admpc_shoot_kernel(const AdmpcConfig* __
 {
     const int N = cfg->N;
     const long total = (long)B * N * 3;
-    for (long tsk = (long)blockIdx.x * WAVE + threadIdx.x; tsk < total; tsk += (long)gridDim.x * WAVE) {
+    if (threadIdx.x >= LIN_TASKS) return;                // same task -> lane map as the linearisation kernel (gp_eval relies on it)
+    for (long tsk = (long)blockIdx.x * LIN_TASKS + threadIdx.x; tsk < total; tsk += (long)gridDim.x * LIN_TASKS) {
         const long sk = tsk / 3; const int g = (int)(tsk % 3);
         const long inst = sk / N; const int k = (int)(sk % N);
         double x[NX], u[NU], phi[NX], col[3][NX];
@@ -2188,7 +2212,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     int gridB = s->num_cu * s->blocks_per_cu;
     if (gridB > B) gridB = B;
     const long totalA = (long)B * N * 3;
-    int gridA = (int)((totalA + LIN_BLOCK - 1) / LIN_BLOCK);
+    int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
     if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     for (int sq = 0; sq < nsqp; ++sq) {
@@ -2240,7 +2264,7 @@ int admpc_shoot_batch(AdmpcSolver* s, int B, const double* xbar, const double* u
     if (!xbar || !ubar || !p || !phi || !A || !Bm) return fail(ADMPC_EINVAL, "null array argument");
     HIPCHK(hipSetDevice(s->device));
     long total = (long)B * s->cfg.N * 3;
-    int grid = (int)((total + WAVE - 1) / WAVE); if (grid > s->num_cu * 32) grid = s->num_cu * 32;
+    int grid = (int)((total + LIN_TASKS - 1) / LIN_TASKS); if (grid > s->num_cu * 32) grid = s->num_cu * 32;
     hipLaunchKernelGGL(admpc_shoot_kernel, dim3(grid), dim3(WAVE), 0, (hipStream_t)stream, s->d_cfg, B, xbar, ubar, p, phi, A, Bm);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
