@@ -120,7 +120,7 @@ def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TER
     c.mass, c.L_F, c.L_R, c.Iz, c.Cf, c.Cr = VEH_MASS, VEH_L_F, VEH_L_R, VEH_IZ, VEH_CF, VEH_CR
     c.ipm_mu0, c.ipm_thr0 = IPM_MU0, IPM_THR0
     c.ipm_tol_comp, c.ipm_tol_res, c.ipm_tol_step = IPM_TOL_COMP, IPM_TOL_RES, IPM_TOL_STEP
-    c.ipm_try_unconstrained = 1.0 if int(N) == 20 else 0.0      # implemented by the condensed N = 20 device path (and the oracle)
+    c.ipm_try_unconstrained = 1.0
     return c
 
 

@@ -593,6 +593,7 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
     const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
     const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
     const int itmax = cfg->ipm_iter_max;
+    const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
     const int nu_sets = 2 * N;
     Roles R;
@@ -668,6 +669,48 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
         bool failed = false;
         double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
         int it = 0;
+        // ---- trial: the QP without its inequalities (cfg.ipm_try_unconstrained).  One Riccati factorisation with the plain
+        //      weights and one solve from the start point (du = 0, rolled-out dx, pi = 0) give its exact minimiser; if that
+        //      respects the input box and the steering box it is the solution of the full QP and the interior point is skipped
+        //      (iters = 0).  Same rule as the oracle and the condensed N = 20 path.
+        bool solved = false;
+        if (try_unc) {
+#pragma unroll
+            for (int m = 0; m < UPL; ++m) {
+                const int sid = lane + WAVE * m;
+                if (sid < nu_sets) { L.Rt[sid] = (sid & 1) ? Rd[1] : Rd[0]; L.guk[sid] = U[m].r; }
+            }
+            DSET_LOOP {
+                DSET_BIND
+                (void)D;
+                if (dact) L.Qt[dk] = Qd[6];
+            }
+#pragma unroll
+            for (int m = 0; m < TPL; ++m) if (T[m].k) L.gx[(T[m].k - 1) * 7 + T[m].i] = T[m].w * T[m].dx + T[m].q0;
+            WSYNC();
+            riccati_factor_fused(L, N, lane, R);
+            riccati_forward2<false>(L, N, lane, Ts, 0.0);
+            WSYNC();
+            bool ok = true;
+#pragma unroll
+            for (int m = 0; m < UPL; ++m) {
+                const int sid = lane + WAVE * m;
+                if (sid < nu_sets) { const double u = L.guk[sid]; ok = ok && (u >= U[m].dl && u <= U[m].duu); }
+            }
+            DSET_LOOP {
+                DSET_BIND
+                if (dact) { const double v = D.dx6 + L.ddx[(dk - 1) * 7 + 6]; ok = ok && (v >= D.dl && v <= D.du); }
+            }
+            if (__all(ok)) {
+                solved = true;
+#pragma unroll
+                for (int m = 0; m < UPL; ++m) { const int sid = lane + WAVE * m; if (sid < nu_sets) U[m].du = L.guk[sid]; }
+#pragma unroll
+                for (int m = 0; m < TPL; ++m) if (T[m].k) T[m].dx += L.ddx[(T[m].k - 1) * 7 + T[m].i];
+            }
+            WSYNC();
+        }
+        if (!solved)
         for (; it < itmax; ++it) {
             // ---- reciprocals, complementarity, residuals of the input sets
             double musum = 0.0, cmax = 0.0, rmax = 0.0;
@@ -2084,7 +2127,7 @@ int admpc_default_config(AdmpcConfig* c, int N, double Ts)
     c->Iz = c->L_F * c->L_R * (r_mass + f_mass);
     c->Cf = f_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195; c->Cr = r_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195;
     c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9; c->ipm_tol_step = 1e-6;
-    c->ipm_try_unconstrained = N == 20 ? 1.0 : 0.0;
+    c->ipm_try_unconstrained = 1.0;
     return ADMPC_OK;
 }
 

@@ -97,8 +97,7 @@ typedef struct AdmpcConfig {
     double  ipm_tol_step;      /* ... and the last applied input step max|alpha*ddu| <= tol_step      */
     double  ipm_try_unconstrained; /* != 0: first solve the QP without its inequalities (one factorisation + one solve);
                                     * if that minimiser respects every bound it IS the QP solution (iters = 0) and the
-                                    * interior point is skipped.  Implemented by the condensed N = 20 path and by the
-                                    * oracle; admpc_default_config sets it for N = 20 only. */
+                                    * interior point is skipped.  Default 1 (all device paths and the oracle). */
     AdmpcGp gp[ADMPC_GP_MAX];
 } AdmpcConfig;
 

@@ -81,14 +81,17 @@ def test_both_qp_kernels_agree_at_n20(gpu_engine_factory, oracle, monkeypatch):
     s = random_scenarios(512, N=20, seed=77, blend=(3.0, 5.0))
     o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
     g_dense = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-    # the Riccati kernel has no unconstrained trial (cfg.ipm_try_unconstrained is a condensed-path / oracle feature)
+    monkeypatch.setenv("ADMPC_QP", "riccati")
+    g_ric = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    # and once more with the unconstrained trial switched off on both sides
     cfg_r = cfg.copy(); cfg_r.ipm_try_unconstrained = 0.0
     o_r = oracle.solve_batch(cfg_r, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-    monkeypatch.setenv("ADMPC_QP", "riccati")
-    g_ric = gpu_engine_factory(cfg_r).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    g_ric0 = gpu_engine_factory(cfg_r).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
     monkeypatch.delenv("ADMPC_QP")
     _assert_parity(g_dense, o)
-    _assert_parity(g_ric, o_r)
+    _assert_parity(g_ric, o)
+    _assert_parity(g_ric0, o_r)
+    assert (g_ric[4] == 0).mean() > 0.3 and (g_ric0[4] >= 4).all()
     assert np.abs(g_dense[1] - g_ric[1]).max() <= TOL
 
 
