@@ -2017,6 +2017,32 @@ __global__ __launch_bounds__(WAVE) void admpc_shoot_kernel(const AdmpcConfig* __
     }
 }
 
+// receding-horizon shift of the iterate: stage k takes the values of stage k+1, the last input is kept and the new
+// terminal state is either a copy (rollout = 0) or one model step from the old terminal state under the last input.
+// Three lanes per instance as in the linearisation kernel (gp_eval shares its sums among them); lane 0 moves x, lane 1 moves u.
+__global__ __launch_bounds__(WAVE) void admpc_shift_kernel(const AdmpcConfig* __restrict__ cfg, int B, double* __restrict__ xbarg,
+                                                           double* __restrict__ ubarg, const double* __restrict__ pg, int rollout)
+{
+    const int N = cfg->N;
+    const long total = (long)B * 3;
+    if (threadIdx.x >= LIN_TASKS) return;
+    for (long tsk = (long)blockIdx.x * LIN_TASKS + threadIdx.x; tsk < total; tsk += (long)gridDim.x * LIN_TASKS) {
+        const long inst = tsk / 3; const int g = (int)(tsk % 3);
+        double* xb = xbarg + inst * (N + 1) * NX;
+        double* ub = ubarg + inst * N * NU;
+        double x[NX], u[NU], phi[NX], col[3][NX];
+        for (int i = 0; i < NX; ++i) { x[i] = xb[N * NX + i]; phi[i] = x[i]; }
+        u[0] = ub[(N - 1) * NU]; u[1] = ub[(N - 1) * NU + 1];
+        if (rollout) rk4_group(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
+        if (g == 0) {
+            for (int i = 0; i < N * NX; ++i) xb[i] = xb[i + NX];
+            for (int i = 0; i < NX; ++i) xb[N * NX + i] = phi[i];
+        } else if (g == 1) {
+            for (int i = 0; i < (N - 1) * NU; ++i) ub[i] = ub[i + NU];
+        }
+    }
+}
+
 // arg-min over cost[0..B): one block; ties -> lowest index; NaN treated as +inf
 __global__ __launch_bounds__(256) void admpc_argmin_kernel(const double* __restrict__ cost, int B, int64_t offset,
                                                            double* __restrict__ val, int64_t* __restrict__ idx)
@@ -2318,6 +2344,20 @@ int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset
     if (!s || !cost || !val || !idx || B <= 0) return fail(ADMPC_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(s->device));
     hipLaunchKernelGGL(admpc_argmin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cost, B, index_offset, val, idx);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_shift_batch(AdmpcSolver* s, int B, double* xbar, double* ubar, const double* p, int rollout, void* stream)
+{
+    if (!s || B < 0) return fail(ADMPC_EINVAL, "bad argument");
+    if (B == 0) return ADMPC_OK;
+    if (!xbar || !ubar || (rollout && !p)) return fail(ADMPC_EINVAL, "null array argument");
+    HIPCHK(hipSetDevice(s->device));
+    const long total = (long)B * 3;
+    long grid = (total + LIN_TASKS - 1) / LIN_TASKS;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(admpc_shift_kernel, dim3((unsigned)grid), dim3(WAVE), 0, (hipStream_t)stream, s->d_cfg, B, xbar, ubar, p, rollout ? 1 : 0);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

@@ -100,6 +100,19 @@ class BatchSolver:
         _lib.check(self.lib.admpc_shoot_batch(self._h, B, _ptr(xbar), _ptr(ubar), _ptr(p), _ptr(phi), _ptr(A), _ptr(Bm), self._stream()))
         return phi, A, Bm
 
+    def shift(self, xbar, ubar, p=None, rollout=True):
+        """Receding-horizon shift of the iterate, in place (the reference itself never shifts).
+        rollout: new terminal state by one model step under the last input (needs p), else a copy."""
+        N = self.N
+        B = xbar.shape[0]
+        self._chk(xbar, (B, N + 1, NX)); self._chk(ubar, (B, N, NU))
+        if rollout:
+            if p is None:
+                raise ValueError("shift(rollout=True) needs the blend parameter p")
+            self._chk(p, (B,))
+        _lib.check(self.lib.admpc_shift_batch(self._h, B, _ptr(xbar), _ptr(ubar), _ptr(p if rollout else None), 1 if rollout else 0,
+                                              self._stream()))
+
     def argmin(self, cost, index_offset=0):
         """Local arg-min over a device cost vector -> (val tensor[1], idx tensor[1] int64), ties -> lowest index."""
         B = cost.shape[0]

@@ -4,7 +4,8 @@ The reference stores an ``acados_template.AcadosOcpSolver`` at ad_3d_optimizer.p
 with ``set(stage, field, value)`` (:330-331,:430,:438,:441-442,:450), ``solve()`` (:456) and
 ``get(stage, field)`` (:462-465).  This class offers exactly those calls for ONE instance and runs
 the solve on the GPU through admpc_solve_batch (B = 1).  Like the acados object it owns a persistent
-iterate (initially all zeros, acados_solver_sim_car.c:705-731) that is never shifted or reset.
+iterate (initially all zeros, acados_solver_sim_car.c:705-731) that is never shifted or reset --
+unless the caller sets ``shift_iterate`` (off by default: an option the reference does not have).
 """
 import json
 import os
@@ -30,6 +31,7 @@ class AdmpcOcpSolver:
         self._status = 0
         self._qp_iter = 0
         self._cost = float("nan")
+        self.shift_iterate = None                # None: keep the iterate as the reference does; "copy" / "rollout": shift before each solve
 
     # ---- acados-style setters / getters -------------------------------------------------------
     def set(self, stage_, field_, value_):
@@ -93,6 +95,13 @@ class AdmpcOcpSolver:
             raise Exception("AdmpcOcpSolver.solve(): stage-0 lbx and ubx must both equal the measured state")
         if not np.all(self._p == self._p[0]):
             raise Exception("AdmpcOcpSolver.solve(): the blend parameter p must be the same on all stages")
+        if self.shift_iterate not in (None, "copy", "rollout"):
+            raise Exception("AdmpcOcpSolver.solve(): shift_iterate must be None, \"copy\" or \"rollout\"")
+        if self.shift_iterate is not None:
+            d = self._eng.to_device
+            tx, tu, tp = d(self._x[None]).clone(), d(self._u[None]).clone(), d(np.array([self._p[0]]))
+            self._eng.shift(tx, tu, tp, rollout=self.shift_iterate == "rollout")
+            self._x, self._u = tx[0].cpu().numpy(), tu[0].cpu().numpy()
         x, u, cost, st, it = self._eng.solve_numpy(self._lbx0[None], self._yref[None], self._yref_e[None],
                                                    np.array([self._p[0]]), self._x[None], self._u[None])
         if st[0] == 0:          # acados leaves the iterate untouched only if the QP failed outright

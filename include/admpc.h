@@ -148,6 +148,14 @@ int admpc_shoot_batch(AdmpcSolver* s, int B,
 int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset,
                  double* val, int64_t* idx, void* stream);
 
+/* Receding-horizon shift of the iterate between two solves.  The reference never shifts its iterate
+ * (the acados capsule keeps it as it is, acados_solver_sim_car.c:705-731; reset_mpc_optimizer is a stub,
+ * gp_ad_mpc_node.py:154-158), so this is an option the caller turns on, never part of admpc_solve_batch.
+ *   xbar [B][N+1][7], ubar [B][N][2] in place: stage k <- stage k+1; the last input is kept;
+ *   new terminal state = old terminal state (rollout = 0) or one RK4 step of the model (p [B]: blend
+ *   parameter, GP residual included when configured) from it under the last input (rollout = 1). */
+int admpc_shift_batch(AdmpcSolver* s, int B, double* xbar, double* ubar, const double* p, int rollout, void* stream);
+
 /* Post-solve epilogue: validity test of ad_3d_optimizer.py:385-394 and the
  * Ackermann mapping of create_ros_ad_mpc.py:95-98 for every instance.
  *   xopt [B][N+1][7], uopt [B][N][2], xref_xy [B][N+1][2]

@@ -648,6 +648,31 @@ void oracle_rk4_sens(const AdmpcConfig* c, const double* x, const double* u, dou
     for (int i = 0; i < NX; ++i) { phi[i] = (double)ph[i]; for (int j = 0; j < NX; ++j) A[i * NX + j] = (double)a[i][j]; for (int j = 0; j < NU; ++j) B[i * NU + j] = (double)b[i][j]; }
 }
 
+/* Receding-horizon shift of the iterate (same argument meaning as admpc_shift_batch, host pointers).  Not a reference
+ * function: the reference keeps its iterate as it is (acados_solver_sim_car.c:705-731); SURVEY 8f-3 lists it as an option. */
+int oracle_shift_batch(const AdmpcConfig* c, int B, double* xbar, double* ubar, const double* p, int rollout)
+{
+    if (!c || c->N < 2 || c->N > MAXN || B < 0) return ADMPC_EINVAL;
+    const int N = c->N;
+    for (int b = 0; b < B; ++b) {
+        double* xb = xbar + (size_t)b * (N + 1) * NX;
+        double* ub = ubar + (size_t)b * N * NU;
+        double xn[NX];
+        for (int i = 0; i < NX; ++i) xn[i] = xb[N * NX + i];
+        if (rollout) {
+            real xr[NX], ur[NU], ph[NX], a[NX][NX], bm[NX][NU];
+            for (int i = 0; i < NX; ++i) xr[i] = xb[N * NX + i];
+            for (int j = 0; j < NU; ++j) ur[j] = ub[(N - 1) * NU + j];
+            rk4_sens(c, xr, ur, (real)p[b], (real)c->Ts, ph, a, bm);
+            for (int i = 0; i < NX; ++i) xn[i] = (double)ph[i];
+        }
+        for (int i = 0; i < N * NX; ++i) xb[i] = xb[i + NX];
+        for (int i = 0; i < NX; ++i) xb[N * NX + i] = xn[i];
+        for (int i = 0; i < (N - 1) * NU; ++i) ub[i] = ub[i + NU];
+    }
+    return ADMPC_OK;
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -30,6 +30,9 @@ int oracle_solve_batch(const AdmpcConfig* c, int B,
                        double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters,
                        int nthreads);
 
+/* Receding-horizon shift of the iterate, as admpc_shift_batch (an option of this build; host pointers). */
+int oracle_shift_batch(const AdmpcConfig* c, int B, double* xbar, double* ubar, const double* p, int rollout);
+
 /* The QP of one RTI step solved for a single instance, returning everything the KKT checker in
  * tests/ needs: du[N][2], dx[N+1][7], the stage linearisation A[N][7][7], Bm[N][7][2], b[N][7]
  * and the inequality multipliers lam_u[N][2][4] (lower, upper, sl>=0, su>=0), lam_d[N][2]

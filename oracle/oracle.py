@@ -43,6 +43,8 @@ class Oracle:
         L.oracle_solve_batch.restype = C.c_int
         L.oracle_qp_debug.argtypes = [cp, _dp, _dp, _dp, C.c_double, _dp, _dp] + [_dp] * 9 + [_ip]
         L.oracle_qp_debug.restype = C.c_int
+        L.oracle_shift_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, C.c_int]
+        L.oracle_shift_batch.restype = C.c_int
         L.oracle_max_threads.restype = C.c_int
 
     def max_threads(self):
@@ -83,6 +85,18 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle_solve_batch failed: %d" % rc)
         return x, u, cost, status, iters
+
+    def shift_batch(self, cfg, xbar, ubar, p, rollout=True):
+        """Returns the shifted (x, u); the arguments are not modified."""
+        N = cfg.N
+        x = np.array(xbar, dtype=np.float64).reshape(-1, N + 1, NX).copy()
+        B = x.shape[0]
+        u = np.array(ubar, dtype=np.float64).reshape(B, N, NU).copy()
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(B)
+        rc = self.lib.oracle_shift_batch(C.byref(cfg), B, _ptr(x), _ptr(u), _ptr(p), 1 if rollout else 0)
+        if rc != 0:
+            raise RuntimeError("oracle_shift_batch failed: %d" % rc)
+        return x, u
 
     def qp_debug(self, cfg, x0, yref, yref_e, p, xbar, ubar):
         N = cfg.N

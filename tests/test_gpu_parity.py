@@ -306,6 +306,35 @@ def test_empty_batch_and_argument_errors(gpu_engine_factory):
         eng.solve(torch.zeros(3, 7), torch.zeros(3, 20, 9), torch.zeros(3, 7), torch.zeros(3), torch.zeros(3, 21, 7), torch.zeros(3, 20, 2))
 
 
+@pytest.mark.parametrize("with_gp", [False, True])
+def test_iterate_shift_matches_oracle(gpu_engine_factory, oracle, with_gp):
+    """admpc_shift_batch (SURVEY 8f-3 option): the moved stages are copies (bit-exact), the rolled-out terminal state
+    agrees with the oracle's RK4 step to 1e-12 relative."""
+    import torch
+    cfg = default_config(N=20)
+    if with_gp:
+        set_gp(cfg, grid_gp())
+    s = random_scenarios(67, N=20, seed=11, blend=(3.0, 5.0))          # 67: not a multiple of the 21 instances per wave
+    eng = gpu_engine_factory(cfg)
+    X, U, _, st, _ = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    d = eng.to_device
+    for rollout in (False, True):
+        tx, tu = d(X).clone(), d(U).clone()
+        eng.shift(tx, tu, d(s["p"]), rollout=rollout)
+        torch.cuda.synchronize()
+        gx, gu = tx.cpu().numpy(), tu.cpu().numpy()
+        ox, ou = oracle.shift_batch(cfg, X, U, s["p"], rollout=rollout)
+        assert np.array_equal(gu, ou) and np.array_equal(gx[:, :20], ox[:, :20])
+        if rollout:
+            assert np.abs(gx[:, 20] - ox[:, 20]).max() <= 1e-12 * max(1.0, np.abs(ox[:, 20]).max())
+            assert np.abs(gx[:, 20] - X[:, 20]).max() > 1e-3
+        else:
+            assert np.array_equal(gx[:, 20], ox[:, 20])
+    with pytest.raises(ValueError):
+        eng.shift(d(X), d(U), None, rollout=True)
+    eng.shift(d(X[:0]), d(U[:0]), d(s["p"][:0]))                        # empty batch: no launch
+
+
 def test_argmin_kernel(gpu_engine_factory):
     import torch
     eng = gpu_engine_factory(default_config())

@@ -100,3 +100,36 @@ def test_acados_shaped_seam_errors_and_iterate_io(tmp_path, golden_kat):
     sol.set(1, "p", np.array([0.5]))
     with pytest.raises(Exception, match="same on all stages"):
         sol.solve()
+
+
+def test_shift_iterate_option_of_the_seam(oracle):
+    """Off by default (the reference never shifts); "copy"/"rollout" shift the stored iterate before the solve."""
+    from ad_mpc_amd.ocp_solver import AdmpcOcpSolver
+    from ad_mpc_amd.scenarios import random_scenarios
+    cfg = default_config(N=20)
+    s = random_scenarios(1, N=20, seed=21)
+
+    def run(mode):
+        sol = AdmpcOcpSolver(cfg)
+        assert sol.shift_iterate is None
+        for k in range(20):
+            sol.set(k, "yref", s["yref"][0, k])
+        sol.set(20, "yref", s["yref_e"][0])
+        sol.set(0, "lbx", s["x0"][0]); sol.set(0, "ubx", s["x0"][0])
+        for k in range(21):
+            sol.set(k, "p", np.array([s["p"][0]])); sol.set(k, "x", s["x0"][0])
+        assert sol.solve() == 0
+        X1 = np.array([sol.get(k, "x") for k in range(21)]); U1 = np.array([sol.get(k, "u") for k in range(20)])
+        sol.shift_iterate = mode
+        assert sol.solve() == 0
+        return X1, U1, np.array([sol.get(k, "u") for k in range(20)])
+
+    X1, U1, u_plain = run(None)
+    for mode in ("copy", "rollout"):
+        _, _, u_shift = run(mode)
+        xs, us = oracle.shift_batch(cfg, X1[None], U1[None], s["p"], rollout=mode == "rollout")
+        want = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], xs, us)[1][0]
+        assert np.abs(u_shift - want).max() < 1e-8 and np.abs(u_shift - u_plain).max() > 1e-6
+    sol = AdmpcOcpSolver(cfg); sol.shift_iterate = "yes"
+    with pytest.raises(Exception, match="shift_iterate"):
+        sol.solve()

@@ -96,6 +96,36 @@ def test_gp_residual_changes_the_dynamics_consistently(oracle):
         np.testing.assert_allclose(Jx[:, j], fd, rtol=1e-6, atol=1e-6)
 
 
+def test_iterate_shift_restatement(oracle):
+    """SURVEY 8f-3 option (the reference never shifts): stage k takes stage k+1, the last input stays, the terminal state
+    is a copy or one RK4 step of the model under the last input."""
+    cfg = default_config(N=20)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(3, 21, 7)); x[:, :, 3] = 5.0 + rng.uniform(0, 5, size=(3, 21)); u = rng.normal(size=(3, 20, 2)) * 0.3
+    p = np.array([0.0, 0.4, 1.0])
+    xs, us = oracle.shift_batch(cfg, x, u, p, rollout=False)
+    assert np.array_equal(xs[:, :20], x[:, 1:]) and np.array_equal(xs[:, 20], x[:, 20])
+    assert np.array_equal(us[:, :19], u[:, 1:]) and np.array_equal(us[:, 19], u[:, 19])
+    xr, ur = oracle.shift_batch(cfg, x, u, p, rollout=True)
+    assert np.array_equal(xr[:, :20], xs[:, :20]) and np.array_equal(ur, us)
+    for b in range(3):
+        phi, _, _ = oracle.rk4_sens(cfg, x[b, 20], u[b, 19], p[b], cfg.Ts)
+        assert np.array_equal(xr[b, 20], phi)
+    # a shifted converged solution of a stationary problem is a far better start than the unshifted one
+    from ad_mpc_amd.scenarios import random_scenarios
+    s = random_scenarios(8, N=20, seed=3)
+    c15 = cfg.copy(); c15.sqp_iters = 15
+    X, U, _, st, _ = oracle.solve_batch(c15, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert (st == 0).all()
+    x0n = X[:, 1].copy()                                                 # the plant follows the prediction for one period
+    yn = np.concatenate([s["yref"][:, 1:], s["yref"][:, -1:]], axis=1)  # reference window moves on, last row repeated
+    Xs, Us = oracle.shift_batch(cfg, X, U, s["p"], rollout=True)
+    a = oracle.solve_batch(cfg, x0n, yn, s["yref_e"], s["p"], Xs, Us)
+    b = oracle.solve_batch(cfg, x0n, yn, s["yref_e"], s["p"], X, U)
+    ref = oracle.solve_batch(c15, x0n, yn, s["yref_e"], s["p"], Xs, Us)
+    assert np.abs(a[1] - ref[1]).max() < np.abs(b[1] - ref[1]).max()
+
+
 def test_zero_iterate_with_dynamic_branch_reports_qp_failure(oracle):
     """v_x = 0 in the iterate and p > 0: the model divides by v_x + 1e-99 (ad_3d_optimizer.py:290-297) and the
     linearisation overflows; the solve must flag status 4, leave the iterate untouched and return cost = +inf."""
