@@ -2069,6 +2069,26 @@ __global__ __launch_bounds__(256) void admpc_argmin_kernel(const double* __restr
     }
 }
 
+// second level of the arg-min: W gathered (cost, global index) pairs, 16 bytes each, as the per-GPU admpc_argmin wrote them
+// and an all-gather laid them out; one wave; same tie-break (lowest index) and NaN rule
+__global__ __launch_bounds__(WAVE) void admpc_argmin_pairs_kernel(const double* __restrict__ pairs, int W,
+                                                                  double* __restrict__ val, int64_t* __restrict__ idx)
+{
+    double best = INFINITY; int64_t bi = INT64_MAX;
+    for (int i = threadIdx.x; i < W; i += WAVE) {
+        double c = pairs[2 * i];
+        const int64_t ix = (int64_t)__double_as_longlong(pairs[2 * i + 1]);
+        if (!(c == c)) c = INFINITY;
+        if (c < best || (c == best && ix < bi)) { best = c; bi = ix; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(best, o, WAVE);
+        int64_t oi = __shfl_xor((long long)bi, o, WAVE);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (threadIdx.x == 0) { *val = best; *idx = bi == INT64_MAX ? 0 : bi; }
+}
+
 // post-solve epilogue: validity test ad_3d_optimizer.py:385-394 + Ackermann mapping
 // create_ros_ad_mpc.py:95-98; one thread per instance
 __global__ void admpc_epilogue_kernel(int N, int B, const double* __restrict__ xopt, const double* __restrict__ uopt,
@@ -2344,6 +2364,16 @@ int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset
     if (!s || !cost || !val || !idx || B <= 0) return fail(ADMPC_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(s->device));
     hipLaunchKernelGGL(admpc_argmin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cost, B, index_offset, val, idx);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, int64_t* idx, void* stream)
+{
+    if (!s || W <= 0) return fail(ADMPC_EINVAL, "bad argument");
+    if (!pairs || !val || !idx) return fail(ADMPC_EINVAL, "null array argument");
+    HIPCHK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(admpc_argmin_pairs_kernel, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, pairs, W, val, idx);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

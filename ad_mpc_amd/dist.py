@@ -47,3 +47,24 @@ def global_argmin(val, idx, group=None):
     vals = pairs[:, 0].contiguous()
     idxs = pairs[:, 1].contiguous().view(torch.int64)
     return pick_min(vals, idxs)
+
+
+def global_argmin_device(engine, cost, index_offset=0, group=None, gathered=None):
+    """The N-GPU arg-min in three device operations and no host synchronisation: admpc_argmin into a 16-byte record,
+    all-gather of the records (RCCL), admpc_argmin_pairs.  Returns a float64[2] device tensor
+    (value, bits of the int64 global index); `unpack_pair` reads it on the host."""
+    pair = engine.argmin_pair(cost, index_offset)
+    if not (dist.is_available() and dist.is_initialized()):
+        return pair
+    world = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((world, 2), dtype=torch.float64, device=pair.device)
+    dist.all_gather_into_tensor(gathered.view(-1), pair, group=group)
+    return engine.argmin_pairs(gathered)
+
+
+def unpack_pair(pair):
+    """(value, global index) of a float64[2] record on the host (synchronises)."""
+    h = pair.detach().cpu()
+    return float(h[0]), int(h[1:2].view(torch.int64)[0])
+

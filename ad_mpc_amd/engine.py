@@ -122,6 +122,29 @@ class BatchSolver:
         _lib.check(self.lib.admpc_argmin(self._h, _ptr(cost), B, int(index_offset), _ptr(val), _ptr(idx), self._stream()))
         return val, idx
 
+    def argmin_pair(self, cost, index_offset=0, pair=None):
+        """admpc_argmin with value and index written next to each other: a float64[2] tensor whose second element carries
+        the bits of the int64 global index -- the 16-byte record that is all-gathered across GPUs."""
+        B = cost.shape[0]
+        self._chk(cost, (B,))
+        if pair is None:
+            pair = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._chk(pair, (2,))
+        _lib.check(self.lib.admpc_argmin(self._h, _ptr(cost), B, int(index_offset), C.c_void_p(pair.data_ptr()),
+                                         C.c_void_p(pair.data_ptr() + 8), self._stream()))
+        return pair
+
+    def argmin_pairs(self, pairs, out=None):
+        """Second level: float64[W,2] gathered records -> float64[2] record of the winner (admpc_argmin_pairs)."""
+        W = pairs.shape[0]
+        self._chk(pairs, (W, 2))
+        if out is None:
+            out = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._chk(out, (2,))
+        _lib.check(self.lib.admpc_argmin_pairs(self._h, _ptr(pairs), W, C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 8),
+                                               self._stream()))
+        return out
+
     def epilogue(self, xopt, uopt, xref_xy):
         """Validity bit + Ackermann record per instance."""
         N = self.N

@@ -148,6 +148,11 @@ int admpc_shoot_batch(AdmpcSolver* s, int B,
 int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset,
                  double* val, int64_t* idx, void* stream);
 
+/* Second level of the arg-min: W (cost, global index) pairs of 16 bytes each -- val and idx of admpc_argmin written next to
+ * each other by every GPU, all-gathered into one array -- reduced with the same rules to the device scalars val/idx.
+ * (val and idx of admpc_argmin may point into one such 16-byte pair; the index travels as the bit pattern of an int64.) */
+int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, int64_t* idx, void* stream);
+
 /* Receding-horizon shift of the iterate between two solves.  The reference never shifts its iterate
  * (the acados capsule keeps it as it is, acados_solver_sim_car.c:705-731; reset_mpc_optimizer is a stub,
  * gp_ad_mpc_node.py:154-158), so this is an option the caller turns on, never part of admpc_solve_batch.

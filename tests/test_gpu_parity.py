@@ -6,6 +6,7 @@ Stated fp64 tolerance: |u - u_oracle|, |x - x_oracle| <= 1e-8 absolute (measured
 quantities <= 1e-11 relative.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -304,6 +305,34 @@ def test_empty_batch_and_argument_errors(gpu_engine_factory):
     assert L.admpc_create(C.byref(cfg), 99, C.byref(h)) == -2                           # no such device
     with pytest.raises(ValueError):
         eng.solve(torch.zeros(3, 7), torch.zeros(3, 20, 9), torch.zeros(3, 7), torch.zeros(3), torch.zeros(3, 21, 7), torch.zeros(3, 20, 2))
+
+
+def test_two_level_argmin_through_a_process_group(gpu_engine_factory):
+    """The N-GPU arg-min path of bench.py / config 4 on the one GPU of the box: admpc_argmin into a 16-byte record,
+    all-gather (RCCL, one rank), admpc_argmin_pairs; and the second level alone on hand-made records of 8 'ranks'."""
+    import torch
+    import torch.distributed as dist
+    from ad_mpc_amd import dist as adist
+    eng = gpu_engine_factory(default_config())
+    rng = np.random.default_rng(3)
+    cost = rng.uniform(1.0, 2.0, size=5000); cost[[17, 4000]] = 0.5; cost[100] = np.nan
+    tc = eng.to_device(cost)
+    pair = eng.argmin_pair(tc, index_offset=70000)
+    assert adist.unpack_pair(pair) == (0.5, 70017)
+    vals = np.array([3.0, np.nan, 1.25, 7.0, 1.25, np.inf, 2.0, 1.25])
+    idxs = np.array([5, 1, 900, 3, 40, 2, 6, 41], dtype=np.int64)
+    rec = np.stack([vals, idxs.view(np.float64)], axis=1)
+    assert adist.unpack_pair(eng.argmin_pairs(eng.to_device(rec))) == (1.25, 40)
+    allbad = np.stack([np.full(3, np.nan), np.array([9, 4, 6], dtype=np.int64).view(np.float64)], axis=1)
+    v, i = adist.unpack_pair(eng.argmin_pairs(eng.to_device(allbad)))
+    assert v == np.inf and i == 4
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        out = adist.global_argmin_device(eng, tc, index_offset=70000)
+        assert adist.unpack_pair(out) == (0.5, 70017)
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("with_gp", [False, True])
