@@ -110,6 +110,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # torch.distributed.run: one rank per GPU, also for N = 1
+    # stdout carries exactly one JSON line: whatever native libraries print there (the RCCL banner at communicator
+    # creation) is sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -205,7 +210,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg, scen)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
