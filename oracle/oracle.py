@@ -31,8 +31,11 @@ def _ptr(a, ty=_dp):
 class Oracle:
     def __init__(self, omp=False):
         path = os.path.join(_HERE, "liboracle_omp.so" if omp else "liboracle.so")
-        if not os.path.exists(path):
-            build(omp=omp)
+        try:
+            build(omp=omp)                      # no-op when up to date; a stale library must not outlive a change of the C file
+        except Exception:
+            if not os.path.exists(path):
+                raise
         self.lib = C.CDLL(path)
         L = self.lib
         cp = C.POINTER(AdmpcConfig)
