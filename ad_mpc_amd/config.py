@@ -54,6 +54,7 @@ class AdmpcConfig(C.Structure):
         ("ipm_tol_res", C.c_double),
         ("ipm_tol_step", C.c_double),
         ("ipm_try_unconstrained", C.c_double),
+        ("ipm_warm_thr", C.c_double),
         ("gp", AdmpcGp * GP_MAX),
     ]
 
@@ -93,6 +94,7 @@ SLACK_L1 = 10.0            # ocp.cost.zl = zu = 1e1, src/ad_mpc/ad_3d_optimizer.
 IPM_ITER_MAX = 50
 IPM_MU0 = 1.0
 IPM_THR0 = 0.1
+IPM_WARM_THR = 0.01
 IPM_TOL_COMP = 1e-10
 IPM_TOL_RES = 1e-9
 IPM_TOL_STEP = 1e-6
@@ -121,6 +123,7 @@ def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TER
     c.ipm_mu0, c.ipm_thr0 = IPM_MU0, IPM_THR0
     c.ipm_tol_comp, c.ipm_tol_res, c.ipm_tol_step = IPM_TOL_COMP, IPM_TOL_RES, IPM_TOL_STEP
     c.ipm_try_unconstrained = 1.0
+    c.ipm_warm_thr = IPM_WARM_THR
     return c
 
 

@@ -594,6 +594,7 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
     const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
     const int itmax = cfg->ipm_iter_max;
     const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
+    const double thw = cfg->ipm_warm_thr;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
     const int nu_sets = 2 * N;
     Roles R;
@@ -707,6 +708,51 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                 for (int m = 0; m < UPL; ++m) { const int sid = lane + WAVE * m; if (sid < nu_sets) U[m].du = L.guk[sid]; }
 #pragma unroll
                 for (int m = 0; m < TPL; ++m) if (T[m].k) T[m].dx += L.ddx[(T[m].k - 1) * 7 + T[m].i];
+            } else if (thw > 0.0) {
+                // warm start (cfg.ipm_warm_thr): the interior point starts from that minimiser -- its inputs, states and dynamics
+                // multipliers; a violated input bound is absorbed by its slack, a violated steering bound stays as a residual
+#pragma unroll
+                for (int m = 0; m < UPL; ++m) {
+                    const int sid = lane + WAVE * m;
+                    if (sid < nu_sets) {
+                        USet2& s = U[m];
+                        const double v = L.guk[sid];
+                        s.du = v;
+                        s.sl = fmax(s.dl - v, 0.0) + thw; s.su = fmax(v - s.duu, 0.0) + thw;
+                        const double r0[4] = { v + s.sl - s.dl, s.su + s.duu - v, s.sl, s.su };
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { s.t[i] = r0[i] > thw ? r0[i] : thw; s.lam[i] = mu0 / s.t[i]; }
+                    }
+                }
+                DSET_LOOP {
+                    DSET_BIND
+                    if (dact) {
+                        D.dx6 += L.ddx[(dk - 1) * 7 + 6];
+                        const double r0[2] = { D.dx6 - D.dl, D.du - D.dx6 };
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { D.t[i] = r0[i] > thw ? r0[i] : thw; D.lam[i] = mu0 / D.t[i]; }
+                    }
+                }
+                double dpi0[TPL];
+#pragma unroll
+                for (int m = 0; m < TPL; ++m) {
+                    dpi0[m] = 0.0;
+                    if (T[m].k) {
+                        const int k = T[m].k, i = T[m].i;
+                        const double* dk = L.ddx + (k - 1) * 7;
+                        const double* Pp = L.Pk + (k - 1) * PKS;
+                        double dp = L.pv[(k - 1) * 7 + i];
+#pragma unroll
+                        for (int l = 0; l < NX; ++l) {
+                            const int lo = l < i ? l : i, hi = l < i ? i : l;
+                            dp += Pp[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)] * dk[l];
+                        }
+                        dpi0[m] = dp;
+                        T[m].dx += dk[i];
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < TPL; ++m) if (T[m].k) L.pi[(T[m].k - 1) * 7 + T[m].i] = dpi0[m];
             }
             WSYNC();
         }
@@ -1457,6 +1503,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
     const int itmax = cfg->ipm_iter_max;
     const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
+    const double thw = cfg->ipm_warm_thr;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
     // Factorisation of the Newton matrix M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) into L D L' (LDS: Lp, invd).
     // Used twice per instance at most: once without barrier terms (the unconstrained trial) and once per interior-point iteration.
@@ -1593,6 +1640,21 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             const bool ok = (!uact || (duc >= dl_i && duc <= duu_i)) && (!dact || (dx6c >= Ddl && dx6c <= Ddu));
             WSYNC();
             if (__all(ok)) { du = duc; solved = true; }
+            else if (thw > 0.0) {
+                // warm start (cfg.ipm_warm_thr): the interior point starts from that minimiser.  A violated input bound is absorbed
+                // by its slack (the input box is soft), a violated steering bound stays as a primal residual.
+                du = duc;
+                sl = fmax(dl_i - duc, 0.0) + thw; su = fmax(duc - duu_i, 0.0) + thw;
+                const double r0[4] = { duc + sl - dl_i, su + duu_i - duc, sl, su };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thw ? r0[i] : thw; lam[i] = mu0 * rcp_nr(t[i]); }
+                if (dact) {
+                    dx6 = dx6c;
+                    const double q0[2] = { dx6 - Ddl, Ddu - dx6 };
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { Dt[i] = q0[i] > thw ? q0[i] : thw; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
+                }
+            }
         }
         PHASE_STAMP(8);
         if (!solved)
@@ -2173,7 +2235,7 @@ int admpc_default_config(AdmpcConfig* c, int N, double Ts)
     c->Iz = c->L_F * c->L_R * (r_mass + f_mass);
     c->Cf = f_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195; c->Cr = r_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195;
     c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9; c->ipm_tol_step = 1e-6;
-    c->ipm_try_unconstrained = 1.0;
+    c->ipm_try_unconstrained = 1.0; c->ipm_warm_thr = 0.01;
     return ADMPC_OK;
 }
 
@@ -2189,6 +2251,7 @@ static int validate(const AdmpcConfig* c)
     }
     if (!(c->W[NX] > 0 && c->W[NX + 1] > 0)) return fail(ADMPC_EINVAL, "input weights must be positive (strict convexity)");
     if (c->ipm_iter_max < 1) return fail(ADMPC_EINVAL, "ipm_iter_max < 1");
+    if (!(c->ipm_mu0 > 0) || !(c->ipm_thr0 > 0) || !(c->ipm_warm_thr >= 0)) return fail(ADMPC_EINVAL, "ipm_mu0, ipm_thr0 must be > 0 and ipm_warm_thr >= 0");
     return ADMPC_OK;
 }
 

@@ -98,6 +98,10 @@ typedef struct AdmpcConfig {
     double  ipm_try_unconstrained; /* != 0: first solve the QP without its inequalities (one factorisation + one solve);
                                     * if that minimiser respects every bound it IS the QP solution (iters = 0) and the
                                     * interior point is skipped.  Default 1 (all device paths and the oracle). */
+    double  ipm_warm_thr;      /* > 0 (and the trial on): when that minimiser violates a bound the interior point starts
+                                * from it instead of from the zero step -- inputs, states and dynamics multipliers of the
+                                * minimiser, input slacks sl/su = violation + ipm_warm_thr, every inequality slack clipped
+                                * below at ipm_warm_thr, multipliers ipm_mu0 / slack.  0: cold start.  Default 0.01. */
     AdmpcGp gp[ADMPC_GP_MAX];
 } AdmpcConfig;
 

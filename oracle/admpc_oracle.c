@@ -480,6 +480,27 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             }
             return 0;
         }
+        if (c->ipm_warm_thr > 0) {
+            /* warm start (cfg.ipm_warm_thr): the interior point starts from that minimiser instead of from the zero step.
+             * Inputs, states and dynamics multipliers are the minimiser's; a violated input bound is absorbed by its slack
+             * (the bounds are soft), a violated delta bound is left as a primal residual (residual form of the method). */
+            const real thw = c->ipm_warm_thr;
+            for (int k = 0; k < N; ++k) {
+                for (int j = 0; j < NU; ++j) {
+                    const real v = w->ddu[k][j];
+                    const real vl = qp->dlu[k][j] - v, vu = v - qp->duu[k][j];
+                    s->du[k][j] = v;
+                    s->sl[k][j] = (vl > 0 ? vl : 0) + thw; s->su[k][j] = (vu > 0 ? vu : 0) + thw;
+                    real r0[4] = { v + s->sl[k][j] - qp->dlu[k][j], -v + s->su[k][j] + qp->duu[k][j], s->sl[k][j], s->su[k][j] };
+                    for (int i = 0; i < 4; ++i) { s->t[k][j][i] = r0[i] > thw ? r0[i] : thw; s->lam[k][j][i] = mu0 / s->t[k][j][i]; }
+                }
+                for (int i = 0; i < NX; ++i) { s->dx[k + 1][i] += w->ddx[k + 1][i]; s->pi[k][i] = w->dpi[k][i]; }
+            }
+            for (int k = 1; k < N; ++k) {
+                real r0[2] = { s->dx[k][6] - qp->dld[k], qp->dud[k] - s->dx[k][6] };
+                for (int i = 0; i < 2; ++i) { s->td[k][i] = r0[i] > thw ? r0[i] : thw; s->lamd[k][i] = mu0 / s->td[k][i]; }
+            }
+        }
     }
     int it;
     real rmax_prev = 0, step = 1e300;   /* step: max-norm of the last applied input step */

@@ -110,6 +110,27 @@ def test_unconstrained_trial_on_and_off(gpu_engine_factory, oracle):
     assert np.abs(g_on[1] - g_off[1]).max() <= 1e-9 and np.abs(g_on[0] - g_off[0]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("N", [20, 24, 40])
+def test_warm_start_from_the_unconstrained_minimiser(gpu_engine_factory, oracle, N):
+    """cfg.ipm_warm_thr: after a failed trial the interior point starts from the inequality-free minimiser (default) or from
+    the zero step (0).  Same solution either way, oracle parity for both, and fewer iterations with the warm start --
+    on the condensed path (N = 20) and on the Riccati path (N = 24, 40)."""
+    s = random_scenarios(512, N=N, seed=4321, blend=(3.0, 5.0))
+    warm = default_config(N=N); cold = warm.copy(); cold.ipm_warm_thr = 0.0
+    assert warm.ipm_warm_thr == 0.01
+    g_w, o_w = _solve_both(gpu_engine_factory(warm), oracle, warm, s)
+    g_c, o_c = _solve_both(gpu_engine_factory(cold), oracle, cold, s)
+    _assert_parity(g_w, o_w); _assert_parity(g_c, o_c)
+    np.testing.assert_array_equal(g_w[4] == 0, g_c[4] == 0)                 # the trial decides the same way
+    assert np.abs(g_w[1] - g_c[1]).max() <= 1e-7 and np.abs(g_w[0] - g_c[0]).max() <= 1e-7
+    ipm = g_c[4] > 0
+    assert ipm.any() and g_w[4][ipm].mean() < 0.9 * g_c[4][ipm].mean()
+    bad = cold.copy(); bad.ipm_warm_thr = -1.0
+    h = C.c_void_p(0)
+    from ad_mpc_amd import _lib
+    assert _lib.load().admpc_create(C.byref(bad), 0, C.byref(h)) == -1
+
+
 def test_all_state_weights_nonzero(gpu_engine_factory, oracle):
     """The shipped weights only track x, y, psi (specialised condensing kernel); with velocity / yaw-rate / steering weights
     the general instantiation runs.  N = 20 (condensed path) and N = 24 (Riccati path) against the oracle."""
