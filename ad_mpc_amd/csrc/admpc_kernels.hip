@@ -249,6 +249,7 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
 #define KLS 17           // K0[7] K1[7] i00 i01 i11
 #define LIN_BLOCK 64     // threads per block of the linearisation kernel: single waves balance best over the CUs (256 registers each)
 #define LIN_TASKS 63     // tasks per block (multiple of 3)
+#ifndef ADMPC_TU_RICCATI
 // work scheduler of the condensed path (int array): [0] ticket counter, [64 + q] number of instances in effort bucket q,
 // [SCHED_HDR + q * cap + j] j-th instance of bucket q.  Zeroed by the linearisation kernel, filled by the condensing kernel,
 // drained (highest bucket first) by the persistent interior-point waves.
@@ -289,6 +290,8 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
         }
     }
 }
+
+#endif  // !ADMPC_TU_RICCATI
 
 // ---------------------------------------------------------------------------------------------
 // wave-level primitives
@@ -368,6 +371,7 @@ __device__ __forceinline__ double sel7(const double* a, int i) {
     return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : i == 4 ? a[4] : i == 5 ? a[5] : a[6];
 }
 
+#ifndef ADMPC_TU_MAIN      // ---- the stage-wise Riccati path: its own translation unit when the library is built in two (Makefile)
 struct Roles {       // stage-independent lane roles of the Riccati factorisation
     int i1, c1;      // L1: M^T[c1][i1], lanes < 49
     double r6_1;     // implicit row 6 of stored column c1
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
                                                         const double* __restrict__ GTg, const double* __restrict__ blg,
                                                         double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                         double* __restrict__ costg, int32_t* __restrict__ statusg,
-                                                        int32_t* __restrict__ itersg, int first_pass)
+                                                        int32_t* __restrict__ itersg, int first_pass, int* __restrict__ ticket)
 {
     extern __shared__ double lds_raw[];
     const int lane = threadIdx.x;
@@ -600,7 +604,14 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
     Roles R;
     make_roles(lane, Ts, Qd, Qe, R);
 
-    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+    // Instances need 0 .. 20 interior-point iterations each: the waves draw them from a counter (zeroed by the linearisation
+    // kernel) instead of striding over the batch, so that no wave is left with a run of expensive ones.
+    auto next_instance = [&]() __attribute__((always_inline)) -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ticket, 1);
+        return (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int inst = blockIdx.x; inst < B; inst = next_instance()) {
         if (!first_pass && statusg[inst] != 0) continue;          // failed in an earlier SQP step: leave untouched
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
@@ -1041,6 +1052,36 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
     }
 }
 
+}  // namespace
+// Host side of the Riccati path.  This part of the file is compiled at -O1 in a translation unit of its own (ADMPC_TU_RICCATI,
+// see the Makefile): with -O2/-O3 hipcc 7.2 produced wrong code for the N = 33 .. 45 instantiation once the instance loop drew
+// tickets (open issue), and the -O1 code is also the faster one (1.92 vs 2.25 ms at N = 40, B = 2048).
+extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_prepare(void)
+{
+    const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
+                             (const void*)admpc_qp_kernel<2, 5, 1, 0>, (const void*)admpc_qp_kernel<2, 7, 1, 0>,
+                             (const void*)admpc_qp_kernel<3, 11, 2, 0>, (const void*)admpc_qp_kernel<4, 14, 2, 0> };
+    for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    // > 64 KB of dynamic LDS
+}
+extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_launch(int N, int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B,
+        const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
+        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, int first, int* ticket)
+{
+    // (the NT template parameter allows compile-time-N instantiations; none is dispatched)
+#define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(grid), dim3(WAVE), lds_bytes, st, d_cfg, B, x0, yref, yref_e, \
+                           GT, bl, xbar, ubar, cost, stat, iters, first, ticket)
+    if (N <= 27) LAUNCH_QP(1, 3, 1, 0);
+    else if (N <= 32) LAUNCH_QP(1, 4, 1, 0);
+    else if (N <= 45) LAUNCH_QP(2, 5, 1, 0);
+    else if (N <= 64) LAUNCH_QP(2, 7, 1, 0);
+    else if (N <= 96) LAUNCH_QP(3, 11, 2, 0);      // 7N <= 704, 2N <= 192
+    else LAUNCH_QP(4, 14, 2, 0);                   // N <= 128
+#undef LAUNCH_QP
+}
+namespace {
+#endif  // !ADMPC_TU_MAIN
+
+#ifndef ADMPC_TU_RICCATI   // ---- everything below: main translation unit only
 // ---------------------------------------------------------------------------------------------
 // kernel B' : condensed QP, dense Cholesky -- the reference's own QP strategy (FULL_CONDENSING_HPIPM,
 // acados_solver_sim_car.c:145) for horizons with 2N <= 64 inputs.  One instance per wavefront,
@@ -2214,6 +2255,13 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ADMPC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
+#ifdef ADMPC_TU_MAIN      // defined in the Riccati translation unit
+extern "C" void admpc_riccati_prepare(void);
+extern "C" void admpc_riccati_launch(int N, int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B,
+        const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
+        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, int first, int* ticket);
+#endif
+
 extern "C" {
 
 const char* admpc_last_error(void) { return g_err.c_str(); }
@@ -2287,10 +2335,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     s->qmask = 7;
     for (int c = 3; c < NX; ++c) if (cfg->W[c] != 0.0 || cfg->We[c] != 0.0) s->qmask = 127;
     // opt in to > 64 KB of dynamic LDS
-    const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
-                             (const void*)admpc_qp_kernel<2, 5, 1, 0>, (const void*)admpc_qp_kernel<2, 7, 1, 0>,
-                             (const void*)admpc_qp_kernel<3, 11, 2, 0>, (const void*)admpc_qp_kernel<4, 14, 2, 0> };
-    for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    admpc_riccati_prepare();
     (void)hipFuncSetAttribute((const void*)admpc_qp_dense_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
@@ -2344,6 +2389,8 @@ int admpc_reserve(AdmpcSolver* s, int B)
         HIPCHK(hipMalloc((void**)&s->d_H, (size_t)B * DenseLds<20>::NTRI * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s->d_aux, (size_t)B * 128 * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s->d_sched, ((size_t)SCHED_HDR + (size_t)SCHED_NB * B) * sizeof(int)));
+    } else {
+        HIPCHK(hipMalloc((void**)&s->d_sched, (size_t)SCHED_HDR * sizeof(int)));       // [0]: instance counter of the Riccati kernel
     }
     s->cap = B;
     return ADMPC_OK;
@@ -2370,9 +2417,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     for (int sq = 0; sq < nsqp; ++sq) {
         const int first = sq == 0 ? 1 : 0;
         hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
-                           first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->use_dense ? s->d_sched : (int*)nullptr);
-#define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(gridB), dim3(WAVE), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, \
-                           (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, iters, first)
+                           first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->d_sched);
         if (s->use_dense) {
             constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + NX * 64) * (int)sizeof(double);
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
@@ -2394,15 +2439,9 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
             hipLaunchKernelGGL((admpc_expand_kernel<20>), dim3(gridE), dim3(WAVE), exp_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, (const double*)s->d_aux);
         }
-        // (the NT template parameter allows compile-time-N instantiations; none is dispatched: a <2,5,40> build gave
-        //  nondeterministic results at B >= 64 on MI355X while the runtime-N kernels are correct -- cause not yet understood)
-        else if (N <= 27) LAUNCH_QP(1, 3, 1, 0);
-        else if (N <= 32) LAUNCH_QP(1, 4, 1, 0);
-        else if (N <= 45) LAUNCH_QP(2, 5, 1, 0);
-        else if (N <= 64) LAUNCH_QP(2, 7, 1, 0);
-        else if (N <= 96) LAUNCH_QP(3, 11, 2, 0);      // 7N <= 704, 2N <= 192
-        else LAUNCH_QP(4, 14, 2, 0);                   // N <= 128
-#undef LAUNCH_QP
+        else
+            admpc_riccati_launch(N, gridB, s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
+                                 xbar, ubar, cost, stat, iters, first, s->d_sched);
     }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -2486,3 +2525,7 @@ int admpc_waypoints_batch(int device, int M, int H, double dt, int B,
 }
 
 }  // extern "C"
+#endif  // !ADMPC_TU_RICCATI
+#ifdef ADMPC_TU_RICCATI
+}  // namespace
+#endif

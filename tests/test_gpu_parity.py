@@ -158,6 +158,24 @@ def test_bitwise_repeatability(gpu_engine_factory):
                 np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("N,B", [(24, 300), (40, 64), (40, 1500), (64, 600)])
+def test_riccati_path_repeatable_and_ticket_order_free(gpu_engine_factory, oracle, N, B):
+    """The stage-wise kernel (N != 20) draws its instances from a counter: more instances than resident waves (B = 1500 at
+    four waves per CU would not fit 1024 slots at N = 40) must give the same bits as any other draw order, run after run,
+    and the oracle's answer.  (A -O2/-O3 build of the ticket loop failed exactly this at N = 40; the kernel is built at -O1.)"""
+    cfg = default_config(N=N)
+    s = random_scenarios(B, N=N, seed=77, blend=(3.0, 5.0))
+    eng = gpu_engine_factory(cfg)
+    ref = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    for _ in range(4):
+        g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        for a, b in zip(g, ref):
+            np.testing.assert_array_equal(a, b)
+    n = min(B, 256)
+    o = oracle.solve_batch(cfg, s["x0"][:n], s["yref"][:n], s["yref_e"][:n], s["p"][:n], s["xbar"][:n], s["ubar"][:n])
+    _assert_parity(tuple(a[:n] for a in ref), o)
+
+
 def test_full_size_batch_4096(gpu_engine_factory, oracle):
     """BASELINE configs[1] at full size: direct parity for every instance plus size-independent properties."""
     cfg = default_config(N=20)
