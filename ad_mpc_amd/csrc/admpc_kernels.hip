@@ -1129,6 +1129,10 @@ __device__ __forceinline__ int wave_scan_incl_int(int v) {        // inclusive p
 // stragglers start early instead of last.  Lane l looks at bin SCHED_NB-1-l.
 // The first ticket of a wave is its block index (no atomic: 2048 simultaneous draws on one word queue up for ~20 us),
 // later ones are gridDim.x + a global counter.
+// Placement (observed, scripts/probes/place_probe.hip + scripts/trace_d.py; nothing depends on it): the grid fills one wave
+// per SIMD first, block b + 4*CUs lands on the SIMD of block b, and the wave that arrived first keeps full speed
+// (11.1-11.9 us per iteration) while the second one gets 14-18 us as long as both are busy.  With first ticket = block index
+// the 1024 predicted-longest instances are exactly the ones that run at full speed.
 __device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap, bool first) {
     const int lane = threadIdx.x;
     int t = blockIdx.x;
@@ -1630,6 +1634,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     PHASE_DECL();
     for (int inst = sched_next(sched, cap, true); inst >= 0; inst = sched_next(sched, cap, false)) {
         PHASE_STAMP(7);
+#ifdef ADMPC_TRACE_SCHED   // debug build (scripts/trace_d.py): start time, duration, block and iteration count of every instance, packed into `cost`
+        unsigned long long dbg_t0; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_t0));
+#endif
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
         // ---------------- stage: condensed Hessian (kernel C) and per-lane data ----------------
@@ -1862,6 +1869,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             statusg[inst] = failed ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
             if (failed && costg) costg[inst] = INFINITY;
             if (itersg) itersg[inst] = it;
+#ifdef ADMPC_TRACE_SCHED
+            { unsigned long long dbg_t1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_t1));
+              unsigned long long dur = dbg_t1 - dbg_t0; if (dur > 32767) dur = 32767;          // 100 MHz ticks
+              const unsigned long long pk = ((dbg_t0 & 0xfffffull) << 33) | (dur << 18) | ((unsigned long long)blockIdx.x << 6) | (unsigned long long)(it & 63);
+              if (costg) costg[inst] = (double)pk; }
+#endif
         }
         WSYNC();
         PHASE_STAMP(6);
@@ -1959,7 +1972,9 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         }
         const double Jt = wave_reduce<OpSum>(J + Ju);
         if (lane == 0) {
+#ifndef ADMPC_TRACE_SCHED
             if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? Jt : INFINITY;
+#endif
             statusg[inst] = status;
         }
         WSYNC();
