@@ -195,7 +195,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
-                         "kernel": "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~70 %) + admpc_expand_kernel<20>" if N == 20 else "one step = admpc_linearize_kernel + admpc_qp_kernel (stage-wise Riccati)", "kernel_ms": kern_ms,
+                         "kernel": "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>" if N == 20 else "one step = admpc_linearize_kernel + admpc_qp_kernel (stage-wise Riccati)", "kernel_ms": kern_ms,
                          "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N)},
