@@ -401,6 +401,22 @@ def test_iterate_shift_matches_oracle(gpu_engine_factory, oracle, with_gp):
     with pytest.raises(ValueError):
         eng.shift(d(X), d(U), None, rollout=True)
     eng.shift(d(X[:0]), d(U[:0]), d(s["p"][:0]))                        # empty batch: no launch
+    L = eng.lib
+    assert L.admpc_shift_batch(eng._h, 3, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), 0, C.c_void_p(0)) == -1      # null arrays
+    assert L.admpc_argmin_pairs(eng._h, C.c_void_p(0), 0, C.c_void_p(0), C.c_void_p(0), C.c_void_p(0)) == -1
+    if not with_gp:                                                     # the shortest and a long horizon, dynamic branch
+        for N, B in ((2, 5), (64, 9)):
+            c2 = default_config(N=N)
+            s2 = random_scenarios(B, N=N, seed=12, blend=(3.0, 5.0))
+            e2 = gpu_engine_factory(c2)
+            X2 = s2["xbar"] + np.random.default_rng(1).normal(size=s2["xbar"].shape) * 0.01
+            U2 = s2["ubar"] + np.random.default_rng(2).normal(size=s2["ubar"].shape) * 0.1
+            tx, tu = e2.to_device(X2).clone(), e2.to_device(U2).clone()
+            e2.shift(tx, tu, e2.to_device(s2["p"]), rollout=True)
+            torch.cuda.synchronize()
+            ox, ou = oracle.shift_batch(c2, X2, U2, s2["p"], rollout=True)
+            assert np.array_equal(tu.cpu().numpy(), ou) and np.array_equal(tx.cpu().numpy()[:, :N], ox[:, :N])
+            assert np.abs(tx.cpu().numpy()[:, N] - ox[:, N]).max() <= 1e-12 * max(1.0, np.abs(ox[:, N]).max())
 
 
 def test_argmin_kernel(gpu_engine_factory):
