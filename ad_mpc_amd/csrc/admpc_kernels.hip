@@ -88,7 +88,7 @@ __device__ __forceinline__ double exp_nonpos(const double x) {
 __device__ __forceinline__ void gp_eval(const AdmpcGp& g, double z, double& mu, double& dmu) {
     double m = 0.0, d = 0.0;
     const int n = g.n_points;
-    const int lane = threadIdx.x & 63, sub = lane % 3, base = lane - sub;
+    const int lane = threadIdx.x & 63, sub = lane - 3 * (int)(((unsigned)lane * 21846u) >> 16), base = lane - sub;   // lane % 3 without a narrow urem (see div7)
     for (int i = sub; i < n; i += 3) {
         const double dz = z - g.Z[i];
         const double k = g.sigma_f * exp_nonpos(-0.5 * dz * dz * g.inv_l2);
@@ -362,6 +362,10 @@ __device__ __forceinline__ void lds2_carve(double* p, int N, Lds2& L) {
 #define WSYNC() __syncthreads()
 #endif
 
+// x / 7 for 0 <= x < 13107 as a 32-bit multiply-shift: hipcc 7.2 narrows small non-negative ints to 16 bits and its backend
+// cannot select the 16-bit udivrem by 7 at -Oz ("Cannot select: i16 udivrem"); there is no `/ 7` or `% 7` on the device.
+__device__ __forceinline__ int div7(int x) { return (int)(((unsigned)x * 9363u) >> 16); }
+
 __device__ __forceinline__ int tri_index(int i, int j) {   // packed index of (i<=j) in a 7x7 upper triangle, row-major
     return i * 7 - (i * (i - 1)) / 2 + (j - i);
 }
@@ -387,7 +391,7 @@ struct Roles {       // stage-independent lane roles of the Riccati factorisatio
 __device__ __forceinline__ double r6_of(int c, double h) { return c == 4 ? 1.0 : (c == 6 ? h : 0.0); }
 
 __device__ __forceinline__ void make_roles(int lane, double h, const double* Qd, const double* Qe, Roles& R) {
-    R.i1 = lane / 7; R.c1 = lane % 7;
+    R.i1 = div7(lane); R.c1 = lane - 7 * R.i1;
     if (lane >= 49) { R.i1 = 0; R.c1 = 0; }
     R.r6_1 = r6_of(R.c1, h);
     int t = lane < 45 ? lane : 0, r = 0;
@@ -396,7 +400,7 @@ __device__ __forceinline__ void make_roles(int lane, double h, const double* Qd,
     R.r2 = r; R.c2 = r + t;
     R.altoff = R.c2 < 2 ? R.r2 * 8 + R.c2 : (R.c2 - 2) * 8 + R.r2;
     R.r6_2 = r6_of(R.r2 >= 2 ? R.r2 - 2 : 0, h);
-    R.i3 = R.i1; R.j3 = lane < 49 ? lane % 7 : 0;
+    R.i3 = R.i1; R.j3 = lane < 49 ? R.c1 : 0;
     R.pkoff = (lane < 49 && R.i3 <= R.j3) ? tri_index(R.i3, R.j3) : -1;
     R.qd2 = sel7(Qd, R.r2 < 7 ? R.r2 : 0);
     R.qe3 = R.i3 == R.j3 ? sel7(Qe, R.i3) : 0.0;
@@ -631,7 +635,9 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
             const int t = lane + WAVE * m;
             const bool on = t < N * 7;
             const int tt = on ? t : 0;
-            const int k = tt / 7 + 1, i = tt % 7;
+            int ttl = tt; asm volatile("" : "+v"(ttl));          // opaque: keeps the index arithmetic in 32 bits (see div7)
+            const int kq = div7(ttl);
+            const int k = kq + 1, i = ttl - 7 * kq;
             T[m].k = on ? k : 0; T[m].i = i;
             T[m].w = k < N ? sel7(Qd, i) : sel7(Qe, i);
             T[m].q0 = T[m].w * (xbg[7 + tt] - (k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i]));
@@ -650,6 +656,11 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
             const double r0[4] = { thr - U[m].dl, thr + U[m].duu, thr, thr };
 #pragma unroll
             for (int i = 0; i < 4; ++i) { U[m].t[i] = r0[i] > thr ? r0[i] : thr; U[m].lam[i] = mu0 / U[m].t[i]; }
+            // every field defined from the start: the slots beyond 2N inputs never receive a step, and an undefined value must not
+            // reach the arithmetic below even where its result is discarded
+            U[m].ru = 0.0; U[m].dsl = 0.0; U[m].dsu = 0.0; U[m].iG02 = 0.0; U[m].iG13 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { U[m].it[i] = 0.0; U[m].il[i] = 0.0; U[m].rc[i] = 0.0; U[m].dt[i] = 0.0; U[m].dlam[i] = 0.0; }
         }
         DSet2 Dv[DPL];
 #define DSET_LOOP _Pragma("unroll") for (int md = 0; md < DPL; ++md)
@@ -658,6 +669,9 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
             DSET_BIND
             const double x6 = xbg[(dact ? dk : 0) * 7 + 6];
             D.dl = cfg->lbx_delta - x6; D.du = cfg->ubx_delta - x6;
+            D.dx6 = 0.0; D.rx6 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { D.t[i] = 1.0; D.lam[i] = 0.0; D.it[i] = 0.0; D.il[i] = 0.0; D.rc[i] = 0.0; D.dt[i] = 0.0; D.dlam[i] = 0.0; }
         }
         const double dx0 = lane < NX ? x0g[(size_t)inst * NX + lane] - xbg[lane] : 0.0;
         WSYNC();
@@ -1054,14 +1068,13 @@ __global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __res
 
 }  // namespace
 // Host side of the Riccati path.  This part of the file is compiled at -O1 in a translation unit of its own (ADMPC_TU_RICCATI,
-// see the Makefile): with -O2/-O3 hipcc 7.2 produced wrong code for the N = 33 .. 45 instantiation once the instance loop drew
-// tickets (open issue), and the -O1 code is also the faster one (1.92 vs 2.25 ms at N = 40, B = 2048).
+// see the Makefile): the -O1 code is the faster one (1.92 vs 2.25 ms at N = 40, B = 2048).
 extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_prepare(void)
 {
-    const void* kerns[6] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
-                             (const void*)admpc_qp_kernel<2, 5, 1, 0>, (const void*)admpc_qp_kernel<2, 7, 1, 0>,
+    const void* kerns[5] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
+                             (const void*)admpc_qp_kernel<2, 7, 1, 0>,
                              (const void*)admpc_qp_kernel<3, 11, 2, 0>, (const void*)admpc_qp_kernel<4, 14, 2, 0> };
-    for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    // > 64 KB of dynamic LDS
+    for (int i = 0; i < 5; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    // > 64 KB of dynamic LDS
 }
 extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_launch(int N, int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B,
         const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
@@ -1072,7 +1085,9 @@ extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_launch(int N
                            GT, bl, xbar, ubar, cost, stat, iters, first, ticket)
     if (N <= 27) LAUNCH_QP(1, 3, 1, 0);
     else if (N <= 32) LAUNCH_QP(1, 4, 1, 0);
-    else if (N <= 45) LAUNCH_QP(2, 5, 1, 0);
+    // N = 33 .. 45 would fit five state entries per lane, but every build of a <2,5,..> instantiation that went wrong on the GPU
+    // (run-to-run different results, on some MI355X boxes only, following the code generation: DESIGN.md) was that one; the
+    // <2,7,..> code computes the same horizons correctly on the same boxes at 5 % more time
     else if (N <= 64) LAUNCH_QP(2, 7, 1, 0);
     else if (N <= 96) LAUNCH_QP(3, 11, 2, 0);      // 7N <= 704, 2N <= 192
     else LAUNCH_QP(4, 14, 2, 0);                   // N <= 128
@@ -1172,7 +1187,7 @@ __device__ __forceinline__ void stage_dq(double* __restrict__ dq, const double* 
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1;
-        const int k = i / 7, c = i - 7 * k;
+        const int k = div7(i), c = i - 7 * k;
         xv[it] = xb[i];
         yv[it] = k < NN ? yr[k * 9 + c] : yre[c];
     }

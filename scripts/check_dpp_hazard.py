@@ -4,7 +4,9 @@ Rules (wait state = one issued VALU or SALU instruction, s_nop N = N + 1; LDS / 
   R1  VALU writes VGPR  -> DPP source (src0 of v_*_dpp) reads it          : 2 wait states   (informational: hipcc itself emits
       such pairs back to back on gfx950, so this is not a hazard there)
   R2  VALU writes VGPR  -> v_readlane / v_readfirstlane reads it          : 1 wait state    (REAL: measured with
-      scripts/probes/subst_probe.hip -- wrong, non-repeatable results; the exit code reflects this rule only)
+      scripts/probes/subst_probe.hip -- wrong, non-repeatable results; the exit code reflects this rule only.
+      v_writelane lane L -> v_readlane lane L back to back returns the OLD value 99 % of the time, a different lane is
+      safe: scripts/probes/wlane_probe.hip; hipcc's SGPR spill code uses exactly these two instructions)
   R3  VALU writes SGPR (v_readlane, v_cmp) -> VALU reads that SGPR        : 2 wait states   (informational: hipcc emits them)
 Usage: check_dpp_hazard.py file.s"""
 import re, sys
@@ -49,7 +51,22 @@ def count_hazards(path, verbose=False):
             if '_dpp' in op and len(args) >= 2:
                 src = vregs(args[1]); lookback(2, lambda k, vw, sw: k == 'valu' and vw & src, 1)
             if op.startswith(('v_readlane', 'v_readfirstlane')) and len(args) >= 2:
-                src = vregs(args[1]); lookback(1, lambda k, vw, sw: k == 'valu' and vw & src, 2)
+                src = vregs(args[1])
+                rl = args[2] if op.startswith('v_readlane') and len(args) >= 3 else None
+                def writes_what_is_read(k, vw, sw, txt):
+                    if not (k == 'valu' and vw & src): return False
+                    if txt.startswith('v_writelane') and rl is not None and rl.isdigit():
+                        wl = txt.split(',')[-1].split()[0].strip()
+                        if wl.isdigit() and wl != rl: return False       # another lane: measured safe (probes/wlane_probe.hip)
+                    return True
+                ws = 0
+                for kind, vw, sw, w, txt in reversed(hist[-12:]):
+                    if ws >= 1: break
+                    if writes_what_is_read(kind, vw, sw, txt):
+                        bad[2] += 1
+                        if verbose and bad[2] <= 8: print("R2: %-60s -> %s" % (txt, t))
+                        break
+                    ws += w
             ss = set()
             for a in args[1:]: ss |= sregs(a)
             if op.startswith('v_cndmask') and len(args) == 3: ss |= {'vcc'}

@@ -10,7 +10,7 @@ from ad_mpc_amd.engine import BatchSolver
 from ad_mpc_amd.scenarios import random_scenarios
 from oracle.oracle import Oracle
 o = Oracle(omp=True)
-for N, B in ((24, 2048), (40, 2048), (80, 2048)):
+for N, B in ((24, 512), (33, 512), (40, 2048), (45, 512), (64, 256), (80, 2048)):
     cfg = default_config(N=N); s = random_scenarios(B, N=N, seed=1234, blend=(3.0, 5.0))
     eng = BatchSolver(cfg, device=0); d = eng.to_device
     g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
