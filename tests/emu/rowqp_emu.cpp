@@ -1,0 +1,143 @@
+// rowqp_emu.cpp -- 16-lane emulator backend for ad_mpc_amd/csrc/rowqp_core.h.  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the product's own QP algorithm source (the text the gfx950 kernel is built from) for the host, one emulated
+// DPP row = one MPC instance, so that the CPU test suite (-m "not gpu") checks it against the oracle.  Loaded by tests/ only;
+// the product has no CPU path (ad_mpc_amd/_lib.py raises without the HIP library and a GPU).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../include/admpc.h"
+#include <cstdio>
+#include <cstdlib>
+#define RQ_DBG(...) do { if (getenv("EDBG")) fprintf(stderr, __VA_ARGS__); } while (0)
+#define RQ_FN inline
+#define RQ_UNROLL
+#define RQ_NOUNROLL
+#include "../../ad_mpc_amd/csrc/rowqp_core.h"
+
+namespace {
+constexpr int NL = 16;
+template <class T> struct EV { T v[NL]; };
+struct EI { int v[NL]; };
+struct EM { bool v[NL]; };
+
+#define EV_BIN(op) template <class T> inline EV<T> operator op(const EV<T>& a, const EV<T>& b) { EV<T> r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] op b.v[l]; return r; }
+EV_BIN(+) EV_BIN(-) EV_BIN(*) EV_BIN(/)
+template <class T> inline EV<T> operator-(const EV<T>& a) { EV<T> r; for (int l = 0; l < NL; ++l) r.v[l] = -a.v[l]; return r; }
+#define EV_CMP(op) template <class T> inline EM operator op(const EV<T>& a, const EV<T>& b) { EM r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] op b.v[l]; return r; }
+EV_CMP(<) EV_CMP(<=) EV_CMP(>) EV_CMP(>=) EV_CMP(==)
+#define EI_BIN(op) inline EI operator op(const EI& a, const EI& b) { EI r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] op b.v[l]; return r; } \
+                   inline EI operator op(const EI& a, int b) { EI r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] op b; return r; }
+EI_BIN(+) EI_BIN(-) EI_BIN(*) EI_BIN(>>) EI_BIN(&)
+#define EI_CMP(op) inline EM operator op(const EI& a, int b) { EM r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] op b; return r; } \
+                   inline EM operator op(const EI& a, const EI& b) { EM r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] op b.v[l]; return r; }
+EI_CMP(<) EI_CMP(<=) EI_CMP(>) EI_CMP(>=) EI_CMP(==)
+inline EM operator&(const EM& a, const EM& b) { EM r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] && b.v[l]; return r; }
+inline EM operator|(const EM& a, const EM& b) { EM r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l] || b.v[l]; return r; }
+inline EM operator!(const EM& a) { EM r; for (int l = 0; l < NL; ++l) r.v[l] = !a.v[l]; return r; }
+
+template <class T_>
+struct EmuX {
+    typedef T_ T;
+    typedef EV<T> V;
+    typedef EI I;
+    typedef EM M;
+    struct Lds { T* base; int size; };
+
+    static V splat(T x) { V r; for (int l = 0; l < NL; ++l) r.v[l] = x; return r; }
+    static I isplat(int x) { I r; for (int l = 0; l < NL; ++l) r.v[l] = x; return r; }
+    static I lane() { I r; for (int l = 0; l < NL; ++l) r.v[l] = l; return r; }
+    static M mtrue() { M r; for (int l = 0; l < NL; ++l) r.v[l] = true; return r; }
+    static M mfalse() { M r; for (int l = 0; l < NL; ++l) r.v[l] = false; return r; }
+    static M mfrom(bool b) { return b ? mtrue() : mfalse(); }
+    static V sel(const M& m, const V& a, const V& b) { V r; for (int l = 0; l < NL; ++l) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+    static I isel(const M& m, const I& a, const I& b) { I r; for (int l = 0; l < NL; ++l) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+    static V fma(const V& a, const V& b, const V& c) { V r; for (int l = 0; l < NL; ++l) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
+    static V rcp(const V& a) { V r; for (int l = 0; l < NL; ++l) r.v[l] = (T)1 / a.v[l]; return r; }
+    static V vabs(const V& a) { V r; for (int l = 0; l < NL; ++l) r.v[l] = std::fabs(a.v[l]); return r; }
+    static V vmax(const V& a, const V& b) { V r; for (int l = 0; l < NL; ++l) r.v[l] = std::fmax(a.v[l], b.v[l]); return r; }
+    static V vmin(const V& a, const V& b) { V r; for (int l = 0; l < NL; ++l) r.v[l] = std::fmin(a.v[l], b.v[l]); return r; }
+    static V vmaxnan(const V& a, const V& b) { V r; for (int l = 0; l < NL; ++l) r.v[l] = (b.v[l] > a.v[l] || b.v[l] != b.v[l]) ? b.v[l] : a.v[l]; return r; }
+    // memory
+    static void chk(const Lds& L, int o) { if (o < 0 || o >= L.size) __builtin_trap(); }
+    static V lds_ld(const Lds& L, const I& off, int imm) { V r; for (int l = 0; l < NL; ++l) { chk(L, off.v[l] + imm); r.v[l] = L.base[off.v[l] + imm]; } return r; }
+    static void lds_st(const Lds& L, const I& off, int imm, const V& v, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) { chk(L, off.v[l] + imm); L.base[off.v[l] + imm] = v.v[l]; } }
+    static void lds_ld2(const Lds& L, const I& off, int imm, V& a, V& b) { a = lds_ld(L, off, imm); b = lds_ld(L, off, imm + 1); }
+    static void lds_st2(const Lds& L, const I& off, int imm, const V& a, const V& b, const M& m) { lds_st(L, off, imm, a, m); lds_st(L, off, imm + 1, b, m); }
+    static void lds_fence() {}
+    static V gld(const T* p, const I& off) { V r; for (int l = 0; l < NL; ++l) r.v[l] = p[off.v[l]]; return r; }
+    static void gld6(const T* p, const I& off, V out[6]) { for (int i = 0; i < 6; ++i) for (int l = 0; l < NL; ++l) out[i].v[l] = p[off.v[l] + i]; }
+    static void gst(T* p, const I& off, const V& v, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) p[off.v[l]] = v.v[l]; }
+    // cross-lane
+    template <int L> static V bc(const V& a) { return splat(a.v[L]); }
+    static V swap1(const V& a) { V r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l ^ 1]; return r; }
+    template <int n, int L0> static void dotbc(const V* coef, const V& src, V& acc) {
+        for (int i = 0; i < n; ++i) for (int l = 0; l < NL; ++l) acc.v[l] = std::fma(src.v[L0 + i], coef[i].v[l], acc.v[l]);
+    }
+    static void pg(const V P[7], const V G7[7], V Mm[7]) {           // M[i] = sum_l P[i]{lane l} * G[l]
+        for (int i = 0; i < 7; ++i) { Mm[i] = splat((T)0); for (int l = 0; l < 7; ++l) for (int c = 0; c < NL; ++c) Mm[i].v[c] = std::fma(P[i].v[l], G7[l].v[c], Mm[i].v[c]); }
+    }
+    static void gtm(const V Gc[6], const V Mm[7], T h, V H[9]) {     // H[r] = sum_l G[l]{lane r} * M[l] ; structural row 6
+        H[0] = Mm[0]; H[1] = Mm[1];
+        for (int r = 2; r < 9; ++r) {
+            H[r] = splat((T)0);
+            for (int l = 0; l < 6; ++l) for (int c = 0; c < NL; ++c) H[r].v[c] = std::fma(Gc[l].v[r], Mm[l].v[c], H[r].v[c]);
+            if (r == 6) H[r] = H[r] + Mm[6];
+            if (r == 8) for (int c = 0; c < NL; ++c) H[r].v[c] = std::fma(h, Mm[6].v[c], H[r].v[c]);
+        }
+    }
+    static void schur(V H[9], const V& K0, const V& K1) {
+        for (int i = 0; i < 7; ++i) {
+            const T a = H[i].v[7], b = H[i].v[8];
+            for (int c = 0; c < NL; ++c) H[i].v[c] = std::fma(b, K1.v[c], std::fma(a, K0.v[c], H[i].v[c]));
+        }
+    }
+    static V row_sum(const V& a) { T s = 0; for (int l = 0; l < NL; ++l) s += a.v[l]; return splat(s); }
+    static V row_max(const V& a) { T s = a.v[0]; for (int l = 1; l < NL; ++l) s = std::fmax(s, a.v[l]); return splat(s); }
+    static V row_maxnan(const V& a) { T s = a.v[0]; for (int l = 1; l < NL; ++l) s = (a.v[l] > s || a.v[l] != a.v[l]) ? a.v[l] : s; return splat(s); }
+    static M row_and(const M& a) { bool s = true; for (int l = 0; l < NL; ++l) s = s && a.v[l]; return mfrom(s); }
+    static M row_or(const M& a) { bool s = false; for (int l = 0; l < NL; ++l) s = s || a.v[l]; return mfrom(s); }
+    static double at(const V& a, int l) { return (double)a.v[l]; }
+    static double first(const V& a) { return (double)a.v[0]; }
+    static bool any(const M& a) { for (int l = 0; l < NL; ++l) if (a.v[l]) return true; return false; }
+};
+
+template <class T>
+int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T* yref_e, const T* GT, const T* bl,
+              T* xbar, T* ubar, T* cost, int32_t* status, int32_t* iters, T* pi, T* rmax)
+{
+    typedef EmuX<T> X;
+    const int N = cfg->N;
+    RqParams<T> q; rq_make_params<T>(*cfg, q);
+    std::vector<T> lds((size_t)(N + 1) * RQ_RS);
+    for (int b = 0; b < B; ++b) {
+        for (auto& v : lds) v = std::nan("");                    // any read of an unwritten slot that matters shows up
+        RqRow<T> io;
+        io.x0 = x0 + (size_t)b * 7; io.yref = yref + (size_t)b * N * 9; io.yref_e = yref_e + (size_t)b * 7;
+        io.GT = GT + (size_t)b * N * RQ_GTS; io.bl = bl + (size_t)b * N * 7;
+        io.xbar = xbar + (size_t)b * (N + 1) * 7; io.ubar = ubar + (size_t)b * N * 2;
+        typename X::Lds L{lds.data(), (int)lds.size()};
+        RowQp<X> S(q, io, L);
+        typename RowQp<X>::Result res;
+        S.solve(X::mtrue(), res, pi ? pi + (size_t)b * N * 7 : nullptr);
+        typename X::M failed = res.failed;
+        typename X::V J;
+        S.finish(X::mtrue(), failed, J);
+        status[b] = failed.v[0] ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+        iters[b] = res.iters.v[0];
+        cost[b] = failed.v[0] ? (T)INFINITY : J.v[0];
+        if (rmax) rmax[b] = res.rmax.v[0];
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+int rowqp_emu_solve_f64(const AdmpcConfig* cfg, int B, const double* x0, const double* yref, const double* yref_e, const double* GT,
+                        const double* bl, double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, double* pi, double* rmax)
+{ return emu_solve<double>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, rmax); }
+int rowqp_emu_solve_f32(const AdmpcConfig* cfg, int B, const float* x0, const float* yref, const float* yref_e, const float* GT,
+                        const float* bl, float* xbar, float* ubar, float* cost, int32_t* status, int32_t* iters, float* pi, float* rmax)
+{ return emu_solve<float>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, rmax); }
+}
