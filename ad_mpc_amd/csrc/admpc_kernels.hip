@@ -1,26 +1,21 @@
-// admpc_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched AD-MPC solve engine.
+// admpc_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the batched AD-MPC solve engine, main translation unit.
 //
-// Two kernels per SQP step:
+// One SQP step:
 //   A  admpc_linearize_kernel  one thread per (instance, stage, sensitivity-column group): ERK4 + forward
-//                              sensitivities, writes the packed stage linearisation (42+7 doubles per stage)
-//   B  admpc_qp_kernel         one MPC instance per 64-lane wavefront (workgroup = 1 wave): all per-stage data
-//                              of the instance lives in LDS (~20 KB at N=20 -> 8 instances per CU), the
-//                              per-constraint interior-point state lives in registers.
+//                              sensitivities, writes the packed stage linearisation (42+7 values per stage)
+//   then the QP of the step (H2-H6), one of
+//   R  admpc_rowqp_kernel      (admpc_rowqp.hip) stage-wise Riccati interior point, one instance per 16-lane DPP row:
+//                              every horizon, fp64 and fp32
+//   C, D, E                    condensed pipeline for N = 20 fp64 (the reference's own QP strategy): condensing, dense
+//                              LDL' interior point, expansion
 //
 // Hot path restated (reference = data_driven_mpc/ros_gp_mpc/src/ad_mpc/...):
 //   H0/H1  model + ERK4 with forward sensitivities   ad_3d_optimizer.py:280-310, acados ERK
 //                                                     (acados_solver_sim_car.c:655-665)
 //   H2/H3  Gauss-Newton LS cost, soft/hard bounds     ad_3d_optimizer.py:146-199
-//   H4/H5  QP solve: stage-wise Riccati factorisation inside a Mehrotra predictor-corrector
-//          primal-dual IPM (reference: full condensing + HPIPM, acados_solver_sim_car.c:145,688-692;
-//          same unique minimiser)
+//   H4/H5  QP solve: Mehrotra predictor-corrector primal-dual IPM (reference: full condensing + HPIPM,
+//          acados_solver_sim_car.c:145,688-692; same unique minimiser)
 //   H6     full step update of the iterate            acados_solver_sim_car.c:647-648,677
-//
-// Lane roles (N = horizon):
-//   shooting      task t=3k+g  -> stage k, sensitivity column group g in {x-cols 2..4, x-cols 5..6, u-cols}
-//   u-constraint  set  s=2k+j  -> soft box on input j of stage k (4 inequalities), UPL sets per lane
-//   d-constraint  stage k      -> hard box on delta (state 6), stages 1..N-1
-//   Riccati       lane l<63    -> matrix entry (l/9,l%9) / (l/7,l%7) of the 7x9 / 9x7 stage products
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
@@ -249,7 +244,6 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
 #define KLS 17           // K0[7] K1[7] i00 i01 i11
 #define LIN_BLOCK 64     // threads per block of the linearisation kernel: single waves balance best over the CUs (256 registers each)
 #define LIN_TASKS 63     // tasks per block (multiple of 3)
-#ifndef ADMPC_TU_RICCATI
 // work scheduler of the condensed path (int array): [0] ticket counter, [64 + q] number of instances in effort bucket q,
 // [SCHED_HDR + q * cap + j] j-th instance of bucket q.  Zeroed by the linearisation kernel, filled by the condensing kernel,
 // drained (highest bucket first) by the persistent interior-point waves.
@@ -291,8 +285,6 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
     }
 }
 
-#endif  // !ADMPC_TU_RICCATI
-
 // ---------------------------------------------------------------------------------------------
 // wave-level primitives
 // ---------------------------------------------------------------------------------------------
@@ -324,37 +316,6 @@ __device__ __forceinline__ double wave_reduce(double v) {
     return rdlane(v, 63);
 }
 
-// ---------------------------------------------------------------------------------------------
-// kernel B: the QP of one RTI step, one instance per wavefront.
-// LDS map (doubles): see lds2_doubles(); per-stage arrays of the instance + three transients.
-// ---------------------------------------------------------------------------------------------
-struct Lds2 {
-    double *GT;    // [N][7][6]   packed linearisation
-    double *Pk;    // [N][28]     packed symmetric P_k, k = 1..N at slot k-1
-    double *KL;    // [N][17]     feedback gains + inverse of Huu
-    double *pi;    // [N][7]      multipliers of the dynamics
-    double *gx;    // [N][7]      state stationarity residual / modified gradient of stage k = 1..N at slot k-1
-    double *pv;    // [N][7]      Riccati gradient p_k, k = 1..N at slot k-1
-    double *ddx;   // [N][7]      Newton step ddx_k, k = 1..N at slot k-1 (ddx_0 = 0); also b_k during the start-up roll-out
-    double *guk;   // [N][2]      gu -> kff -> ddu (each overwrites the previous in place)
-    double *Rt;    // [N][2]
-    double *Qt;    // [N]
-    double *Pf;    // [7][8]      transient: full P_{k+1}
-    double *MT;    // [7][8]      transient: (P_{k+1} [A B])^T, stored columns
-    double *Hs;    // [81]        transient: 9x9 stage Hessian
-    double *hs;    // [10]        transient: 9 stage gradient entries
-    double *pvs;   // [8]         transient: p_{k+1}
-};
-// Hs/hs/pvs (100 doubles) are only live inside the factor sweep, when the ddx slots are dead: aliased if they fit
-__host__ __device__ inline int lds2_doubles(int N) { return N * (GTS + PKS + KLS + 7 * 4 + 2 + 2 + 1) + 56 + 56 + (N * 7 >= 100 ? 0 : 100); }
-__device__ __forceinline__ void lds2_carve(double* p, int N, Lds2& L) {
-    L.GT = p; p += N * GTS;  L.Pk = p; p += N * PKS;  L.Pf = p; p += 56;  L.MT = p; p += 56;
-    L.KL = p; p += N * KLS;  L.pi = p; p += N * 7;    L.gx = p; p += N * 7;  L.pv = p; p += N * 7;  L.ddx = p; p += N * 7;
-    L.guk = p; p += N * 2;   L.Rt = p; p += N * 2;    L.Qt = p; p += N;
-    double* tr = N * 7 >= 100 ? L.ddx : p;
-    L.Hs = tr; L.hs = tr + 82; L.pvs = tr + 92;
-}
-
 // A workgroup is ONE wavefront.  WSYNC orders a cross-lane exchange through LDS (write, WSYNC, read).
 #ifdef ADMPC_WSYNC_FENCE_ONLY
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -366,737 +327,6 @@ __device__ __forceinline__ void lds2_carve(double* p, int N, Lds2& L) {
 // cannot select the 16-bit udivrem by 7 at -Oz ("Cannot select: i16 udivrem"); there is no `/ 7` or `% 7` on the device.
 __device__ __forceinline__ int div7(int x) { return (int)(((unsigned)x * 9363u) >> 16); }
 
-__device__ __forceinline__ int tri_index(int i, int j) {   // packed index of (i<=j) in a 7x7 upper triangle, row-major
-    return i * 7 - (i * (i - 1)) / 2 + (j - i);
-}
-
-// select a[i] with constant indices only (runtime-indexed private arrays would be placed in scratch memory)
-__device__ __forceinline__ double sel7(const double* a, int i) {
-    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : i == 4 ? a[4] : i == 5 ? a[5] : a[6];
-}
-
-#ifndef ADMPC_TU_MAIN      // ---- the stage-wise Riccati path: its own translation unit when the library is built in two (Makefile)
-struct Roles {       // stage-independent lane roles of the Riccati factorisation
-    int i1, c1;      // L1: M^T[c1][i1], lanes < 49
-    double r6_1;     // implicit row 6 of stored column c1
-    int r2, c2;      // L2: unique entry (r2 <= c2) of the 9x9 H, lanes < 45
-    int altoff;      // L2: offset of the copied value when r2 < 2 (relative to Pf if c2 < 2 else MT)
-    double r6_2;
-    int i3, j3;      // L3: P entry, lanes < 49
-    int pkoff;       // packed offset of (i3,j3) if i3 <= j3 else -1
-    double qd2;      // L2: constant state weight on the diagonal entry (r2 == c2 < 7)
-    double qe3;      // terminal weight of the diagonal entry (i3 == j3), else 0
-};
-
-__device__ __forceinline__ double r6_of(int c, double h) { return c == 4 ? 1.0 : (c == 6 ? h : 0.0); }
-
-__device__ __forceinline__ void make_roles(int lane, double h, const double* Qd, const double* Qe, Roles& R) {
-    R.i1 = div7(lane); R.c1 = lane - 7 * R.i1;
-    if (lane >= 49) { R.i1 = 0; R.c1 = 0; }
-    R.r6_1 = r6_of(R.c1, h);
-    int t = lane < 45 ? lane : 0, r = 0;
-#pragma unroll
-    for (int rr = 0; rr < 9; ++rr) { const int len = 9 - rr; if (t >= len && r == rr) { t -= len; r = rr + 1; } }
-    R.r2 = r; R.c2 = r + t;
-    R.altoff = R.c2 < 2 ? R.r2 * 8 + R.c2 : (R.c2 - 2) * 8 + R.r2;
-    R.r6_2 = r6_of(R.r2 >= 2 ? R.r2 - 2 : 0, h);
-    R.i3 = R.i1; R.j3 = lane < 49 ? R.c1 : 0;
-    R.pkoff = (lane < 49 && R.i3 <= R.j3) ? tri_index(R.i3, R.j3) : -1;
-    R.qd2 = sel7(Qd, R.r2 < 7 ? R.r2 : 0);
-    R.qe3 = R.i3 == R.j3 ? sel7(Qe, R.i3) : 0.0;
-}
-
-// Backward Riccati sweep for the matrices, fused with the backward sweep of the gradient for the
-// predictor right-hand side (gx, guk=gu).  Leaves Pk, KL, pv, kff (in guk).
-__device__ __forceinline__ void riccati_factor_fused(const Lds2& L, int N, int lane, const Roles& R)
-{
-    if (lane < 49) L.Pf[R.i3 * 8 + R.j3] = R.qe3;
-    if (lane < NX) L.pvs[lane] = L.gx[(N - 1) * 7 + lane];
-    if (lane < 49 && R.pkoff >= 0) L.Pk[(N - 1) * PKS + R.pkoff] = R.qe3;
-    if (lane < NX) L.pv[(N - 1) * 7 + lane] = L.gx[(N - 1) * 7 + lane];
-    WSYNC();
-#pragma unroll 1
-    for (int k = N - 1; k >= 0; --k) {
-        const double* GT = L.GT + k * GTS;
-        // ---- L1: M^T[c][i] = P+[i][:] . G[:,c]   (+ gradient h for the fused predictor sweep)
-        {
-            const double* prow = L.Pf + R.i1 * 8;
-            const double* gcol = GT + R.c1 * 6;
-            double m = prow[6] * R.r6_1;
-#pragma unroll
-            for (int l = 0; l < 6; ++l) m += prow[l] * gcol[l];
-            if (lane < 49) L.MT[R.c1 * 8 + R.i1] = m;
-            // h: lanes 0..6 -> entry c+2 (their own stored column), lanes 49,50 -> entries 0,1
-            double hv = L.pvs[6] * R.r6_1;
-#pragma unroll
-            for (int l = 0; l < 6; ++l) hv += gcol[l] * L.pvs[l];
-            if (lane < 7) {
-                const double g = lane < 5 ? (k >= 1 ? L.gx[(k - 1) * 7 + lane + 2] : 0.0) : L.guk[k * 2 + lane - 5];
-                L.hs[lane + 2] = hv + g;
-            } else if (lane == 49 || lane == 50) {
-                const int a = lane - 49;
-                L.hs[a] = (k >= 1 ? L.gx[(k - 1) * 7 + a] : 0.0) + L.pvs[a];
-            }
-        }
-        WSYNC();
-        // ---- L2: unique entries of H = [A B]' M + diag
-        if (lane < 45) {
-            const int rc = R.r2 >= 2 ? R.r2 - 2 : 0, cc = R.c2 >= 2 ? R.c2 - 2 : 0;
-            const double* gcol = GT + rc * 6;
-            const double* mcol = L.MT + cc * 8;
-            double hv = mcol[6] * R.r6_2;
-#pragma unroll
-            for (int l = 0; l < 6; ++l) hv += gcol[l] * mcol[l];
-            const double alt = (R.c2 < 2 ? L.Pf : L.MT)[R.altoff];
-            if (R.r2 < 2) hv = alt;
-            if (R.r2 == R.c2) {
-                double dg;
-                if (R.r2 < 7) dg = (R.r2 == 6 && k >= 1) ? L.Qt[k] : R.qd2;
-                else dg = L.Rt[k * 2 + R.r2 - 7];
-                hv += dg;
-            }
-            L.Hs[R.r2 * 9 + R.c2] = hv;
-            L.Hs[R.c2 * 9 + R.r2] = hv;
-        }
-        WSYNC();
-        // ---- L3: Schur complement, gains, gradient
-        {
-            const double h00 = L.Hs[70], h01 = L.Hs[71], h11 = L.Hs[80];
-            const double idet = 1.0 / (h00 * h11 - h01 * h01);
-            const double i00 = h11 * idet, i01 = -h01 * idet, i11 = h00 * idet;
-            const double hu0 = L.hs[7], hu1 = L.hs[8];
-            if (lane < 49) {
-                const double h0i = L.Hs[63 + R.i3], h1i = L.Hs[72 + R.i3], h0j = L.Hs[63 + R.j3], h1j = L.Hs[72 + R.j3];
-                // symmetric evaluation of Hxu Huu^-1 Hux (bitwise identical for (i,j) and (j,i))
-                const double cross = __dadd_rn(__dmul_rn(h0i, h1j), __dmul_rn(h1i, h0j));
-                const double s = __dadd_rn(__dadd_rn(__dmul_rn(i00, __dmul_rn(h0i, h0j)), __dmul_rn(i01, cross)), __dmul_rn(i11, __dmul_rn(h1i, h1j)));
-                const double pij = L.Hs[R.i3 * 9 + R.j3] - s;
-                L.Pf[R.i3 * 8 + R.j3] = pij;
-                if (R.pkoff >= 0 && k >= 1) L.Pk[(k - 1) * PKS + R.pkoff] = pij;
-                if (R.i3 == 0) {
-                    const double K0 = -(i00 * h0j + i01 * h1j), K1 = -(i01 * h0j + i11 * h1j);
-                    L.KL[k * KLS + R.j3] = K0; L.KL[k * KLS + 7 + R.j3] = K1;
-                    const double pvk = L.hs[R.j3] + K0 * hu0 + K1 * hu1;
-                    L.pvs[R.j3] = pvk;
-                    if (k >= 1) L.pv[(k - 1) * 7 + R.j3] = pvk;
-                }
-            }
-            if (lane == 63) {
-                L.KL[k * KLS + 14] = i00; L.KL[k * KLS + 15] = i01; L.KL[k * KLS + 16] = i11;
-                L.guk[k * 2 + 0] = -(i00 * hu0 + i01 * hu1);
-                L.guk[k * 2 + 1] = -(i01 * hu0 + i11 * hu1);
-            }
-        }
-        WSYNC();
-    }
-}
-
-// Backward sweep of the gradient alone (corrector right-hand side); p_k travels in registers of lanes 0..6.
-__device__ __forceinline__ void riccati_backward2(const Lds2& L, int N, int lane, double h)
-{
-    double pvv = lane < NX ? L.gx[(N - 1) * 7 + lane] : 0.0;
-    if (lane < NX) L.pv[(N - 1) * 7 + lane] = pvv;
-    const int c = lane >= 2 && lane < 9 ? lane - 2 : 0;       // lanes 2..8 own stored column c, lanes 0,1 the unit columns
-    const double r6 = r6_of(c, h);
-#pragma unroll 1
-    for (int k = N - 1; k >= 0; --k) {
-        const double* gcol = L.GT + k * GTS + c * 6;
-        double g = 0.0;
-        if (lane < 7) g = k >= 1 ? L.gx[(k - 1) * 7 + lane] : 0.0; else if (lane < 9) g = L.guk[k * 2 + lane - 7];
-        const double K0 = lane < 7 ? L.KL[k * KLS + lane] : 0.0, K1 = lane < 7 ? L.KL[k * KLS + 7 + lane] : 0.0;
-        const double i00 = L.KL[k * KLS + 14], i01 = L.KL[k * KLS + 15], i11 = L.KL[k * KLS + 16];
-        const double g0 = gcol[0], g1 = gcol[1], g2 = gcol[2], g3 = gcol[3], g4 = gcol[4], g5 = gcol[5];
-        const double p0 = rdlane(pvv, 0), p1 = rdlane(pvv, 1), p2 = rdlane(pvv, 2), p3 = rdlane(pvv, 3),
-                     p4 = rdlane(pvv, 4), p5 = rdlane(pvv, 5), p6 = rdlane(pvv, 6);
-        double hv = g + (g0 * p0 + g1 * p1) + (g2 * p2 + g3 * p3) + (g4 * p4 + g5 * p5) + r6 * p6;
-        if (lane < 2) hv = g + (lane == 0 ? p0 : p1);
-        const double hu0 = rdlane(hv, 7), hu1 = rdlane(hv, 8);
-        pvv = lane < NX ? hv + K0 * hu0 + K1 * hu1 : 0.0;
-        if (lane < NX && k >= 1) L.pv[(k - 1) * 7 + lane] = pvv;
-        if (lane == 63) {
-            L.guk[k * 2 + 0] = -(i00 * hu0 + i01 * hu1);
-            L.guk[k * 2 + 1] = -(i01 * hu0 + i11 * hu1);
-        }
-    }
-}
-
-// Forward roll-out of the Newton step: ddu_k = K_k ddx_k + kff_k, ddx_{k+1} = A ddx_k + B ddu_k (+ b_k at start-up).
-// ddx travels in registers of lanes 0..6.  WITH_B: start-up roll-out with du = 0 (writes dx into pv slots).
-template <bool STARTUP>
-__device__ __forceinline__ void riccati_forward2(const Lds2& L, int N, int lane, double h, double dx0)
-{
-    double dxv = STARTUP ? dx0 : 0.0;           // lanes 0..6
-    const int li = lane < 6 ? lane : 0;
-#pragma unroll 1
-    for (int k = 0; k < N; ++k) {
-        const double* GT = L.GT + k * GTS;
-        const double a2 = GT[0 * 6 + li], a3 = GT[1 * 6 + li], a4 = GT[2 * 6 + li], a5 = GT[3 * 6 + li], a6 = GT[4 * 6 + li];
-        const double d0 = rdlane(dxv, 0), d1 = rdlane(dxv, 1), d2 = rdlane(dxv, 2), d3 = rdlane(dxv, 3),
-                     d4 = rdlane(dxv, 4), d5 = rdlane(dxv, 5), d6 = rdlane(dxv, 6);
-        double part = (a2 * d2 + a3 * d3) + (a4 * d4 + a5 * d5) + a6 * d6;
-        part += lane == 0 ? d0 : (lane == 1 ? d1 : 0.0);
-        if (STARTUP) {
-            const double bk = lane < NX ? L.ddx[k * 7 + lane] : 0.0;
-            dxv = lane < 6 ? part + bk : (lane == 6 ? d6 + bk : 0.0);
-            if (lane < NX) L.pv[k * 7 + lane] = dxv;            // dx_{k+1}
-        } else {
-            const double b0 = GT[5 * 6 + li], b1 = GT[6 * 6 + li];
-            double du = 0.0;
-            if (lane < 2) {
-                const double* Kr = L.KL + k * KLS + lane * 7;
-                du = L.guk[k * 2 + lane] + (Kr[0] * d0 + Kr[1] * d1) + (Kr[2] * d2 + Kr[3] * d3) + (Kr[4] * d4 + Kr[5] * d5) + Kr[6] * d6;
-            }
-            const double du0 = rdlane(du, 0), du1 = rdlane(du, 1);
-            if (lane < 2) L.guk[k * 2 + lane] = du;              // ddu_k overwrites kff_k
-            dxv = lane < 6 ? part + b0 * du0 + b1 * du1 : (lane == 6 ? d6 + h * du1 : 0.0);
-            if (lane < NX) L.ddx[k * 7 + lane] = dxv;           // ddx_{k+1}
-        }
-    }
-}
-
-struct USet2 {     // soft box on one input: 0 lower, 1 upper, 2 sl>=0, 3 su>=0
-    double t[4], lam[4], du, sl, su, dl, duu, r;
-    double it[4], il[4], iG02, iG13;               // reciprocals, refreshed once per iteration
-    double rc[4], ru, dt[4], dlam[4], dsl, dsu;
-    // primal residuals of the four inequalities and of the slack stationarity are cheap: recomputed where needed
-    __device__ __forceinline__ double rd0() const { return du + sl - dl - t[0]; }
-    __device__ __forceinline__ double rd1() const { return -du + su + duu - t[1]; }
-    __device__ __forceinline__ double rd2() const { return sl - t[2]; }
-    __device__ __forceinline__ double rd3() const { return su - t[3]; }
-};
-struct DSet2 {     // hard box on delta of one stage
-    double t[2], lam[2], dl, du, dx6, rx6;
-    double it[2], il[2], rc[2], dt[2], dlam[2];
-    __device__ __forceinline__ double rd0() const { return dx6 - dl - t[0]; }
-    __device__ __forceinline__ double rd1() const { return du - dx6 - t[1]; }
-};
-struct XTask {     // one state entry (k,i), k = 1..N
-    double q0, dx, w;   // q0 = w*(xbar - xref): gradient of the GN model at the iterate; w: Ts*q_i (terminal W_e for k = N)
-    int k, i;           // k = 0 marks an unused slot
-};
-
-template <int UPL, int TPL, int DPL, int NT>     // DPL: delta-box stages per lane; NT > 0: horizon known at compile time (all LDS offsets fold to constants)
-// One wave per SIMD (512-register budget): at 256 registers the kernel spills ~200 VGPRs to scratch, and
-// back-to-back launches of kernels with large private segments aborted inside the runtime.
-__global__ __launch_bounds__(WAVE) void admpc_qp_kernel(const AdmpcConfig* __restrict__ cfg, int B,
-                                                        const double* __restrict__ x0g, const double* __restrict__ yrefg,
-                                                        const double* __restrict__ yrefeg,
-                                                        const double* __restrict__ GTg, const double* __restrict__ blg,
-                                                        double* __restrict__ xbarg, double* __restrict__ ubarg,
-                                                        double* __restrict__ costg, int32_t* __restrict__ statusg,
-                                                        int32_t* __restrict__ itersg, int first_pass, int* __restrict__ ticket)
-{
-    extern __shared__ double lds_raw[];
-    const int lane = threadIdx.x;
-    const int N = NT > 0 ? NT : cfg->N;
-    Lds2 L;
-    lds2_carve(lds_raw, N, L);
-    const double Ts = cfg->Ts;
-    double Qd[NX], Qe[NX], Rd[NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cfg->W[i]; Qe[i] = cfg->We[i]; }
-#pragma unroll
-    for (int j = 0; j < NU; ++j) Rd[j] = Ts * cfg->W[NX + j];
-    const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
-    const double thr = cfg->ipm_thr0, mu0 = cfg->ipm_mu0;
-    const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
-    const int itmax = cfg->ipm_iter_max;
-    const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
-    const double thw = cfg->ipm_warm_thr;
-    const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
-    const int nu_sets = 2 * N;
-    Roles R;
-    make_roles(lane, Ts, Qd, Qe, R);
-
-    // Instances need 0 .. 20 interior-point iterations each: the waves draw them from a counter (zeroed by the linearisation
-    // kernel) instead of striding over the batch, so that no wave is left with a run of expensive ones.
-    auto next_instance = [&]() __attribute__((always_inline)) -> int {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(ticket, 1);
-        return (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
-    };
-    for (int inst = blockIdx.x; inst < B; inst = next_instance()) {
-        if (!first_pass && statusg[inst] != 0) continue;          // failed in an earlier SQP step: leave untouched
-        const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
-        const double* ubg = ubarg + (size_t)inst * N * NU;
-        const double* yrg = yrefg + (size_t)inst * N * NY;
-        // ---- stage the linearisation (coalesced), defects into the ddx slots
-        {
-            const double* gt = GTg + (size_t)inst * N * GTS;
-            const double* bl = blg + (size_t)inst * N * NX;
-            for (int i = lane; i < N * GTS; i += WAVE) L.GT[i] = gt[i];
-            for (int i = lane; i < N * NX; i += WAVE) L.ddx[i] = bl[i];
-            for (int i = lane; i < N * NX; i += WAVE) L.pi[i] = 0.0;
-        }
-        // ---- per-lane problem data
-        XTask T[TPL];
-#pragma unroll
-        for (int m = 0; m < TPL; ++m) {
-            const int t = lane + WAVE * m;
-            const bool on = t < N * 7;
-            const int tt = on ? t : 0;
-            int ttl = tt; asm volatile("" : "+v"(ttl));          // opaque: keeps the index arithmetic in 32 bits (see div7)
-            const int kq = div7(ttl);
-            const int k = kq + 1, i = ttl - 7 * kq;
-            T[m].k = on ? k : 0; T[m].i = i;
-            T[m].w = k < N ? sel7(Qd, i) : sel7(Qe, i);
-            T[m].q0 = T[m].w * (xbg[7 + tt] - (k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i]));
-            T[m].dx = 0.0;
-        }
-        USet2 U[UPL];
-#pragma unroll
-        for (int m = 0; m < UPL; ++m) {
-            const int sid = lane + WAVE * m;
-            const int sc = sid < nu_sets ? sid : 0;
-            const int k = sc >> 1, j = sc & 1;
-            const double ub = ubg[sc];
-            U[m].dl = cfg->lbu[j] - ub; U[m].duu = cfg->ubu[j] - ub;
-            U[m].r = (j ? Rd[1] : Rd[0]) * (ub - yrg[k * 9 + 7 + j]);
-            U[m].du = 0.0; U[m].sl = thr; U[m].su = thr;
-            const double r0[4] = { thr - U[m].dl, thr + U[m].duu, thr, thr };
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { U[m].t[i] = r0[i] > thr ? r0[i] : thr; U[m].lam[i] = mu0 / U[m].t[i]; }
-            // every field defined from the start: the slots beyond 2N inputs never receive a step, and an undefined value must not
-            // reach the arithmetic below even where its result is discarded
-            U[m].ru = 0.0; U[m].dsl = 0.0; U[m].dsu = 0.0; U[m].iG02 = 0.0; U[m].iG13 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { U[m].it[i] = 0.0; U[m].il[i] = 0.0; U[m].rc[i] = 0.0; U[m].dt[i] = 0.0; U[m].dlam[i] = 0.0; }
-        }
-        DSet2 Dv[DPL];
-#define DSET_LOOP _Pragma("unroll") for (int md = 0; md < DPL; ++md)
-#define DSET_BIND DSet2& D = Dv[md]; const int dk = lane + WAVE * md; const bool dact = dk >= 1 && dk < N; (void)dact; (void)dk;
-        DSET_LOOP {
-            DSET_BIND
-            const double x6 = xbg[(dact ? dk : 0) * 7 + 6];
-            D.dl = cfg->lbx_delta - x6; D.du = cfg->ubx_delta - x6;
-            D.dx6 = 0.0; D.rx6 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { D.t[i] = 1.0; D.lam[i] = 0.0; D.it[i] = 0.0; D.il[i] = 0.0; D.rc[i] = 0.0; D.dt[i] = 0.0; D.dlam[i] = 0.0; }
-        }
-        const double dx0 = lane < NX ? x0g[(size_t)inst * NX + lane] - xbg[lane] : 0.0;
-        WSYNC();
-        // ---- start-up: du = 0, states rolled out through the linearised dynamics (dx_{k+1} into pv slots)
-        riccati_forward2<true>(L, N, lane, Ts, dx0);
-        WSYNC();
-#pragma unroll
-        for (int m = 0; m < TPL; ++m) if (T[m].k) T[m].dx = L.pv[(T[m].k - 1) * 7 + T[m].i];
-        DSET_LOOP {
-            DSET_BIND
-            D.dx6 = dact ? L.pv[(dk - 1) * 7 + 6] : 0.0;
-            D.t[0] = D.t[1] = 1.0; D.lam[0] = D.lam[1] = 0.0; D.rx6 = 0.0;
-            if (dact) {
-                const double r0[2] = { D.dx6 - D.dl, D.du - D.dx6 };
-#pragma unroll
-                for (int i = 0; i < 2; ++i) { D.t[i] = r0[i] > thr ? r0[i] : thr; D.lam[i] = mu0 / D.t[i]; }
-            }
-        }
-        WSYNC();
-
-        bool failed = false;
-        double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
-        int it = 0;
-        // ---- trial: the QP without its inequalities (cfg.ipm_try_unconstrained).  One Riccati factorisation with the plain
-        //      weights and one solve from the start point (du = 0, rolled-out dx, pi = 0) give its exact minimiser; if that
-        //      respects the input box and the steering box it is the solution of the full QP and the interior point is skipped
-        //      (iters = 0).  Same rule as the oracle and the condensed N = 20 path.
-        bool solved = false;
-        if (try_unc) {
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                const int sid = lane + WAVE * m;
-                if (sid < nu_sets) { L.Rt[sid] = (sid & 1) ? Rd[1] : Rd[0]; L.guk[sid] = U[m].r; }
-            }
-            DSET_LOOP {
-                DSET_BIND
-                (void)D;
-                if (dact) L.Qt[dk] = Qd[6];
-            }
-#pragma unroll
-            for (int m = 0; m < TPL; ++m) if (T[m].k) L.gx[(T[m].k - 1) * 7 + T[m].i] = T[m].w * T[m].dx + T[m].q0;
-            WSYNC();
-            riccati_factor_fused(L, N, lane, R);
-            riccati_forward2<false>(L, N, lane, Ts, 0.0);
-            WSYNC();
-            bool ok = true;
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                const int sid = lane + WAVE * m;
-                if (sid < nu_sets) { const double u = L.guk[sid]; ok = ok && (u >= U[m].dl && u <= U[m].duu); }
-            }
-            DSET_LOOP {
-                DSET_BIND
-                if (dact) { const double v = D.dx6 + L.ddx[(dk - 1) * 7 + 6]; ok = ok && (v >= D.dl && v <= D.du); }
-            }
-            if (__all(ok)) {
-                solved = true;
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) { const int sid = lane + WAVE * m; if (sid < nu_sets) U[m].du = L.guk[sid]; }
-#pragma unroll
-                for (int m = 0; m < TPL; ++m) if (T[m].k) T[m].dx += L.ddx[(T[m].k - 1) * 7 + T[m].i];
-            } else if (thw > 0.0) {
-                // warm start (cfg.ipm_warm_thr): the interior point starts from that minimiser -- its inputs, states and dynamics
-                // multipliers; a violated input bound is absorbed by its slack, a violated steering bound stays as a residual
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) {
-                    const int sid = lane + WAVE * m;
-                    if (sid < nu_sets) {
-                        USet2& s = U[m];
-                        const double v = L.guk[sid];
-                        s.du = v;
-                        s.sl = fmax(s.dl - v, 0.0) + thw; s.su = fmax(v - s.duu, 0.0) + thw;
-                        const double r0[4] = { v + s.sl - s.dl, s.su + s.duu - v, s.sl, s.su };
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { s.t[i] = r0[i] > thw ? r0[i] : thw; s.lam[i] = mu0 / s.t[i]; }
-                    }
-                }
-                DSET_LOOP {
-                    DSET_BIND
-                    if (dact) {
-                        D.dx6 += L.ddx[(dk - 1) * 7 + 6];
-                        const double r0[2] = { D.dx6 - D.dl, D.du - D.dx6 };
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) { D.t[i] = r0[i] > thw ? r0[i] : thw; D.lam[i] = mu0 / D.t[i]; }
-                    }
-                }
-                double dpi0[TPL];
-#pragma unroll
-                for (int m = 0; m < TPL; ++m) {
-                    dpi0[m] = 0.0;
-                    if (T[m].k) {
-                        const int k = T[m].k, i = T[m].i;
-                        const double* dk = L.ddx + (k - 1) * 7;
-                        const double* Pp = L.Pk + (k - 1) * PKS;
-                        double dp = L.pv[(k - 1) * 7 + i];
-#pragma unroll
-                        for (int l = 0; l < NX; ++l) {
-                            const int lo = l < i ? l : i, hi = l < i ? i : l;
-                            dp += Pp[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)] * dk[l];
-                        }
-                        dpi0[m] = dp;
-                        T[m].dx += dk[i];
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < TPL; ++m) if (T[m].k) L.pi[(T[m].k - 1) * 7 + T[m].i] = dpi0[m];
-            }
-            WSYNC();
-        }
-        if (!solved)
-        for (; it < itmax; ++it) {
-            // ---- reciprocals, complementarity, residuals of the input sets
-            double musum = 0.0, cmax = 0.0, rmax = 0.0;
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                USet2& s = U[m];
-                const int sid = lane + WAVE * m;
-                const bool act = sid < nu_sets;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s.it[i] = 1.0 / s.t[i]; s.il[i] = 1.0 / s.lam[i];
-                    s.rc[i] = s.t[i] * s.lam[i];
-                    if (act) { musum += s.rc[i]; cmax = fmax(cmax, s.rc[i]); }
-                }
-                s.iG02 = 1.0 / (s.lam[0] * s.it[0] + s.lam[2] * s.it[2]);
-                s.iG13 = 1.0 / (s.lam[1] * s.it[1] + s.lam[3] * s.it[3]);
-                if (act) {
-                    const int k = sid >> 1, j = sid & 1;
-                    const double* bcol = L.GT + k * GTS + (5 + j) * 6;
-                    const double* pik = L.pi + k * 7;
-                    double a = (j ? Rd[1] : Rd[0]) * s.du + s.r - s.lam[0] + s.lam[1] + (j == 1 ? Ts * pik[6] : 0.0);
-#pragma unroll
-                    for (int l = 0; l < 6; ++l) a += bcol[l] * pik[l];
-                    s.ru = a;
-                    rmax = OpMaxNan::f(rmax, fabs(s.ru));
-                    rmax = OpMaxNan::f(rmax, fabs(rho_l - s.lam[0] - s.lam[2])); rmax = OpMaxNan::f(rmax, fabs(rho_u - s.lam[1] - s.lam[3]));
-                    rmax = OpMaxNan::f(rmax, fabs(s.rd0())); rmax = OpMaxNan::f(rmax, fabs(s.rd1()));
-                    rmax = OpMaxNan::f(rmax, fabs(s.rd2())); rmax = OpMaxNan::f(rmax, fabs(s.rd3()));
-                }
-            }
-            DSET_LOOP {
-                DSET_BIND
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    D.it[i] = 1.0 / D.t[i]; D.il[i] = 1.0 / D.lam[i];
-                    D.rc[i] = D.t[i] * D.lam[i];
-                    if (dact) { musum += D.rc[i]; cmax = fmax(cmax, D.rc[i]); }
-                }
-            }
-            // ---- state stationarity rows (k,i), k = 1..N (the delta-bound multipliers are added by the owner lane)
-#pragma unroll
-            for (int m = 0; m < TPL; ++m) {
-                const XTask& tk = T[m];
-                if (tk.k) {
-                    const int k = tk.k, i = tk.i;
-                    double a;
-                    if (k < N) {
-                        a = tk.w * tk.dx + tk.q0 - L.pi[(k - 1) * 7 + i];
-                        const double* pik = L.pi + k * 7;
-                        if (i < 2) a += pik[i];
-                        else {
-                            const double* acol = L.GT + k * GTS + (i - 2) * 6;
-#pragma unroll
-                            for (int l = 0; l < 6; ++l) a += acol[l] * pik[l];
-                            if (i == 6) a += pik[6];
-                        }
-                    } else {
-                        a = tk.w * tk.dx + tk.q0 - L.pi[(N - 1) * 7 + i];
-                    }
-                    L.gx[(k - 1) * 7 + i] = a;
-                    if (!(k < N && i == 6)) rmax = OpMaxNan::f(rmax, fabs(a));
-                }
-            }
-            WSYNC();
-            DSET_LOOP {
-                DSET_BIND
-                if (!dact) continue;
-                D.rx6 = L.gx[(dk - 1) * 7 + 6] - D.lam[0] + D.lam[1];
-                rmax = OpMaxNan::f(rmax, fabs(D.rx6)); rmax = OpMaxNan::f(rmax, fabs(D.rd0())); rmax = OpMaxNan::f(rmax, fabs(D.rd1()));
-            }
-            const double mu = wave_reduce<OpSum>(musum) * inv_nineq;
-            cmax = wave_reduce<OpMax>(cmax);
-            rmax = wave_reduce<OpMaxNan>(rmax);
-            step = wave_reduce<OpMax>(stp_local);
-            if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
-            if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
-            rmax_prev = rmax;
-
-            double mu_aff = 0.0;
-#pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {            // 0: predictor, 1: corrector
-                // ---- eliminate slacks / multipliers
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) {
-                    USet2& s = U[m];
-                    const int sid = lane + WAVE * m;
-                    if (sid < nu_sets) {
-                        const double G0 = s.lam[0] * s.it[0], G1 = s.lam[1] * s.it[1], G2 = s.lam[2] * s.it[2], G3 = s.lam[3] * s.it[3];
-                        const double c0 = s.rc[0] * s.it[0], c1 = s.rc[1] * s.it[1], c2 = s.rc[2] * s.it[2], c3 = s.rc[3] * s.it[3];
-                        const double rd0 = s.rd0(), rd1 = s.rd1();
-                        const double e1 = (rho_l - s.lam[0] - s.lam[2]) + c0 + c2 + G0 * rd0 + G2 * s.rd2();
-                        const double e2 = (rho_u - s.lam[1] - s.lam[3]) + c1 + c3 + G1 * rd1 + G3 * s.rd3();
-                        const double etal = c0 + G0 * rd0 - G0 * e1 * s.iG02;
-                        const double etau = -c1 - G1 * rd1 + G1 * e2 * s.iG13;
-                        if (pass == 0) L.Rt[sid] = ((sid & 1) ? Rd[1] : Rd[0]) + G0 * G2 * s.iG02 + G1 * G3 * s.iG13;
-                        L.guk[sid] = s.ru + etal + etau;
-                    }
-                }
-                DSET_LOOP {
-                    DSET_BIND
-                    if (!dact) continue;
-                    const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
-                    if (pass == 0) L.Qt[dk] = Qd[6] + G5 + G6;
-                    L.gx[(dk - 1) * 7 + 6] = D.rx6 + (D.rc[0] * D.it[0] + G5 * D.rd0()) - (D.rc[1] * D.it[1] + G6 * D.rd1());
-                }
-                WSYNC();
-                if (pass == 0) riccati_factor_fused(L, N, lane, R);
-                else { riccati_backward2(L, N, lane, Ts); WSYNC(); }
-                riccati_forward2<false>(L, N, lane, Ts, 0.0);
-                WSYNC();
-                // ---- recover slack / t / lam steps; largest step to the boundary via max(-d/v)
-                double rr = 0.0;
-#pragma unroll
-                for (int m = 0; m < UPL; ++m) {
-                    USet2& s = U[m];
-                    const int sid = lane + WAVE * m;
-                    if (sid < nu_sets) {
-                        const double G[4] = { s.lam[0] * s.it[0], s.lam[1] * s.it[1], s.lam[2] * s.it[2], s.lam[3] * s.it[3] };
-                        const double u = L.guk[sid];
-                        const double rd0 = s.rd0(), rd1 = s.rd1(), rd2 = s.rd2(), rd3 = s.rd3();
-                        const double e1 = (rho_l - s.lam[0] - s.lam[2]) + s.rc[0] * s.it[0] + s.rc[2] * s.it[2] + G[0] * rd0 + G[2] * rd2;
-                        const double e2 = (rho_u - s.lam[1] - s.lam[3]) + s.rc[1] * s.it[1] + s.rc[3] * s.it[3] + G[1] * rd1 + G[3] * rd3;
-                        s.dsl = -(e1 + G[0] * u) * s.iG02;
-                        s.dsu = -(e2 - G[1] * u) * s.iG13;
-                        s.dt[0] = u + s.dsl + rd0; s.dt[1] = -u + s.dsu + rd1; s.dt[2] = s.dsl + rd2; s.dt[3] = s.dsu + rd3;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            s.dlam[i] = -s.rc[i] * s.it[i] - G[i] * s.dt[i];
-                            rr = fmax(rr, fmax(-s.dt[i] * s.it[i], -s.dlam[i] * s.il[i]));
-                        }
-                    }
-                }
-                DSET_LOOP {
-                    DSET_BIND
-                    if (!dact) continue;
-                    const double G5 = D.lam[0] * D.it[0], G6 = D.lam[1] * D.it[1];
-                    const double x6 = L.ddx[(dk - 1) * 7 + 6];
-                    D.dt[0] = x6 + D.rd0();  D.dlam[0] = -D.rc[0] * D.it[0] - G5 * D.dt[0];
-                    D.dt[1] = -x6 + D.rd1(); D.dlam[1] = -D.rc[1] * D.it[1] - G6 * D.dt[1];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) rr = fmax(rr, fmax(-D.dt[i] * D.it[i], -D.dlam[i] * D.il[i]));
-                }
-                rr = wave_reduce<OpMax>(rr);
-                const double amax = rr > 1.0 ? 1.0 / rr : 1.0;
-                if (pass == 0) {
-                    double s_aff = 0.0;
-#pragma unroll
-                    for (int m = 0; m < UPL; ++m) {
-                        USet2& s = U[m];
-                        if (lane + WAVE * m < nu_sets)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) s_aff += (s.t[i] + amax * s.dt[i]) * (s.lam[i] + amax * s.dlam[i]);
-                    }
-                    DSET_LOOP {
-                        DSET_BIND
-                        if (dact)
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) s_aff += (D.t[i] + amax * D.dt[i]) * (D.lam[i] + amax * D.dlam[i]);
-                    }
-                    mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
-                    double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
-                    const double smu = sigma * mu;
-#pragma unroll
-                    for (int m = 0; m < UPL; ++m) {
-                        USet2& s = U[m];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) s.rc[i] = s.t[i] * s.lam[i] + s.dt[i] * s.dlam[i] - smu;
-                    }
-                    DSET_LOOP {
-                        DSET_BIND
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) D.rc[i] = D.t[i] * D.lam[i] + D.dt[i] * D.dlam[i] - smu;
-                    }
-                } else {
-                    double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
-                    const double alpha = fmin(tau * amax, 1.0);
-                    stp_local = 0.0;
-#pragma unroll
-                    for (int m = 0; m < UPL; ++m) {
-                        USet2& s = U[m];
-                        const int sid = lane + WAVE * m;
-                        if (sid < nu_sets) {
-                            const double u = L.guk[sid];
-                            stp_local = fmax(stp_local, fabs(alpha * u));
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                s.t[i] = fmax(s.t[i] + alpha * s.dt[i], IPM_FLOOR);
-                                s.lam[i] = fmax(s.lam[i] + alpha * s.dlam[i], IPM_FLOOR);
-                            }
-                            s.du += alpha * u; s.sl += alpha * s.dsl; s.su += alpha * s.dsu;
-                        }
-                    }
-                    DSET_LOOP {
-                        DSET_BIND
-                        if (!dact) continue;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            D.t[i] = fmax(D.t[i] + alpha * D.dt[i], IPM_FLOOR);
-                            D.lam[i] = fmax(D.lam[i] + alpha * D.dlam[i], IPM_FLOOR);
-                        }
-                        D.dx6 += alpha * L.ddx[(dk - 1) * 7 + 6];
-                    }
-                    // dx += alpha ddx ; pi[k-1] += alpha (P_k ddx_k + p_k)   for the entries (k,i) this lane owns
-                    double dpi[TPL];
-#pragma unroll
-                    for (int m = 0; m < TPL; ++m) {
-                        dpi[m] = 0.0;
-                        if (T[m].k) {
-                            const int k = T[m].k, i = T[m].i;
-                            const double* dk = L.ddx + (k - 1) * 7;
-                            const double* Pp = L.Pk + (k - 1) * PKS;
-                            double dp = L.pv[(k - 1) * 7 + i];
-#pragma unroll
-                            for (int l = 0; l < NX; ++l) {
-                                const int lo = l < i ? l : i, hi = l < i ? i : l;
-                                dp += Pp[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)] * dk[l];
-                            }
-                            dpi[m] = dp;
-                            T[m].dx += alpha * dk[i];
-                        }
-                    }
-#pragma unroll
-                    for (int m = 0; m < TPL; ++m) if (T[m].k) L.pi[(T[m].k - 1) * 7 + T[m].i] += alpha * dpi[m];
-                    WSYNC();
-                }
-            }
-        }
-        // ---- H6: full step, outputs
-        bool bad = failed;
-        double xnew[TPL];
-#pragma unroll
-        for (int m = 0; m < TPL; ++m) {
-            xnew[m] = 0.0;
-            if (T[m].k) { xnew[m] = xbg[7 + lane + WAVE * m] + T[m].dx; if (!(fabs(xnew[m]) <= 1e300)) bad = true; }
-        }
-#pragma unroll
-        for (int m = 0; m < UPL; ++m) {
-            const int sid = lane + WAVE * m;
-            if (sid < nu_sets) { const double v = ubg[sid] + U[m].du; if (!(fabs(v) <= 1e300)) bad = true; }
-        }
-        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
-        double J = 0.0;
-        if (status == ADMPC_STATUS_SUCCESS) {
-            double* xo = xbarg + (size_t)inst * (N + 1) * NX;
-            double* uo = ubarg + (size_t)inst * N * NU;
-            if (lane < NX) {
-                const double x0v = xbg[lane] + dx0;
-                const double e = x0v - yrg[lane];
-                J += 0.5 * sel7(Qd, lane) * e * e;
-                xo[lane] = x0v;
-            }
-#pragma unroll
-            for (int m = 0; m < TPL; ++m) if (T[m].k) {
-                const int k = T[m].k, i = T[m].i;
-                const double e = xnew[m] - (k < N ? yrg[k * 9 + i] : yrefeg[(size_t)inst * NX + i]);
-                J += 0.5 * T[m].w * e * e;
-                xo[7 + lane + WAVE * m] = xnew[m];
-            }
-#pragma unroll
-            for (int m = 0; m < UPL; ++m) {
-                const int sid = lane + WAVE * m;
-                if (sid < nu_sets) {
-                    const int j = sid & 1;
-                    const double ub = ubg[sid];
-                    const double v = ub + U[m].du;
-                    const double rdj = j ? Rd[1] : Rd[0];
-                    const double e = U[m].du + U[m].r / rdj;                   // u - uref
-                    J += 0.5 * rdj * e * e;
-                    if (v < cfg->lbu[j]) J += rho_l * (cfg->lbu[j] - v);
-                    if (v > cfg->ubu[j]) J += rho_u * (v - cfg->ubu[j]);
-                    uo[sid] = v;
-                }
-            }
-        }
-        J = wave_reduce<OpSum>(J);
-        if (lane == 0) {
-            if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? J : INFINITY;
-            statusg[inst] = status;
-            if (itersg) itersg[inst] = it;
-        }
-        WSYNC();
-    }
-}
-
-}  // namespace
-// Host side of the Riccati path.  This part of the file is compiled at -O1 in a translation unit of its own (ADMPC_TU_RICCATI,
-// see the Makefile): the -O1 code is the faster one (1.92 vs 2.25 ms at N = 40, B = 2048).
-extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_prepare(void)
-{
-    const void* kerns[5] = { (const void*)admpc_qp_kernel<1, 3, 1, 0>, (const void*)admpc_qp_kernel<1, 4, 1, 0>,
-                             (const void*)admpc_qp_kernel<2, 7, 1, 0>,
-                             (const void*)admpc_qp_kernel<3, 11, 2, 0>, (const void*)admpc_qp_kernel<4, 14, 2, 0> };
-    for (int i = 0; i < 5; ++i) (void)hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    // > 64 KB of dynamic LDS
-}
-extern "C" __attribute__((visibility("hidden"))) void admpc_riccati_launch(int N, int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B,
-        const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, int first, int* ticket)
-{
-    // (the NT template parameter allows compile-time-N instantiations; none is dispatched)
-#define LAUNCH_QP(U_, T_, D_, N_) hipLaunchKernelGGL((admpc_qp_kernel<U_, T_, D_, N_>), dim3(grid), dim3(WAVE), lds_bytes, st, d_cfg, B, x0, yref, yref_e, \
-                           GT, bl, xbar, ubar, cost, stat, iters, first, ticket)
-    if (N <= 27) LAUNCH_QP(1, 3, 1, 0);
-    else if (N <= 32) LAUNCH_QP(1, 4, 1, 0);
-    // N = 33 .. 45 would fit five state entries per lane, but every build of a <2,5,..> instantiation that went wrong on the GPU
-    // (run-to-run different results, on some MI355X boxes only, following the code generation: DESIGN.md) was that one; the
-    // <2,7,..> code computes the same horizons correctly on the same boxes at 5 % more time
-    else if (N <= 64) LAUNCH_QP(2, 7, 1, 0);
-    else if (N <= 96) LAUNCH_QP(3, 11, 2, 0);      // 7N <= 704, 2N <= 192
-    else LAUNCH_QP(4, 14, 2, 0);                   // N <= 128
-#undef LAUNCH_QP
-}
-namespace {
-#endif  // !ADMPC_TU_MAIN
-
-#ifndef ADMPC_TU_RICCATI   // ---- everything below: main translation unit only
 // ---------------------------------------------------------------------------------------------
 // kernel B' : condensed QP, dense Cholesky -- the reference's own QP strategy (FULL_CONDENSING_HPIPM,
 // acados_solver_sim_car.c:145) for horizons with 2N <= 64 inputs.  One instance per wavefront,
@@ -2266,8 +1496,6 @@ struct AdmpcSolver {
     AdmpcConfig* d_cfg;
     int device;
     int num_cu;
-    int lds_bytes;
-    int blocks_per_cu;
     int use_dense;           // condensed dense-Cholesky QP kernel available for this horizon (N == 20) and not disabled
     int dense_lds_bytes;
     // workspace of the linearisation (kernel A -> kernel B), grown on demand by admpc_reserve
@@ -2285,12 +1513,15 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ADMPC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
-#ifdef ADMPC_TU_MAIN      // defined in the Riccati translation unit
-extern "C" void admpc_riccati_prepare(void);
-extern "C" void admpc_riccati_launch(int N, int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B,
+// kernel R (admpc_rowqp.hip)
+extern "C" int admpc_rowqp_plan(int N, int elem, int B, int num_cu, int* rows, int* inst_stride, int* lds_bytes, int* grid);
+extern "C" void admpc_rowqp_prepare(void);
+extern "C" void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, int first, int* ticket);
-#endif
+        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, int first, int* ticket);
+extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
+        const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
+        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, int first, int* ticket);
 
 extern "C" {
 
@@ -2346,11 +1577,10 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     AdmpcSolver* s = new (std::nothrow) AdmpcSolver();
     if (!s) return fail(ADMPC_ENOMEM, "out of host memory");
     s->cfg = *cfg; s->device = device; s->num_cu = prop.multiProcessorCount;
-    s->lds_bytes = lds2_doubles(cfg->N) * (int)sizeof(double);
-    if (s->lds_bytes > 160 * 1024) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
-    s->blocks_per_cu = (160 * 1024) / s->lds_bytes;
-    if (s->blocks_per_cu > 4) s->blocks_per_cu = 4;          // register-limited: one wave per SIMD
-    if (s->blocks_per_cu < 1) s->blocks_per_cu = 1;
+    {   // the row kernel must fit at least one instance per wave into the 160 KB of LDS
+        int r_, st_, lb_, g_;
+        if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
+    }
     s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr;
     {   // ADMPC_QP=riccati forces the stage-wise Riccati kernel (A/B tests); default: condensed kernel where instantiated
         const char* e = getenv("ADMPC_QP");
@@ -2365,7 +1595,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     s->qmask = 7;
     for (int c = 3; c < NX; ++c) if (cfg->W[c] != 0.0 || cfg->We[c] != 0.0) s->qmask = 127;
     // opt in to > 64 KB of dynamic LDS
-    admpc_riccati_prepare();
+    admpc_rowqp_prepare();
     (void)hipFuncSetAttribute((const void*)admpc_qp_dense_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
@@ -2438,8 +1668,6 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     const int N = s->cfg.N;
     hipStream_t st = (hipStream_t)stream;
     int32_t* stat = status ? status : s->d_status;
-    int gridB = s->num_cu * s->blocks_per_cu;
-    if (gridB > B) gridB = B;
     const long totalA = (long)B * N * 3;
     int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
     if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
@@ -2469,9 +1697,12 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
             hipLaunchKernelGGL((admpc_expand_kernel<20>), dim3(gridE), dim3(WAVE), exp_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, (const double*)s->d_aux);
         }
-        else
-            admpc_riccati_launch(N, gridB, s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
-                                 xbar, ubar, cost, stat, iters, first, s->d_sched);
+        else {
+            int rows, stride, ldsb, gridR;
+            if (admpc_rowqp_plan(N, 8, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
+            admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
+                                   xbar, ubar, cost, stat, iters, (double*)nullptr, first, s->d_sched);
+        }
     }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -2555,7 +1786,3 @@ int admpc_waypoints_batch(int device, int M, int H, double dt, int B,
 }
 
 }  // extern "C"
-#endif  // !ADMPC_TU_RICCATI
-#ifdef ADMPC_TU_RICCATI
-}  // namespace
-#endif

@@ -1,0 +1,118 @@
+// admpc_rowqp.hip -- kernel R: the QP of one RTI step (H2-H6) for every horizon, fp64 and fp32.
+//
+// One MPC instance per 16-lane DPP row, four instances per wavefront (workgroup = one wave).  The algorithm is
+// rowqp_core.h (shared with the CPU lane emulator of tests/emu), the lane primitives are rowqp_dev.h.
+//
+// Data placement
+//   HBM / L2 (read-only during the solve, streamed one stage ahead by every sweep): packed linearisation GT [B][N][7][6] and
+//     defects b [B][N][7] from the linearisation kernel, the iterate xbar / ubar, the references yref / yref_e.
+//   LDS: one record of RQ_RS values per stage and instance (interior-point state, gains, right-hand sides, steps): 480 B (fp64)
+//     / 240 B (fp32) per stage -> N = 20: 10 KB per instance, 4 waves per CU; N = 40 fp64 / N = 80 fp32: 19.7 KB, 2 waves per CU.
+//   Registers: the Riccati matrix P (7 values per lane), the stage linearisation of the current and the next stage, lane constants.
+//     No scratch.
+// Waves draw quadruples of instances from a ticket counter (zeroed by the linearisation kernel).  The four instances of a wave
+// iterate until the last of them has converged; finished rows are frozen by masks (their state is not rewritten).
+#include "rowqp_dev.h"
+#include "../../include/admpc.h"
+
+namespace {
+
+template <class T>
+__global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __restrict__ cfg, int B, int rows, int inst_stride,
+                                                         const T* __restrict__ x0g, const T* __restrict__ yrefg, const T* __restrict__ yrefeg,
+                                                         const T* __restrict__ GTg, const T* __restrict__ blg,
+                                                         T* __restrict__ xbarg, T* __restrict__ ubarg,
+                                                         T* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
+                                                         T* __restrict__ pig, int first_pass, int* __restrict__ ticket)
+{
+    typedef DevX<T> X;
+    extern __shared__ double smem_raw[];
+    typename X::LT* const smem = (typename X::LT*)smem_raw;
+    const int lane16 = (int)(threadIdx.x & 15u), row = (int)(threadIdx.x >> 4);
+    RqParams<T> q;
+    rq_make_params<T>(*cfg, q);
+    RqArrays<T> io;
+    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig;
+    const int nquads = (B + rows - 1) / rows;
+    const bool has_lds = row < rows;
+    typename X::Lds lds{ smem + (has_lds ? row : 0) * inst_stride, has_lds };
+
+    for (int quad = (int)blockIdx.x; quad < nquads;) {
+        const int inst = quad * rows + row;
+        bool valid = has_lds && inst < B;
+        const int ic = inst < B && has_lds ? inst : B - 1;                  // rows without an instance recompute the last one and write nothing
+        if (!first_pass) valid = valid && statusg[ic] == 0;                 // failed in an earlier SQP iteration: left untouched
+        RowQp<X> S(q, io, lds, ic);
+        typename RowQp<X>::Result res;
+        S.solve(valid, res, pig != nullptr, valid);
+        bool failed = res.failed;
+        T J;
+        S.finish(valid, failed, J);
+        if (valid && lane16 == 0) {
+            statusg[ic] = failed ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+            if (costg) costg[ic] = failed ? (T)INFINITY : J;
+            if (itersg) itersg[ic] = res.iters;
+        }
+        X::lds_fence();
+        int v = 0;
+        if (threadIdx.x == 0) v = atomicAdd(ticket, 1);
+        quad = (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
+    }
+}
+
+}  // namespace
+
+// LDS bytes of one instance: (N + 1) records, padded so that consecutive rows of a wave fall on different bank halves
+// (ds_read_b64: lanes 0-31 = rows 0, 1 share one access; 16 consecutive doubles = 32 banks).
+template <class T>
+static int rowqp_inst_stride(int N)
+{
+    int s = (N + 1) * RQ_RS;                                                // values of T, multiple of 4
+    const int half = sizeof(T) == 8 ? 16 : 16;                              // fp64: 16 doubles = 128 B; fp32: 16 floats = 64 B
+    while (s % (2 * half) != half) s += 4;
+    return s;
+}
+
+extern "C" __attribute__((visibility("hidden")))
+int admpc_rowqp_plan(int N, int elem, int B, int num_cu, int* rows, int* inst_stride, int* lds_bytes, int* grid)
+{
+    const int stride = elem == 8 ? rowqp_inst_stride<double>(N) : rowqp_inst_stride<float>(N);
+    const int cap = 160 * 1024;
+    int r = 4;
+    while (r > 1 && r * stride * elem > cap) r >>= 1;
+    if (r * stride * elem > cap) return -1;
+    // small batches: fewer instances per wave spread the work over more SIMDs (one wave per SIMD before rows are shared)
+    while (r > 1 && (B + r - 1) / r < num_cu * 4 && (B + r / 2 - 1) / (r / 2) <= num_cu * 4) r >>= 1;
+    int per_cu = cap / (r * stride * elem);
+    if (per_cu > 8) per_cu = 8;
+    int g = num_cu * per_cu;
+    const int nquads = (B + r - 1) / r;
+    if (g > nquads) g = nquads;
+    *rows = r; *inst_stride = stride; *lds_bytes = r * stride * elem; *grid = g < 1 ? 1 : g;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("hidden")))
+void admpc_rowqp_prepare(void)
+{
+    (void)hipFuncSetAttribute((const void*)admpc_rowqp_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_rowqp_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+extern "C" __attribute__((visibility("hidden")))
+void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
+                            const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
+                            double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, int first, int* ticket)
+{
+    hipLaunchKernelGGL((admpc_rowqp_kernel<double>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
+                       xbar, ubar, cost, stat, iters, pi, first, ticket);
+}
+
+extern "C" __attribute__((visibility("hidden")))
+void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
+                            const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
+                            float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, int first, int* ticket)
+{
+    hipLaunchKernelGGL((admpc_rowqp_kernel<float>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
+                       xbar, ubar, cost, stat, iters, pi, first, ticket);
+}

@@ -35,6 +35,10 @@
 #ifndef RQ_FN
 #define RQ_FN static inline
 #endif
+#ifndef RQ_UNROLL
+#define RQ_UNROLL
+#define RQ_NOUNROLL
+#endif
 
 #ifndef RQ_DBG
 #define RQ_DBG(...) do { } while (0)
@@ -57,9 +61,9 @@ struct RqParams {              // wave-uniform scalars
 };
 
 template <class T>
-struct RqRow {                 // per instance (device: per lane, uniform inside a row)
+struct RqArrays {              // wave-uniform array bases (device: kernel arguments, SGPR-addressed loads with 32-bit lane offsets)
     const T *x0, *yref, *yref_e, *GT, *bl;
-    T *xbar, *ubar;
+    T *xbar, *ubar, *pi;
 };
 
 template <class X>
@@ -71,7 +75,8 @@ struct RowQp {
     typedef typename X::Lds Lds;
 
     const RqParams<T>& q;
-    const RqRow<T>& io;
+    const RqArrays<T>& io;
+    I ix0, iyr, iye, igt, ibl, ixb, iub;   // element offsets of the row's instance in the arrays
     Lds lds;
     const int N;
 
@@ -90,20 +95,25 @@ struct RowQp {
     I sp, side, jin, o_tb, o_ts, o_vl, o_st, o_dxu;
     M e_valid, e_isd, e_even, e_in, dxl;
     V sgn, bound, rho, rjin, isdf;
+    V wsd, wesd, lbj, ubj;     // pass lanes (sp, i < 7): weights of state i; input lanes: bounds of input jin
 
     RQ_FN V splat(T x) { return X::splat(x); }
 
-    RQ_FN RowQp(const RqParams<T>& q_, const RqRow<T>& io_, Lds lds_) : q(q_), io(io_), lds(lds_), N(q_.N)
+    // inst: index of the row's instance (row-uniform)
+    RQ_FN RowQp(const RqParams<T>& q_, const RqArrays<T>& io_, Lds lds_, I inst) : q(q_), io(io_), lds(lds_), N(q_.N)
     {
+        ix0 = inst * 7; iye = ix0; iyr = inst * (N * 9); igt = inst * (N * RQ_GTS); ibl = inst * (N * 7); ixb = inst * ((N + 1) * 7); iub = inst * (N * 2);
         lane = X::lane();
         is_x = lane < 7; is_u = (lane == 7) | (lane == 8); is6 = lane == 6; is7 = lane == 7; lt2 = lane < 2;
         const V one = splat((T)1), zero = splat((T)0);
+        RQ_UNROLL
         for (int r = 0; r < 9; ++r) E[r] = X::sel(lane == r, one, zero);
         keepc = X::sel(lt2, zero, one);
         unitc[0] = E[0]; unitc[1] = E[1];
         lt2f = X::sel(lt2, one, zero);
         g6c = X::sel(is6, one, X::sel(lane == 8, splat(q.h), zero));
         wq = zero; wqe = zero;
+        RQ_UNROLL
         for (int i = 0; i < 7; ++i) { wq = X::sel(lane == i, splat(q.Qd[i]), wq); wqe = X::sel(lane == i, splat(q.Qe[i]), wqe); }
         rjm = X::sel(is7, splat(q.Rd[0]), X::sel(lane == 8, splat(q.Rd[1]), zero));
         const I zi = X::isplat(0);
@@ -133,6 +143,9 @@ struct RowQp {
         rho = X::sel(up, splat(q.rho_u), splat(q.rho_l));
         rjin = X::sel(jin == 0, splat(q.Rd[0]), splat(q.Rd[1]));
         isdf = X::sel(e_isd, one, zero);
+        wsd = zero; wesd = zero;
+        for (int i = 0; i < 7; ++i) { wsd = X::sel(side == i, splat(q.Qd[i]), wsd); wesd = X::sel(side == i, splat(q.Qe[i]), wesd); }
+        lbj = X::sel(jin == 0, splat(q.lbu[0]), splat(q.lbu[1])); ubj = X::sel(jin == 0, splat(q.ubu[0]), splat(q.ubu[1]));
         const I sidec = X::isel(e_valid, side, zi);
         o_tb = sidec;                                                               // bound pair of the side
         o_ts = X::isel(e_in, side + 6, sidec);                                      // slack pair (inputs), own pair otherwise
@@ -148,15 +161,17 @@ struct RowQp {
 
     // column layout of stage k: Gc[l] = G[l][c] for the lane's column c (rows 0..5)
     RQ_FN void load_gc(int k, V Gc[6]) {
-        X::gld6(io.GT, o_gc + k * RQ_GTS, Gc);
+        X::gld6(io.GT, igt + o_gc + k * RQ_GTS, Gc);
     }
     RQ_FN void fix_gc(V Gc[6]) {          // lanes 0, 1: unit columns e0, e1 of A
         Gc[0] = fma(Gc[0], keepc, unitc[0]); Gc[1] = fma(Gc[1], keepc, unitc[1]);
+        RQ_UNROLL
         for (int l = 2; l < 6; ++l) Gc[l] = Gc[l] * keepc;
     }
     // row layout: Gr[c'] = G[lane][2 + c'] for c' = 0..6 (lanes 0..5; other lanes load a valid row and ignore it)
     RQ_FN void load_gr(int k, V Gr[7]) {
-        for (int c = 0; c < 7; ++c) Gr[c] = X::gld(io.GT, o_gr + (k * RQ_GTS + c * 6));
+        RQ_UNROLL
+        for (int c = 0; c < 7; ++c) Gr[c] = X::gld(io.GT, igt + o_gr + (k * RQ_GTS + c * 6));
     }
     // =================================================================================================================
     // sweeps
@@ -170,11 +185,12 @@ struct RowQp {
         V z = ld(o_x + RQ_DX, 0);                                  // dx_0 = rec(-1).DX
         V Gr[7], Gn[7];
         load_gr(0, Gr);
-        V bk = X::gld(io.bl, o_x);
+        V bk = X::gld(io.bl, ibl + o_x);
+        RQ_NOUNROLL
         for (int k = 0; k < N; ++k) {
             const int kn = k + 1 < N ? k + 1 : k;
             load_gr(kn, Gn);
-            const V bn = X::gld(io.bl, o_x + kn * 7);
+            const V bn = X::gld(io.bl, ibl + o_x + kn * 7);
             V zz = X::sel(is_x, z, splat((T)0));
             if (with_du) { const V du = ld(o_u + RQ_DU, (k + 1) * RQ_RS); zz = X::sel(is_x, z, du); }
             V zn = splat((T)0);
@@ -184,6 +200,7 @@ struct RowQp {
             zn = X::sel(is6, fma(u1, splat(q.h), zz), zn) + bk;
             st(o_x + RQ_DX, (k + 1) * RQ_RS, zn, is_x);
             z = zn;
+            RQ_UNROLL
             for (int c = 0; c < 7; ++c) Gr[c] = Gn[c];
             bk = bn;
         }
@@ -195,17 +212,19 @@ struct RowQp {
         V P[7], p;
         {
             const V dxN = ld(o_x + RQ_DX, N * RQ_RS);             // dx_N = rec(N-1).DX
-            const V xN = X::gld(io.xbar, o_x + N * 7), rN = X::gld(io.yref_e, o_x);
+            const V xN = X::gld(io.xbar, ixb + o_x + N * 7), rN = X::gld(io.yref_e, iye + o_x);
             p = X::sel(is_x, wqe * (dxN + xN - rN), splat((T)0));
+            RQ_UNROLL
             for (int i = 0; i < 7; ++i) P[i] = E[i] * wqe;
         }
         V Gc[6], Gn[6];
         load_gc(N - 1, Gc);
-        V xk = X::gld(io.xbar, o_x + (N - 1) * 7), rk = X::gld(io.yref, o_y + (N - 1) * 9);
+        V xk = X::gld(io.xbar, ixb + o_x + (N - 1) * 7), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
+        RQ_NOUNROLL
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
-            const V xn = X::gld(io.xbar, o_x + kn * 7), rn = X::gld(io.yref, o_y + kn * 9);
+            const V xn = X::gld(io.xbar, ixb + o_x + kn * 7), rn = X::gld(io.yref, iyr + o_y + kn * 9);
             const V v1 = ld(o1, k * RQ_RS);                        // lanes < 7: dx_k ; lanes 7, 8: gu
             const V v2 = ld(o2s1, k * RQ_RS);                      // lane 6: X ; lanes 7, 8: Rt
             const V v3 = ld(X::isplat(0), (k + 1) * RQ_RS + RQ_Q1);  // Qt
@@ -217,6 +236,7 @@ struct RowQp {
             X::pg(P, G7, Mm);
             V H[9];
             X::gtm(Gc, Mm, q.h, H);
+            RQ_UNROLL
             for (int r = 0; r < 9; ++r) H[r] = fma(E[r], wd, H[r]);
             const V h00 = X::template bc<7>(H[7]), h01 = X::template bc<7>(H[8]), h11 = X::template bc<8>(H[8]);
             const V idet = X::rcp(h00 * h11 - h01 * h01);
@@ -234,8 +254,10 @@ struct RowQp {
             st(X::isplat(1), (k + 1) * RQ_RS + RQ_LI, i01, is7);
             st(X::isplat(2), (k + 1) * RQ_RS + RQ_LI, i11, lane == 8);
             st(o_u + RQ_U, (k + 1) * RQ_RS, kff, is_u);
+            RQ_UNROLL
             for (int i = 0; i < 7; ++i) P[i] = H[i];
             p = X::sel(is_x, pn, splat((T)0));
+            RQ_UNROLL
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
             xk = xn; rk = rn;
         }
@@ -246,16 +268,17 @@ struct RowQp {
         V p;
         {
             const V dxN = ld(o_x + RQ_DX, N * RQ_RS);
-            const V xN = X::gld(io.xbar, o_x + N * 7), rN = X::gld(io.yref_e, o_x);
+            const V xN = X::gld(io.xbar, ixb + o_x + N * 7), rN = X::gld(io.yref_e, iye + o_x);
             p = X::sel(is_x, wqe * (dxN + xN - rN), splat((T)0));
         }
         V Gc[6], Gn[6];
         load_gc(N - 1, Gc);
-        V xk = X::gld(io.xbar, o_x + (N - 1) * 7), rk = X::gld(io.yref, o_y + (N - 1) * 9);
+        V xk = X::gld(io.xbar, ixb + o_x + (N - 1) * 7), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
+        RQ_NOUNROLL
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
-            const V xn = X::gld(io.xbar, o_x + kn * 7), rn = X::gld(io.yref, o_y + kn * 9);
+            const V xn = X::gld(io.xbar, ixb + o_x + kn * 7), rn = X::gld(io.yref, iyr + o_y + kn * 9);
             const V v1 = ld(o1, k * RQ_RS);                        // dx_k | gA
             const V v2 = ld(o2s3, k * RQ_RS);                      // lane 6: xA ; lanes 7, 8: gB
             const V v3 = ld(X::isplat(0), (k + 1) * RQ_RS + RQ_D + 2);   // xB
@@ -274,6 +297,7 @@ struct RowQp {
             const V kff = X::sel(is7, -(i00 * hu0 + i01 * hu1), -(i01 * hu0 + i11 * hu1));
             st(o_u + RQ_U, (k + 1) * RQ_RS, kff, is_u);
             p = X::sel(is_x, pn, splat((T)0));
+            RQ_UNROLL
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
             xk = xn; rk = rn;
         }
@@ -281,23 +305,24 @@ struct RowQp {
 
     // SA: exact adjoint of the current point -> max-norm of the reduced gradient (the stationarity residual of the stopping
     //     test).  Raw gradients: gu = R (u - uref) - lam_l + lam_u, gx = w (x - ref), steering multipliers on component 6.
-    //     When pi_out != 0 the adjoint (= dynamics multipliers pi_k of the iterate snapshot) is written there, [N][7].
-    RQ_FN V sweep_adjoint(T* pi_out) {
+    //     With want_pi the adjoint (= dynamics multipliers pi_k of the iterate snapshot) is written there, [N][7].
+    RQ_FN V sweep_adjoint(bool want_pi, M pim) {
         V lam;
         {
             const V dxN = ld(o_x + RQ_DX, N * RQ_RS);
-            const V xN = X::gld(io.xbar, o_x + N * 7), rN = X::gld(io.yref_e, o_x);
+            const V xN = X::gld(io.xbar, ixb + o_x + N * 7), rN = X::gld(io.yref_e, iye + o_x);
             lam = X::sel(is_x, wqe * (dxN + xN - rN), splat((T)0));
         }
         V rg = splat((T)0);
         V Gc[6], Gn[6];
         load_gc(N - 1, Gc);
-        V xk = X::gld(io.xbar, o_x + (N - 1) * 7), rk = X::gld(io.yref, o_y + (N - 1) * 9), uk = X::gld(io.ubar, o_u + (N - 1) * 2);
+        V xk = X::gld(io.xbar, ixb + o_x + (N - 1) * 7), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9), uk = X::gld(io.ubar, iub + o_u + (N - 1) * 2);
+        RQ_NOUNROLL
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
-            const V xn = X::gld(io.xbar, o_x + kn * 7), rn = X::gld(io.yref, o_y + kn * 9), un = X::gld(io.ubar, o_u + kn * 2);
-            if (pi_out) X::gst(pi_out, o_x + k * 7, lam, is_x);   // pi_k multiplies dx_{k+1} = A dx_k + B du_k + b_k
+            const V xn = X::gld(io.xbar, ixb + o_x + kn * 7), rn = X::gld(io.yref, iyr + o_y + kn * 9), un = X::gld(io.ubar, iub + o_u + kn * 2);
+            if (want_pi) X::gst(io.pi, ibl + o_x + k * 7, lam, is_x & pim);   // pi_k multiplies dx_{k+1} = A dx_k + B du_k + b_k
             const V v1 = ld(o1sa, k * RQ_RS);                      // dx_k | du_k
             const V l0 = ld(o2sa, k * RQ_RS), l1 = ld(o3sa, k * RQ_RS);   // lane 6: steering pair; lanes 7, 8: bound pair of input j
             fix_gc(Gc);
@@ -307,6 +332,7 @@ struct RowQp {
             X::template dotbc<7, 0>(G7, lam, lv);
             rg = X::vmaxnan(rg, X::sel(is_u, X::vabs(lv), splat((T)0)));
             lam = X::sel(is_x, lv, splat((T)0));
+            RQ_UNROLL
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
             xk = xn; rk = rn; uk = un;
         }
@@ -319,10 +345,12 @@ struct RowQp {
         V z = splat((T)0);
         V Gr[7], Gn[7];
         load_gr(0, Gr);
+        RQ_NOUNROLL
         for (int k = 0; k < N; ++k) {
             const int kn = k + 1 < N ? k + 1 : k;
             load_gr(kn, Gn);
             V Kr[7];
+            RQ_UNROLL
             for (int c = 0; c < 7; ++c) Kr[c] = ld(o_u, (k + 1) * RQ_RS + RQ_K + 2 * c);     // lanes 7, 8: row j of K
             const V kff = ld(o_u + RQ_U, (k + 1) * RQ_RS);
             V ddu = kff;
@@ -337,6 +365,7 @@ struct RowQp {
             if (full) st(o_x + RQ_D, (k + 1) * RQ_RS, zn, is_x);
             else if (k + 1 < N) st(X::isplat(0), (k + 2) * RQ_RS + RQ_Q1, zn, is6);     // predictor ddx6 of stage k+1, in ITS record
             z = X::sel(is_x, zn, splat((T)0));
+            RQ_UNROLL
             for (int c = 0; c < 7; ++c) Gr[c] = Gn[c];
         }
     }
@@ -362,8 +391,8 @@ struct RowQp {
         S.act = e_valid & in & ((!e_isd) | (k >= 1));
         S.stv = e_valid & in & e_even;
         S.inb = e_valid & in;
-        const V ub = X::gld(io.ubar, kc * 2 + jin), xb = X::gld(io.xbar, kc * 7 + 6);
-        S.uref = X::gld(io.yref, kc * 9 + 7 + jin);
+        const V ub = X::gld(io.ubar, iub + kc * 2 + jin), xb = X::gld(io.xbar, ixb + kc * 7 + 6);
+        S.uref = X::gld(io.yref, iyr + kc * 9 + 7 + jin);
         const V vl = ld(S.kl + o_vl, 0);
         S.vabs = X::sel(e_isd, xb, ub) + vl;
         if (with_state) {
@@ -409,6 +438,7 @@ struct RowQp {
 
     RQ_FN void pass_e1(Red& R) {
         R.mu = splat((T)0); R.cmax = splat((T)0); R.rmax = splat((T)0);
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) { Side S; side_load(s, S, true); e1_core(S, R); }
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);
     }
@@ -426,6 +456,7 @@ struct RowQp {
     RQ_FN void pass_e2(V& rr, V& s2) {
         const V zero = splat((T)0), one = splat((T)1);
         rr = zero; s2 = zero;
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             Side S; side_load(s, S, true);
             Bar B; side_barrier(S, B);
@@ -472,6 +503,7 @@ struct RowQp {
     RQ_FN V pass_e3a(V smu) {
         const V zero = splat((T)0);
         V rr = zero;
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             Side S; side_load(s, S, true);
             Bar B; side_barrier(S, B);
@@ -486,6 +518,7 @@ struct RowQp {
 
     // dx += alpha ddx for every stage (lanes (sp, i < 7) <-> record 2s + sp)
     RQ_FN void pass_dx_update(V alpha, M rowact) {
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             const I k = sp + 2 * s;
             const M in = (k < N) & dxl;
@@ -501,6 +534,7 @@ struct RowQp {
         const V zero = splat((T)0);
         V stp = zero;
         R.mu = zero; R.cmax = zero; R.rmax = zero;
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             Side S; side_load(s, S, true);                         // old state, old dx6 (dx is stepped after this loop)
             Bar B; side_barrier(S, B);
@@ -528,13 +562,14 @@ struct RowQp {
     // X = 0, Q1 = Qd6; also zeroes du
     RQ_FN void pass_trial_setup() {
         const V zero = splat((T)0);
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             const I k = sp + 2 * s;
             const M in = k < N;
             const I kc = X::isel(in, k, X::isplat(N - 1));
             const I kl = (kc + 1) * RQ_RS;
             const M stv = e_valid & in & e_even;
-            const V ub = X::gld(io.ubar, kc * 2 + jin), ur = X::gld(io.yref, kc * 9 + 7 + jin);
+            const V ub = X::gld(io.ubar, iub + kc * 2 + jin), ur = X::gld(io.yref, iyr + kc * 9 + 7 + jin);
             st(kl + X::isel(e_isd, X::isplat(RQ_X), jin + RQ_U), 0, X::sel(e_isd, zero, rjin * (ub - ur)), stv);
             st(kl + X::isel(e_isd, X::isplat(RQ_Q1), jin + RQ_A), 0, X::sel(e_isd, splat(q.Qd[6]), rjin), stv);
             st(kl + jin + RQ_DU, 0, zero, stv & e_in);
@@ -544,6 +579,7 @@ struct RowQp {
     // does the step in U / D respect every bound?  (trial: du = 0 before it)
     RQ_FN M pass_trial_check() {
         M ok = X::mtrue();
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             Side S; side_load(s, S, false);
             const V stp = ld(S.kl + X::isel(e_isd, X::isplat(RQ_D + 6 - RQ_RS), jin + RQ_U), 0);
@@ -563,6 +599,7 @@ struct RowQp {
         const V gsc = X::sel(a0 > zero, zero, splat((T)1));        // weight of the plain gradient in the residual
         pass_dx_update(a0, X::mtrue());
         V rs0 = zero;
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             Side S; side_load(s, S, false);
             const V stp = ld(S.kl + X::isel(e_isd, X::isplat(RQ_D + 6 - RQ_RS), jin + RQ_U), 0);
@@ -580,22 +617,21 @@ struct RowQp {
             st(S.kl + o_ts, RQ_LAM, X::sel(S.act, mu0 * X::rcp(ts), zero), S.inb & e_in);
             // stationarity row of the pair: plain gradient (zero step only) - lam_lower + lam_upper
             const V ml = -(sgn * lb);
-            const V ref6 = X::gld(io.yref, (S.kl - RQ_RS) * 0 + X::isel(S.inb, sp + 2 * s, X::isplat(N - 1)) * 9 + 6);
+            const V ref6 = X::gld(io.yref, iyr + X::isel(S.inb, sp + 2 * s, X::isplat(N - 1)) * 9 + 6);
             const V gpl = X::sel(e_isd, splat(q.Qd[6]) * (vabs - ref6), rjin * (vabs - S.uref));
             const V row = fma(gsc, gpl, ml + X::swap1(ml));
             rs0 = X::vmaxnan(rs0, X::sel(S.stv & (e_in | S.act), X::vabs(row), zero));
         }
         // the other state rows (zero step only): w (dx + xbar - ref), k = 1..N; component 6 of stages 1..N-1 is covered above
+        RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             const I k1 = sp + (2 * s + 1);                         // stage index of the state row, 1..N
             const M in = (k1 <= N) & dxl;
             const I kc = X::isel(k1 <= N, k1, X::isplat(N));
             const M term = kc == N;
-            const V xb = X::gld(io.xbar, kc * 7 + o_dxu), dx = ld(kc * RQ_RS + o_dxu, RQ_DX);
-            const V rr = X::gld(io.yref, X::isel(term, X::isplat(0), kc) * 9 + o_dxu), re = X::gld(io.yref_e, o_dxu);
-            V w = zero, we = zero;
-            for (int i = 0; i < 7; ++i) { w = X::sel(side == i, splat(q.Qd[i]), w); we = X::sel(side == i, splat(q.Qe[i]), we); }
-            const V gx = X::sel(term, we, w) * (xb + dx - X::sel(term, re, rr));
+            const V xb = X::gld(io.xbar, ixb + kc * 7 + o_dxu), dx = ld(kc * RQ_RS + o_dxu, RQ_DX);
+            const V rr = X::gld(io.yref, iyr + X::isel(term, X::isplat(0), kc) * 9 + o_dxu), re = X::gld(io.yref_e, iye + o_dxu);
+            const V gx = X::sel(term, wesd, wsd) * (xb + dx - X::sel(term, re, rr));
             rs0 = X::vmaxnan(rs0, X::sel(in & (term | !(side == 6)), X::vabs(gsc * gx), zero));
         }
         return X::row_maxnan(rs0);
@@ -606,11 +642,12 @@ struct RowQp {
     // =================================================================================================================
     struct Result { M failed; I iters; V cost; V rmax; };
 
-    // valid: the row carries an instance to solve.  pi_out (may be 0): dynamics multipliers of the returned iterate.
-    RQ_FN void solve(M valid, Result& res, T* pi_out) {
+    // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the dynamics multipliers of the returned
+    // iterate, [B][N][7], to io.pi on the rows of pim.
+    RQ_FN void solve(M valid, Result& res, bool want_pi, M pim) {
         const V zero = splat((T)0), one = splat((T)1);
         // dx_0 = x0 - xbar_0 into rec(-1).DX ; rec(-1).D = 0
-        st(o_x + RQ_DX, 0, X::gld(io.x0, o_x) - X::gld(io.xbar, o_x), is_x);
+        st(o_x + RQ_DX, 0, X::gld(io.x0, ix0 + o_x) - X::gld(io.xbar, ixb + o_x), is_x);
         st(o_x + RQ_D, 0, zero, is_x);
         X::lds_fence();
         sweep_rollout(false);
@@ -643,6 +680,7 @@ struct RowQp {
         pass_e1(R);
         X::lds_fence();
         V step = splat((T)1e30), rmax_prev = zero, rmax_last = zero;
+        RQ_NOUNROLL
         for (int guard = 0; guard <= q.itmax; ++guard) {
             // every linear residual of a Newton iteration in residual form shrinks by (1 - alpha) per step; the inequality rows are
             // re-evaluated (R.rmax), the stationarity rows (which would need the dynamics multipliers) are tracked: rstat
@@ -692,7 +730,7 @@ struct RowQp {
         // ---- H6: expand the states from the input step through the linearised dynamics (as acados' expand step)
         sweep_rollout(true);
         X::lds_fence();
-        if (pi_out) (void)sweep_adjoint(pi_out);
+        if (want_pi) (void)sweep_adjoint(true, pim);
     }
 
     // full step, cost, outputs.  Call after solve(); `write`: rows whose iterate may be overwritten when the step is finite.
@@ -700,45 +738,46 @@ struct RowQp {
         const V zero = splat((T)0), half = splat((T)0.5);
         M bad = X::mfalse();
         V J = zero;
-        V w = zero, we = zero;
-        for (int i = 0; i < 7; ++i) { w = X::sel(side == i, splat(q.Qd[i]), w); we = X::sel(side == i, splat(q.Qe[i]), we); }
         // states: lanes (sp, i < 7) <-> x_{k}, k = 2s + sp over 0..N (record k - 1)
+        RQ_NOUNROLL
         for (int pass = 0; pass < 2; ++pass) {
             const M wr = write & !failed;
             if (pass == 1 && !X::any(wr)) break;
+            RQ_NOUNROLL
             for (int s = 0; 2 * s < N + 1; ++s) {
                 const I k = sp + 2 * s;
                 const M in = (k <= N) & dxl;
                 const I kc = X::isel(k <= N, k, X::isplat(N));
-                const V xb = X::gld(io.xbar, kc * 7 + o_dxu), dx = ld(kc * RQ_RS + o_dxu, RQ_DX);
+                const V xb = X::gld(io.xbar, ixb + kc * 7 + o_dxu), dx = ld(kc * RQ_RS + o_dxu, RQ_DX);
                 const V xn = xb + dx;
                 if (pass == 0) {
                     const M term = kc == N;
                     const I kr = X::isel(term, X::isplat(0), kc);
-                    const V rr = X::gld(io.yref, kr * 9 + o_dxu), re = X::gld(io.yref_e, o_dxu);
+                    const V rr = X::gld(io.yref, iyr + kr * 9 + o_dxu), re = X::gld(io.yref_e, iye + o_dxu);
                     const V e = xn - X::sel(term, re, rr);
-                    J = J + X::sel(in, half * X::sel(term, we, w) * e * e, zero);
+                    J = J + X::sel(in, half * X::sel(term, wesd, wsd) * e * e, zero);
                     bad = bad | (in & !(X::vabs(xn) <= splat(q.big)));
                 } else {
-                    X::gst(io.xbar, kc * 7 + o_dxu, xn, in & wr);
+                    X::gst(io.xbar, ixb + kc * 7 + o_dxu, xn, in & wr);
                 }
             }
+            RQ_NOUNROLL
             for (int s = 0; 2 * s < N; ++s) {
                 const I k = sp + 2 * s;
                 const M in = (k < N) & e_in & e_even;
                 const I kc = X::isel(k < N, k, X::isplat(N - 1));
-                const V ub = X::gld(io.ubar, kc * 2 + jin), du = ld((kc + 1) * RQ_RS + jin, RQ_DU);
+                const V ub = X::gld(io.ubar, iub + kc * 2 + jin), du = ld((kc + 1) * RQ_RS + jin, RQ_DU);
                 const V un = ub + du;
                 if (pass == 0) {
-                    const V ur = X::gld(io.yref, kc * 9 + 7 + jin);
+                    const V ur = X::gld(io.yref, iyr + kc * 9 + 7 + jin);
                     const V e = un - ur;
-                    const V lb = X::sel(jin == 0, splat(q.lbu[0]), splat(q.lbu[1])), ubd = X::sel(jin == 0, splat(q.ubu[0]), splat(q.ubu[1]));
+                    const V lb = lbj, ubd = ubj;
                     V j = half * rjin * e * e;
                     j = j + X::sel(un < lb, splat(q.rho_l) * (lb - un), zero) + X::sel(un > ubd, splat(q.rho_u) * (un - ubd), zero);
                     J = J + X::sel(in, j, zero);
                     bad = bad | (in & !(X::vabs(un) <= splat(q.big)));
                 } else {
-                    X::gst(io.ubar, kc * 2 + jin, un, in & wr);
+                    X::gst(io.ubar, iub + kc * 2 + jin, un, in & wr);
                 }
             }
             if (pass == 0) { failed = failed | X::row_or(bad); }
@@ -755,6 +794,7 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     const bool f32 = sizeof(T) == 4;
     q.N = c.N; q.itmax = c.ipm_iter_max; q.try_unc = c.ipm_try_unconstrained != 0.0 ? 1 : 0;
     q.h = (T)c.Ts;
+    RQ_UNROLL
     for (int i = 0; i < 7; ++i) { q.Qd[i] = (T)(c.Ts * c.W[i]); q.Qe[i] = (T)c.We[i]; }
     for (int j = 0; j < 2; ++j) { q.Rd[j] = (T)(c.Ts * c.W[7 + j]); q.lbu[j] = (T)c.lbu[j]; q.ubu[j] = (T)c.ubu[j]; }
     q.lbd = (T)c.lbx_delta; q.ubd = (T)c.ubx_delta;

@@ -113,14 +113,12 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
     std::vector<T> lds((size_t)(N + 1) * RQ_RS);
     for (int b = 0; b < B; ++b) {
         for (auto& v : lds) v = std::nan("");                    // any read of an unwritten slot that matters shows up
-        RqRow<T> io;
-        io.x0 = x0 + (size_t)b * 7; io.yref = yref + (size_t)b * N * 9; io.yref_e = yref_e + (size_t)b * 7;
-        io.GT = GT + (size_t)b * N * RQ_GTS; io.bl = bl + (size_t)b * N * 7;
-        io.xbar = xbar + (size_t)b * (N + 1) * 7; io.ubar = ubar + (size_t)b * N * 2;
+        RqArrays<T> io;
+        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi;
         typename X::Lds L{lds.data(), (int)lds.size()};
-        RowQp<X> S(q, io, L);
+        RowQp<X> S(q, io, L, X::isplat(b));
         typename RowQp<X>::Result res;
-        S.solve(X::mtrue(), res, pi ? pi + (size_t)b * N * 7 : nullptr);
+        S.solve(X::mtrue(), res, pi != nullptr, X::mtrue());
         typename X::M failed = res.failed;
         typename X::V J;
         S.finish(X::mtrue(), failed, J);

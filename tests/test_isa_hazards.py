@@ -12,15 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_no_readlane_or_dpp_hazard_in_compiled_kernels(tmp_path):
-    src = os.path.join(ROOT, "ad_mpc_amd", "csrc", "admpc_kernels.hip")
+    csrc = os.path.join(ROOT, "ad_mpc_amd", "csrc")
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import check_dpp_hazard
     import check_inflight
-    # the two translation units exactly as csrc/Makefile builds them, and the one-unit -O3 build used by the debug recipes
-    for name, flags in (("main", ["-O3", "-DADMPC_TU_MAIN"]), ("riccati", ["-O1", "-DADMPC_TU_RICCATI"]), ("single", ["-O3"])):
-        out = str(tmp_path / ("admpc_%s.s" % name))
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-DADMPC_WSYNC_FENCE_ONLY", "-std=c++17", "-S", "--cuda-device-only"] + flags +
-                       ["-o", out, src], check=True, capture_output=True, cwd=os.path.dirname(src))
+    # the two translation units exactly as csrc/Makefile builds them
+    for name in ("admpc_kernels", "admpc_rowqp"):
+        out = str(tmp_path / (name + ".s"))
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-DADMPC_WSYNC_FENCE_ONLY", "-std=c++17", "-O3", "-S", "--cuda-device-only",
+                        "-Wno-bitwise-instead-of-logical", "-o", out, os.path.join(csrc, name + ".hip")], check=True, capture_output=True, cwd=csrc)
         counts = check_dpp_hazard.count_hazards(out)
         assert counts[2] == 0, "%s: VALU write -> v_readlane of the same register / lane without a wait state: %r" % (name, counts)
         assert check_inflight.count(out) == 0, "%s: a register is read while its un-waited ds_read (column-head assembly) is still in flight" % name
