@@ -1507,6 +1507,7 @@ struct AdmpcSolver {
     double* d_aux;           // [cap][128]
     int* d_sched;            // [SCHED_HDR + SCHED_NB * cap] work scheduler of the persistent interior-point waves
     int qmask;               // 7 when only x, y, psi carry tracking weights (specialised condensing kernel), else 127
+    double* d_ws;            // [cap][N+1][36] workspace of the row kernel (sweep-private state, L2-resident)
 };
 
 static thread_local std::string g_err;
@@ -1518,10 +1519,10 @@ extern "C" int admpc_rowqp_plan(int N, int elem, int B, int num_cu, int* rows, i
 extern "C" void admpc_rowqp_prepare(void);
 extern "C" void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, int first, int* ticket);
+        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ws, int first, int* ticket);
 extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
-        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, int first, int* ticket);
+        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ws, int first, int* ticket);
 
 extern "C" {
 
@@ -1581,7 +1582,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         int r_, st_, lb_, g_;
         if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     }
-    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr;
+    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr;
     {   // ADMPC_QP=riccati forces the stage-wise Riccati kernel (A/B tests); default: condensed kernel where instantiated
         const char* e = getenv("ADMPC_QP");
         s->use_dense = (cfg->N == 20) && !(e && strcmp(e, "riccati") == 0);
@@ -1625,6 +1626,7 @@ void admpc_destroy(AdmpcSolver* s)
     if (s->d_status) (void)hipFree(s->d_status);
     if (s->d_H) (void)hipFree(s->d_H);
     if (s->d_aux) (void)hipFree(s->d_aux);
+    if (s->d_ws) (void)hipFree(s->d_ws);
     delete s;
 }
 
@@ -1640,6 +1642,8 @@ int admpc_reserve(AdmpcSolver* s, int B)
     if (s->d_H) (void)hipFree(s->d_H);
     if (s->d_aux) (void)hipFree(s->d_aux);
     if (s->d_sched) (void)hipFree(s->d_sched);
+    if (s->d_ws) (void)hipFree(s->d_ws);
+    s->d_ws = nullptr;
     s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_sched = nullptr; s->cap = 0;
     const size_t N = (size_t)s->cfg.N;
     HIPCHK(hipMalloc((void**)&s->d_GT, (size_t)B * N * GTS * sizeof(double)));
@@ -1650,7 +1654,8 @@ int admpc_reserve(AdmpcSolver* s, int B)
         HIPCHK(hipMalloc((void**)&s->d_aux, (size_t)B * 128 * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s->d_sched, ((size_t)SCHED_HDR + (size_t)SCHED_NB * B) * sizeof(int)));
     } else {
-        HIPCHK(hipMalloc((void**)&s->d_sched, (size_t)SCHED_HDR * sizeof(int)));       // [0]: instance counter of the Riccati kernel
+        HIPCHK(hipMalloc((void**)&s->d_sched, (size_t)SCHED_HDR * sizeof(int)));       // [0]: ticket counter of the row kernel
+        HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 36 * sizeof(double)));
     }
     s->cap = B;
     return ADMPC_OK;
@@ -1701,7 +1706,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
             int rows, stride, ldsb, gridR;
             if (admpc_rowqp_plan(N, 8, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
             admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
-                                   xbar, ubar, cost, stat, iters, (double*)nullptr, first, s->d_sched);
+                                   xbar, ubar, cost, stat, iters, (double*)nullptr, s->d_ws, first, s->d_sched);
         }
     }
     HIPCHK(hipGetLastError());

@@ -4,12 +4,14 @@
 // rowqp_core.h (shared with the CPU lane emulator of tests/emu), the lane primitives are rowqp_dev.h.
 //
 // Data placement
-//   HBM / L2 (read-only during the solve, streamed one stage ahead by every sweep): packed linearisation GT [B][N][7][6] and
-//     defects b [B][N][7] from the linearisation kernel, the iterate xbar / ubar, the references yref / yref_e.
-//   LDS: one record of RQ_RS values per stage and instance (interior-point state, gains, right-hand sides, steps): 480 B (fp64)
-//     / 240 B (fp32) per stage -> N = 20: 10 KB per instance, 4 waves per CU; N = 40 fp64 / N = 80 fp32: 19.7 KB, 2 waves per CU.
-//   Registers: the Riccati matrix P (7 values per lane), the stage linearisation of the current and the next stage, lane constants.
-//     No scratch.
+//   HBM / L2, read-only during the solve (streamed one stage ahead by every sweep): packed linearisation GT [B][N][7][6] and
+//     defects b [B][N][7] from the linearisation kernel, the references yref / yref_e; xbar / ubar at the start and the end.
+//   workspace [B][N+1][36] in global memory (L2 / Infinity Cache resident): what only the sweeps touch -- the absolute state,
+//     its Newton step, the feedback gains, the corrector's sigma-mu coefficients -- written by one sweep, streamed by the next.
+//   LDS: what the passes over the inequalities touch, 30 values per stage and instance (slacks, multipliers, inputs, right-hand
+//     sides and steps of the inputs / the steering angle): 240 B (fp64) / 120 B (fp32) per stage -> N = 40 fp64 / N = 80 fp32:
+//     9.7 KB per instance, four waves (16 instances) per CU, one wave per SIMD.
+//   Registers: the Riccati matrix P (7 values per lane), the stage data of the current and the next stage, lane constants.
 // Waves draw quadruples of instances from a ticket counter (zeroed by the linearisation kernel).  The four instances of a wave
 // iterate until the last of them has converged; finished rows are frozen by masks (their state is not rewritten).
 #include "rowqp_dev.h"
@@ -23,7 +25,7 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
                                                          const T* __restrict__ GTg, const T* __restrict__ blg,
                                                          T* __restrict__ xbarg, T* __restrict__ ubarg,
                                                          T* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
-                                                         T* __restrict__ pig, int first_pass, int* __restrict__ ticket)
+                                                         T* __restrict__ pig, T* __restrict__ wsg, int first_pass, int* __restrict__ ticket)
 {
     typedef DevX<T> X;
     extern __shared__ double smem_raw[];
@@ -32,17 +34,18 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
     RqParams<T> q;
     rq_make_params<T>(*cfg, q);
     RqArrays<T> io;
-    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig;
+    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig; io.ws = wsg;
     const int nquads = (B + rows - 1) / rows;
     const bool has_lds = row < rows;
     typename X::Lds lds{ smem + (has_lds ? row : 0) * inst_stride, has_lds };
 
     for (int quad = (int)blockIdx.x; quad < nquads;) {
         const int inst = quad * rows + row;
-        bool valid = has_lds && inst < B;
+        const bool owns = has_lds && inst < B;
+        bool valid = owns;
         const int ic = inst < B && has_lds ? inst : B - 1;                  // rows without an instance recompute the last one and write nothing
         if (!first_pass) valid = valid && statusg[ic] == 0;                 // failed in an earlier SQP iteration: left untouched
-        RowQp<X> S(q, io, lds, ic);
+        RowQp<X> S(q, io, lds, ic, owns);
         typename RowQp<X>::Result res;
         S.solve(valid, res, pig != nullptr, valid);
         bool failed = res.failed;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
             if (costg) costg[ic] = failed ? (T)INFINITY : J;
             if (itersg) itersg[ic] = res.iters;
         }
-        X::lds_fence();
+        X::fence();
         int v = 0;
         if (threadIdx.x == 0) v = atomicAdd(ticket, 1);
         quad = (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
 template <class T>
 static int rowqp_inst_stride(int N)
 {
-    int s = (N + 1) * RQ_RS;                                                // values of T, multiple of 4
+    int s = RQ_HDR + N * RQ_RS;                                             // values of T, even
     const int half = sizeof(T) == 8 ? 16 : 16;                              // fp64: 16 doubles = 128 B; fp32: 16 floats = 64 B
-    while (s % (2 * half) != half) s += 4;
+    while (s % (2 * half) != half) s += 2;
     return s;
 }
 
@@ -102,17 +105,17 @@ void admpc_rowqp_prepare(void)
 extern "C" __attribute__((visibility("hidden")))
 void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                             const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-                            double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, int first, int* ticket)
+                            double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ws, int first, int* ticket)
 {
     hipLaunchKernelGGL((admpc_rowqp_kernel<double>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                       xbar, ubar, cost, stat, iters, pi, first, ticket);
+                       xbar, ubar, cost, stat, iters, pi, ws, first, ticket);
 }
 
 extern "C" __attribute__((visibility("hidden")))
 void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                             const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
-                            float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, int first, int* ticket)
+                            float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ws, int first, int* ticket)
 {
     hipLaunchKernelGGL((admpc_rowqp_kernel<float>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                       xbar, ubar, cost, stat, iters, pi, first, ticket);
+                       xbar, ubar, cost, stat, iters, pi, ws, first, ticket);
 }

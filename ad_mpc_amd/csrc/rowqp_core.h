@@ -13,23 +13,29 @@
 // oracle/admpc_oracle.c (ipm_solve), reorganised:
 //   * the dynamics multipliers are not iterated.  The primal Newton step does not depend on them (their contribution to the
 //     stationarity residual telescopes over any direction that satisfies the linearised dynamics), so the right-hand sides are
-//     built with pi = 0; where a stationarity residual is needed (stopping test, iterate snapshot) the exact adjoint of the
-//     current point is swept backwards (sweep SA): residual = reduced gradient, as in the condensed N = 20 kernel.
+//     built with pi = 0.  Every linear residual of a Newton iteration in residual form shrinks by exactly (1 - alpha) per step:
+//     the stationarity residual of the stopping test is tracked from its start value instead of being re-evaluated; the
+//     multipliers themselves (iterate snapshot) are the exact adjoint of the returned point (sweep SA).
 //   * sl == t[2], su == t[3] (they start equal and receive identical steps), so they are not stored.
 //   * per-inequality work is organised by SIDE: a lane owns one bound of one input together with its slack pair
 //     (t_b, lam_b, t_s, lam_s), or one steering bound (t_b, lam_b); two stages per pass step (lanes 0-5 and 8-13).
+//   * the iterate is carried in absolute form (xa = xbar + dx, ua = ubar + du).
 //
 // Lane roles inside a row (lane l = 0..15):
 //   sweeps   l < 7: state component l (column l of P, K, A);  l = 7, 8: input 0, 1 (columns of B);  l >= 9 idle
 //   passes   l = 8*sp + side: stage parity sp, side 0..3 = (u0 lower, u0 upper, u1 lower, u1 upper), 4, 5 = steering lower, upper
 //
-// Per-stage record in LDS (RQ_RS values of T; record r = k + 1, k = -1 .. N-1):
-//   T[10] LAM[10]  slack / multiplier of bound pairs (side 0..5) and slack pairs (6 + side, side 0..3)      stage k
-//   DU[2]          input step of stage k                     DX[7]   state step of stage k+1
-//   K[7][2] LI[3]  feedback gains (column c: K0c, K1c), inverse of Huu of stage k
-//   U[2]           gu -> kff -> ddu of stage k               A[2]    Rt (barrier-augmented R) -> predictor ddu
-//   Q1             Qt of stage k -> predictor ddx6 of stage k        X   steering-barrier term of gx6 of stage k
-//   D[7]           ddx of stage k+1; between pass E2 and sweep S4: D[0..1] = sigma-mu coefficient of gu, D[2] = of gx6
+// Data placement per instance
+//   LDS, pass-private, RQ_RS values per stage k = 0..N-1 behind a 16-value dump header:
+//     T[10] LAM[10]  slack / multiplier of the bound pairs (side 0..5) and slack pairs (6 + side, side 0..3)
+//     UA[2]          input of stage k (absolute)        X6   steering angle of stage k (copy of XA_k[6])
+//     U[2]           gu -> kff -> ddu -> (corrector) gA -> kff -> ddu
+//     A[2]           Rt (barrier-augmented R) -> predictor ddu
+//     Q1             Qt -> predictor ddx6              X     steering-barrier term of gx6 -> (corrector) xA -> ddx6
+//   workspace in global memory (L2-resident, streamed one stage ahead by the sweeps), RQ_RW values per record r = 0..N:
+//     XA[7] state of stage r (absolute)   D[7] Newton step of the state of stage r
+//     K0[7] K1[7] LI[3]  feedback gains / inverse of Huu of stage r-1
+//     UB[2] XB           sigma-mu coefficients of the corrector right-hand side of stage r-1
 #pragma once
 
 #ifndef RQ_FN
@@ -39,12 +45,15 @@
 #define RQ_UNROLL
 #define RQ_NOUNROLL
 #endif
-
 #ifndef RQ_DBG
 #define RQ_DBG(...) do { } while (0)
 #endif
-#define RQ_RS 60
-enum { RQ_T = 0, RQ_LAM = 10, RQ_DU = 20, RQ_DX = 22, RQ_X = 29, RQ_K = 30, RQ_LI = 44, RQ_Q1 = 47, RQ_U = 48, RQ_A = 50, RQ_D = 52 };
+
+#define RQ_HDR 16
+#define RQ_RS 30
+enum { RQ_T = 0, RQ_LAM = 10, RQ_UA = 20, RQ_X6 = 22, RQ_X = 23, RQ_U = 24, RQ_A = 26, RQ_Q1 = 28 };
+#define RQ_RW 36
+enum { RW_XA = 0, RW_D = 8, RW_K0 = 16, RW_K1 = 23, RW_LI = 30, RW_UB = 33, RW_XB = 35 };
 #define RQ_GTS 42      // packed linearisation per stage: stored columns c' = 0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each
 
 template <class T>
@@ -61,9 +70,10 @@ struct RqParams {              // wave-uniform scalars
 };
 
 template <class T>
-struct RqArrays {              // wave-uniform array bases (device: kernel arguments, SGPR-addressed loads with 32-bit lane offsets)
+struct RqArrays {              // wave-uniform array bases (device: kernel arguments, SGPR-addressed accesses with 32-bit lane offsets)
     const T *x0, *yref, *yref_e, *GT, *bl;
     T *xbar, *ubar, *pi;
+    T *ws;                     // [B][N+1][RQ_RW]
 };
 
 template <class X>
@@ -76,9 +86,10 @@ struct RowQp {
 
     const RqParams<T>& q;
     const RqArrays<T>& io;
-    I ix0, iyr, iye, igt, ibl, ixb, iub;   // element offsets of the row's instance in the arrays
+    I ix0, iyr, iye, igt, ibl, ixb, iub, iws;   // element offsets of the row's instance in the arrays
     Lds lds;
     const int N;
+    M owns;                    // the row works on an instance of its own (rows that only shadow another row's instance never write its workspace)
 
     // ---- lane constants -------------------------------------------------------------------------------------------
     I lane;
@@ -89,20 +100,20 @@ struct RowQp {
     V lt2f;                    // 1 on lanes 0, 1
     V wq, wqe;                 // state weights of the lane (0 on lanes >= 7)
     V rjm;                     // Rd[j] on lanes 7, 8
-    I o_gc, o_gr, o_x, o_y, o_u, o_k;
-    I o1, o1sa, o2s1, o2s3, o2sa, o3sa;
+    I o_gc, o_gr, o_x, o_y, o_u, o_kr, o_ub;
+    I l_u, l_a, l_ua, l_l0;
     // passes
-    I sp, side, jin, o_tb, o_ts, o_vl, o_st, o_dxu;
+    I sp, side, jin, o_tb, o_ts, o_vl, o_sa, o_sc, o_o1, o_o2, o_dxu;
     M e_valid, e_isd, e_even, e_in, dxl;
-    V sgn, bound, rho, rjin, isdf;
-    V wsd, wesd, lbj, ubj;     // pass lanes (sp, i < 7): weights of state i; input lanes: bounds of input jin
+    V sgn, bound, rho, rjin, wsd, wesd, lbj, ubj, q6orr;
 
     RQ_FN V splat(T x) { return X::splat(x); }
 
-    // inst: index of the row's instance (row-uniform)
-    RQ_FN RowQp(const RqParams<T>& q_, const RqArrays<T>& io_, Lds lds_, I inst) : q(q_), io(io_), lds(lds_), N(q_.N)
+    // inst: index of the row's instance (row-uniform); owns_: it is this row's own instance
+    RQ_FN RowQp(const RqParams<T>& q_, const RqArrays<T>& io_, Lds lds_, I inst, M owns_) : q(q_), io(io_), lds(lds_), N(q_.N), owns(owns_)
     {
-        ix0 = inst * 7; iye = ix0; iyr = inst * (N * 9); igt = inst * (N * RQ_GTS); ibl = inst * (N * 7); ixb = inst * ((N + 1) * 7); iub = inst * (N * 2);
+        ix0 = inst * 7; iye = ix0; iyr = inst * (N * 9); igt = inst * (N * RQ_GTS); ibl = inst * (N * 7); ixb = inst * ((N + 1) * 7);
+        iub = inst * (N * 2); iws = inst * ((N + 1) * RQ_RW);
         lane = X::lane();
         is_x = lane < 7; is_u = (lane == 7) | (lane == 8); is6 = lane == 6; is7 = lane == 7; lt2 = lane < 2;
         const V one = splat((T)1), zero = splat((T)0);
@@ -123,14 +134,12 @@ struct RowQp {
         o_x = X::isel(is_x, lane, zi);
         o_y = X::isel(lane < 9, lane, zi);
         o_u = ju;
-        o_k = X::isel(is_x, lane * 2, X::isel(is_u, ju, zi));                       // K: lanes < 7 their pair, lanes 7, 8 row j (stride 2)
-        // sweep LDS offsets relative to k * RS
-        o1   = X::isel(is_x, lane + RQ_DX, X::isel(is_u, ju + (RQ_RS + RQ_U), X::isplat(RQ_DX)));
-        o1sa = X::isel(is_x, lane + RQ_DX, X::isel(is_u, ju + (RQ_RS + RQ_DU), X::isplat(RQ_DX)));
-        o2s1 = X::isel(is_u, ju + (RQ_RS + RQ_A), X::isplat(RQ_RS + RQ_X));
-        o2s3 = X::isel(is_u, ju + (RQ_RS + RQ_D), X::isplat(RQ_RS + RQ_X));
-        o2sa = X::isel(is_u, ju * 2 + (RQ_RS + RQ_LAM), X::isplat(RQ_RS + RQ_LAM + 4));
-        o3sa = o2sa + 1;
+        o_kr = ju * 7 + RW_K0;                                                      // forward sweeps, lanes 7, 8: row j of K
+        o_ub = X::isel(is_u, ju + RW_UB, X::isplat(RW_XB));                          // S3: lanes 7, 8 UB[j], lane 6 XB
+        l_u = ju + RQ_U;                                                            // LDS: U[j] (lanes 7, 8)
+        l_a = X::isel(is_u, ju + RQ_A, X::isplat(RQ_X));                            // LDS: A[j] (lanes 7, 8), X (lane 6)
+        l_ua = ju + RQ_UA;
+        l_l0 = X::isel(is_u, ju * 2 + RQ_LAM, X::isplat(RQ_LAM + 4));               // SA: lower-bound multiplier; upper = +1
         // pass lanes
         sp = lane >> 3; side = lane & 7;
         e_valid = side < 6; e_isd = (side >= 4) & e_valid; e_in = side < 4; e_even = (side & 1) == 0;
@@ -142,15 +151,19 @@ struct RowQp {
                        X::sel(jin == 0, X::sel(up, splat(q.ubu[0]), splat(q.lbu[0])), X::sel(up, splat(q.ubu[1]), splat(q.lbu[1]))));
         rho = X::sel(up, splat(q.rho_u), splat(q.rho_l));
         rjin = X::sel(jin == 0, splat(q.Rd[0]), splat(q.Rd[1]));
-        isdf = X::sel(e_isd, one, zero);
+        q6orr = X::sel(e_isd, splat(q.Qd[6]), rjin);
         wsd = zero; wesd = zero;
+        RQ_UNROLL
         for (int i = 0; i < 7; ++i) { wsd = X::sel(side == i, splat(q.Qd[i]), wsd); wesd = X::sel(side == i, splat(q.Qe[i]), wesd); }
         lbj = X::sel(jin == 0, splat(q.lbu[0]), splat(q.lbu[1])); ubj = X::sel(jin == 0, splat(q.ubu[0]), splat(q.ubu[1]));
         const I sidec = X::isel(e_valid, side, zi);
         o_tb = sidec;                                                               // bound pair of the side
         o_ts = X::isel(e_in, side + 6, sidec);                                      // slack pair (inputs), own pair otherwise
-        o_vl = X::isel(e_isd, X::isplat(RQ_DX + 6 - RQ_RS), jin + RQ_DU);           // steering: dx6 of stage k = rec(k-1).DX[6]
-        o_st = X::isel(e_isd, X::isplat(RQ_Q1), jin + RQ_U);                        // step slot: ddx6 predictor / U
+        o_vl = X::isel(e_isd, X::isplat(RQ_X6), jin + RQ_UA);                        // absolute value the side bounds: delta_k / u_kj
+        o_sa = X::isel(e_isd, X::isplat(RQ_Q1), jin + RQ_A);                         // predictor step slot
+        o_sc = X::isel(e_isd, X::isplat(RQ_X), jin + RQ_U);                          // (corrector / trial) step slot
+        o_o1 = o_sc;                                                                // pass outputs: X | U
+        o_o2 = o_sa;                                                                //               Q1 | A
         o_dxu = X::isel(dxl, side, zi);
     }
 
@@ -158,11 +171,14 @@ struct RowQp {
     RQ_FN V ld(I off, int imm) { return X::lds_ld(lds, off, imm); }
     RQ_FN void st(I off, int imm, V v, M m) { X::lds_st(lds, off, imm, v, m); }
     RQ_FN static V fma(V a, V b, V c) { return X::fma(a, b, c); }
+    RQ_FN static int rec(int k) { return RQ_HDR + k * RQ_RS; }
+    // workspace: written by one sweep / pass and read back by a later one of the same wave -> accessors of their own (the device
+    // reads it past the CU's L1, whose lines do not follow the wave's own stores)
+    RQ_FN V wld(I off, int imm) { return X::wld(io.ws, iws + off + imm); }
+    RQ_FN void wst(I off, int imm, V v, M m) { X::wst(io.ws, iws + off + imm, v, m & owns); }
 
     // column layout of stage k: Gc[l] = G[l][c] for the lane's column c (rows 0..5)
-    RQ_FN void load_gc(int k, V Gc[6]) {
-        X::gld6(io.GT, igt + o_gc + k * RQ_GTS, Gc);
-    }
+    RQ_FN void load_gc(int k, V Gc[6]) { X::gld6(io.GT, igt + o_gc + k * RQ_GTS, Gc); }
     RQ_FN void fix_gc(V Gc[6]) {          // lanes 0, 1: unit columns e0, e1 of A
         Gc[0] = fma(Gc[0], keepc, unitc[0]); Gc[1] = fma(Gc[1], keepc, unitc[1]);
         RQ_UNROLL
@@ -173,65 +189,83 @@ struct RowQp {
         RQ_UNROLL
         for (int c = 0; c < 7; ++c) Gr[c] = X::gld(io.GT, igt + o_gr + (k * RQ_GTS + c * 6));
     }
+    // zn = G_k zz (zz = (z_0..6, u_0, u_1) on lanes 0..8), rows 0..5 from Gr, row 6 structural (delta' = delta + h u1)
+    RQ_FN V apply_g(const V Gr[7], V zz) {
+        V zn = splat((T)0);
+        X::template dotbc<7, 2>(Gr, zz, zn);                     // columns 2..8
+        zn = fma(zz, lt2f, zn);                                  // unit columns 0, 1
+        const V u1 = X::template bc<8>(zz);
+        return X::sel(is6, fma(u1, splat(q.h), zz), zn);
+    }
+
     // =================================================================================================================
-    // sweeps
+    // sweeps (every loop loads the data of the next stage before it works on the current one)
     // =================================================================================================================
 
-    // gradient of the GN model at the point (lanes < 7: state k), stage k: w (dx_k + xbar_k - ref_k)
-    RQ_FN V gx_plain(V dxk, V xk, V rk, bool terminal) { return (terminal ? wqe : wq) * (dxk + xk - rk); }
-
-    // S0 / SF: states rolled out through the linearised dynamics, dx_{k+1} = A dx_k + B du_k + b_k (S0: du = 0)
+    // S0 / SF: states rolled out through the linearised dynamics, dx_{k+1} = A dx_k + B du_k + b_k, xa = xbar + dx (S0: du = 0)
     RQ_FN void sweep_rollout(bool with_du) {
-        V z = ld(o_x + RQ_DX, 0);                                  // dx_0 = rec(-1).DX
+        const V zero = splat((T)0);
+        V z;
+        {
+            const V x0v = X::gld(io.x0, ix0 + o_x);
+            z = x0v - X::gld(io.xbar, ixb + o_x);
+            wst(o_x + RW_XA, 0, x0v, is_x);
+            wst(o_x + RW_D, 0, zero, is_x);
+        }
         V Gr[7], Gn[7];
         load_gr(0, Gr);
-        V bk = X::gld(io.bl, ibl + o_x);
+        V bk = X::gld(io.bl, ibl + o_x), xk1 = X::gld(io.xbar, ixb + o_x + 7);
+        V uk = zero;
+        if (with_du) uk = ld(l_ua, rec(0)) - X::gld(io.ubar, iub + o_u);
         RQ_NOUNROLL
         for (int k = 0; k < N; ++k) {
             const int kn = k + 1 < N ? k + 1 : k;
             load_gr(kn, Gn);
-            const V bn = X::gld(io.bl, ibl + o_x + kn * 7);
-            V zz = X::sel(is_x, z, splat((T)0));
-            if (with_du) { const V du = ld(o_u + RQ_DU, (k + 1) * RQ_RS); zz = X::sel(is_x, z, du); }
-            V zn = splat((T)0);
-            X::template dotbc<7, 2>(Gr, zz, zn);
-            zn = fma(zz, lt2f, zn);
-            const V u1 = X::template bc<8>(zz);
-            zn = X::sel(is6, fma(u1, splat(q.h), zz), zn) + bk;
-            st(o_x + RQ_DX, (k + 1) * RQ_RS, zn, is_x);
+            const V bn = X::gld(io.bl, ibl + o_x + kn * 7), xn1 = X::gld(io.xbar, ixb + o_x + (kn + 1) * 7);
+            V un = zero;
+            if (with_du) un = ld(l_ua, rec(kn)) - X::gld(io.ubar, iub + o_u + kn * 2);
+            const V zz = X::sel(is_x, z, uk);
+            const V zn = apply_g(Gr, zz) + bk;
+            const V xa = xk1 + zn;
+            wst(o_x + RW_XA, (k + 1) * RQ_RW, xa, is_x);
+            if (k + 1 < N) st(X::isplat(RQ_X6), rec(k + 1), xa, is6);
             z = zn;
             RQ_UNROLL
             for (int c = 0; c < 7; ++c) Gr[c] = Gn[c];
-            bk = bn;
+            bk = bn; xk1 = xn1; uk = un;
         }
     }
 
-    // S1: backward Riccati sweep for the matrices, fused with the backward sweep of the gradient (gx from the point, X; gu = U).
-    //     Leaves K, LI, kff (in U).
+    // terminal values of the backward sweeps: gx_N = W_e (xa_N - yref_e) on lanes < 7
+    RQ_FN V terminal_gx() {
+        const V xN = wld(o_x + RW_XA, N * RQ_RW), rN = X::gld(io.yref_e, iye + o_x);
+        return X::sel(is_x, wqe * (xN - rN), splat((T)0));
+    }
+
+    // S1: backward Riccati sweep for the matrices, fused with the backward sweep of the gradient (gx from the point + X; gu = U).
+    //     Leaves K0, K1, LI (workspace) and kff (U).
     RQ_FN void sweep_factor() {
-        V P[7], p;
-        {
-            const V dxN = ld(o_x + RQ_DX, N * RQ_RS);             // dx_N = rec(N-1).DX
-            const V xN = X::gld(io.xbar, ixb + o_x + N * 7), rN = X::gld(io.yref_e, iye + o_x);
-            p = X::sel(is_x, wqe * (dxN + xN - rN), splat((T)0));
-            RQ_UNROLL
-            for (int i = 0; i < 7; ++i) P[i] = E[i] * wqe;
-        }
+        const V zero = splat((T)0);
+        V P[7], p = terminal_gx();
+        RQ_UNROLL
+        for (int i = 0; i < 7; ++i) P[i] = E[i] * wqe;
         V Gc[6], Gn[6];
         load_gc(N - 1, Gc);
-        V xk = X::gld(io.xbar, ixb + o_x + (N - 1) * 7), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
+        V xk = wld(o_x + RW_XA, (N - 1) * RQ_RW), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
+        V vu = ld(l_u, rec(N - 1)), va = ld(l_a, rec(N - 1)), vq = ld(X::isplat(RQ_Q1), rec(N - 1));
         RQ_NOUNROLL
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
-            const V xn = X::gld(io.xbar, ixb + o_x + kn * 7), rn = X::gld(io.yref, iyr + o_y + kn * 9);
-            const V v1 = ld(o1, k * RQ_RS);                        // lanes < 7: dx_k ; lanes 7, 8: gu
-            const V v2 = ld(o2s1, k * RQ_RS);                      // lane 6: X ; lanes 7, 8: Rt
-            const V v3 = ld(X::isplat(0), (k + 1) * RQ_RS + RQ_Q1);  // Qt
+            const V xn = wld(o_x + RW_XA, kn * RQ_RW), rn = X::gld(io.yref, iyr + o_y + kn * 9);
+            const V vun = ld(l_u, rec(kn)), van = ld(l_a, rec(kn)), vqn = ld(X::isplat(RQ_Q1), rec(kn));
             fix_gc(Gc);
-            const V g = X::sel(is_x, fma(wq, v1 + xk - rk, X::sel(is6, v2, splat((T)0))), v1);
-            const V wd = X::sel(is_x, X::sel(is6, v3, wq), v2);
-            V G7[7]; for (int l = 0; l < 6; ++l) G7[l] = Gc[l]; G7[6] = g6c;
+            const V g = X::sel(is_x, fma(wq, xk - rk, X::sel(is6, va, zero)), vu);
+            const V wd = X::sel(is_x, X::sel(is6, vq, wq), va);
+            V G7[7];
+            RQ_UNROLL
+            for (int l = 0; l < 6; ++l) G7[l] = Gc[l];
+            G7[6] = g6c;
             V Mm[7];
             X::pg(P, G7, Mm);
             V H[9];
@@ -241,164 +275,163 @@ struct RowQp {
             const V h00 = X::template bc<7>(H[7]), h01 = X::template bc<7>(H[8]), h11 = X::template bc<8>(H[8]);
             const V idet = X::rcp(h00 * h11 - h01 * h01);
             const V i00 = h11 * idet, i01 = -(h01 * idet), i11 = h00 * idet;
-            const V K0 = X::sel(is_x, -(i00 * H[7] + i01 * H[8]), splat((T)0));
-            const V K1 = X::sel(is_x, -(i01 * H[7] + i11 * H[8]), splat((T)0));
+            const V K0 = X::sel(is_x, -(i00 * H[7] + i01 * H[8]), zero);
+            const V K1 = X::sel(is_x, -(i01 * H[7] + i11 * H[8]), zero);
             X::schur(H, K0, K1);                                   // H[i] += bc7(H[i]) K0 + bc8(H[i]) K1, i < 7
             V hv = g;
             X::template dotbc<7, 0>(G7, p, hv);
             const V hu0 = X::template bc<7>(hv), hu1 = X::template bc<8>(hv);
             const V pn = fma(K1, hu1, fma(K0, hu0, hv));
             const V kff = X::sel(is7, -(i00 * hu0 + i01 * hu1), -(i01 * hu0 + i11 * hu1));
-            X::lds_st2(lds, o_k, (k + 1) * RQ_RS + RQ_K, K0, K1, is_x);
-            st(X::isplat(0), (k + 1) * RQ_RS + RQ_LI, i00, is7);
-            st(X::isplat(1), (k + 1) * RQ_RS + RQ_LI, i01, is7);
-            st(X::isplat(2), (k + 1) * RQ_RS + RQ_LI, i11, lane == 8);
-            st(o_u + RQ_U, (k + 1) * RQ_RS, kff, is_u);
+            wst(o_x + RW_K0, (k + 1) * RQ_RW, K0, is_x);
+            wst(o_x + RW_K1, (k + 1) * RQ_RW, K1, is_x);
+            wst(X::isplat(RW_LI), (k + 1) * RQ_RW, i00, is7);
+            wst(X::isplat(RW_LI + 1), (k + 1) * RQ_RW, i01, is7);
+            wst(X::isplat(RW_LI + 2), (k + 1) * RQ_RW, i11, lane == 8);
+            st(l_u, rec(k), kff, is_u);
             RQ_UNROLL
             for (int i = 0; i < 7; ++i) P[i] = H[i];
-            p = X::sel(is_x, pn, splat((T)0));
+            p = X::sel(is_x, pn, zero);
             RQ_UNROLL
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
-            xk = xn; rk = rn;
+            xk = xn; rk = rn; vu = vun; va = van; vq = vqn;
         }
     }
 
-    // S3: backward sweep of the gradient alone (corrector right-hand side: gu = U - smu * D[j], gx6 term = X - smu * D[2])
+    // S3: backward sweep of the gradient alone (corrector right-hand side: gu = U - smu * UB, gx6 term = X - smu * XB)
     RQ_FN void sweep_backward(V smu) {
-        V p;
-        {
-            const V dxN = ld(o_x + RQ_DX, N * RQ_RS);
-            const V xN = X::gld(io.xbar, ixb + o_x + N * 7), rN = X::gld(io.yref_e, iye + o_x);
-            p = X::sel(is_x, wqe * (dxN + xN - rN), splat((T)0));
-        }
+        const V zero = splat((T)0);
+        V p = terminal_gx();
         V Gc[6], Gn[6];
         load_gc(N - 1, Gc);
-        V xk = X::gld(io.xbar, ixb + o_x + (N - 1) * 7), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
+        V xk = wld(o_x + RW_XA, (N - 1) * RQ_RW), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
+        V vu = ld(l_u, rec(N - 1)), va = ld(l_a, rec(N - 1));
+        V vb = wld(o_ub, N * RQ_RW), k0 = wld(o_x + RW_K0, N * RQ_RW), k1 = wld(o_x + RW_K1, N * RQ_RW);
+        V i00 = wld(X::isplat(RW_LI), N * RQ_RW), i01 = wld(X::isplat(RW_LI + 1), N * RQ_RW), i11 = wld(X::isplat(RW_LI + 2), N * RQ_RW);
         RQ_NOUNROLL
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
-            const V xn = X::gld(io.xbar, ixb + o_x + kn * 7), rn = X::gld(io.yref, iyr + o_y + kn * 9);
-            const V v1 = ld(o1, k * RQ_RS);                        // dx_k | gA
-            const V v2 = ld(o2s3, k * RQ_RS);                      // lane 6: xA ; lanes 7, 8: gB
-            const V v3 = ld(X::isplat(0), (k + 1) * RQ_RS + RQ_D + 2);   // xB
-            V K0, K1;
-            X::lds_ld2(lds, o_k, (k + 1) * RQ_RS + RQ_K, K0, K1);
-            K0 = X::sel(is_x, K0, splat((T)0)); K1 = X::sel(is_x, K1, splat((T)0));
-            const V i00 = ld(X::isplat(0), (k + 1) * RQ_RS + RQ_LI), i01 = ld(X::isplat(1), (k + 1) * RQ_RS + RQ_LI),
-                    i11 = ld(X::isplat(2), (k + 1) * RQ_RS + RQ_LI);
+            const V xn = wld(o_x + RW_XA, kn * RQ_RW), rn = X::gld(io.yref, iyr + o_y + kn * 9);
+            const V vun = ld(l_u, rec(kn)), van = ld(l_a, rec(kn));
+            const V vbn = wld(o_ub, (kn + 1) * RQ_RW), k0n = wld(o_x + RW_K0, (kn + 1) * RQ_RW), k1n = wld(o_x + RW_K1, (kn + 1) * RQ_RW);
+            const V j00 = wld(X::isplat(RW_LI), (kn + 1) * RQ_RW), j01 = wld(X::isplat(RW_LI + 1), (kn + 1) * RQ_RW),
+                    j11 = wld(X::isplat(RW_LI + 2), (kn + 1) * RQ_RW);
             fix_gc(Gc);
-            const V g = X::sel(is_x, fma(wq, v1 + xk - rk, X::sel(is6, v2 - smu * v3, splat((T)0))), v1 - smu * v2);
-            V G7[7]; for (int l = 0; l < 6; ++l) G7[l] = Gc[l]; G7[6] = g6c;
+            const V K0 = X::sel(is_x, k0, zero), K1 = X::sel(is_x, k1, zero);
+            const V g = X::sel(is_x, fma(wq, xk - rk, X::sel(is6, va - smu * vb, zero)), vu - smu * vb);
+            V G7[7];
+            RQ_UNROLL
+            for (int l = 0; l < 6; ++l) G7[l] = Gc[l];
+            G7[6] = g6c;
             V hv = g;
             X::template dotbc<7, 0>(G7, p, hv);
             const V hu0 = X::template bc<7>(hv), hu1 = X::template bc<8>(hv);
             const V pn = fma(K1, hu1, fma(K0, hu0, hv));
             const V kff = X::sel(is7, -(i00 * hu0 + i01 * hu1), -(i01 * hu0 + i11 * hu1));
-            st(o_u + RQ_U, (k + 1) * RQ_RS, kff, is_u);
-            p = X::sel(is_x, pn, splat((T)0));
+            st(l_u, rec(k), kff, is_u);
+            p = X::sel(is_x, pn, zero);
             RQ_UNROLL
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
-            xk = xn; rk = rn;
+            xk = xn; rk = rn; vu = vun; va = van; vb = vbn; k0 = k0n; k1 = k1n; i00 = j00; i01 = j01; i11 = j11;
         }
     }
 
-    // SA: exact adjoint of the current point -> max-norm of the reduced gradient (the stationarity residual of the stopping
-    //     test).  Raw gradients: gu = R (u - uref) - lam_l + lam_u, gx = w (x - ref), steering multipliers on component 6.
-    //     With want_pi the adjoint (= dynamics multipliers pi_k of the iterate snapshot) is written there, [N][7].
+    // SA: exact adjoint of the current point: returns the max-norm of the reduced gradient and, with want_pi, writes the adjoint
+    //     (= dynamics multipliers pi_k of the iterate snapshot) to io.pi [B][N][7] on the rows of pim.
+    //     Raw gradients: gu = R (u - uref) - lam_l + lam_u, gx = w (x - ref), steering multipliers on component 6.
     RQ_FN V sweep_adjoint(bool want_pi, M pim) {
-        V lam;
-        {
-            const V dxN = ld(o_x + RQ_DX, N * RQ_RS);
-            const V xN = X::gld(io.xbar, ixb + o_x + N * 7), rN = X::gld(io.yref_e, iye + o_x);
-            lam = X::sel(is_x, wqe * (dxN + xN - rN), splat((T)0));
-        }
-        V rg = splat((T)0);
+        const V zero = splat((T)0);
+        V lam = terminal_gx();
+        V rg = zero;
         V Gc[6], Gn[6];
         load_gc(N - 1, Gc);
-        V xk = X::gld(io.xbar, ixb + o_x + (N - 1) * 7), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9), uk = X::gld(io.ubar, iub + o_u + (N - 1) * 2);
+        V xk = wld(o_x + RW_XA, (N - 1) * RQ_RW), rk = X::gld(io.yref, iyr + o_y + (N - 1) * 9);
         RQ_NOUNROLL
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
-            const V xn = X::gld(io.xbar, ixb + o_x + kn * 7), rn = X::gld(io.yref, iyr + o_y + kn * 9), un = X::gld(io.ubar, iub + o_u + kn * 2);
+            const V xn = wld(o_x + RW_XA, kn * RQ_RW), rn = X::gld(io.yref, iyr + o_y + kn * 9);
             if (want_pi) X::gst(io.pi, ibl + o_x + k * 7, lam, is_x & pim);   // pi_k multiplies dx_{k+1} = A dx_k + B du_k + b_k
-            const V v1 = ld(o1sa, k * RQ_RS);                      // dx_k | du_k
-            const V l0 = ld(o2sa, k * RQ_RS), l1 = ld(o3sa, k * RQ_RS);   // lane 6: steering pair; lanes 7, 8: bound pair of input j
+            const V ua = ld(l_ua, rec(k));
+            const V l0 = ld(l_l0, rec(k)), l1 = ld(l_l0, rec(k) + 1);        // lane 6: steering pair; lanes 7, 8: bound pair of input j
             fix_gc(Gc);
-            const V g = X::sel(is_x, fma(wq, v1 + xk - rk, X::sel(is6, l1 - l0, splat((T)0))), fma(rjm, v1 + uk - rk, l1 - l0));
-            V G7[7]; for (int l = 0; l < 6; ++l) G7[l] = Gc[l]; G7[6] = g6c;
+            const V g = X::sel(is_x, fma(wq, xk - rk, X::sel(is6, l1 - l0, zero)), fma(rjm, ua - rk, l1 - l0));
+            V G7[7];
+            RQ_UNROLL
+            for (int l = 0; l < 6; ++l) G7[l] = Gc[l];
+            G7[6] = g6c;
             V lv = g;
             X::template dotbc<7, 0>(G7, lam, lv);
-            rg = X::vmaxnan(rg, X::sel(is_u, X::vabs(lv), splat((T)0)));
-            lam = X::sel(is_x, lv, splat((T)0));
+            rg = X::vmaxnan(rg, X::sel(is_u, X::vabs(lv), zero));
+            lam = X::sel(is_x, lv, zero);
             RQ_UNROLL
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
-            xk = xn; rk = rn; uk = un;
+            xk = xn; rk = rn;
         }
         return X::row_maxnan(rg);
     }
 
     // S2 / S4: forward roll-out of the Newton step: ddu_k = K_k ddx_k + kff_k (into U), ddx_{k+1} = A ddx_k + B ddu_k.
-    //     full = false (predictor): only ddx6_{k+1} is kept (Q1);  full = true: ddx_{k+1} into D.
+    //     full = false (predictor): only ddx6_{k+1} is kept (Q1 of stage k+1);  full = true: ddx_{k+1} into D, ddx6 also into X.
     RQ_FN void sweep_forward(bool full) {
-        V z = splat((T)0);
-        V Gr[7], Gn[7];
+        const V zero = splat((T)0);
+        V z = zero;
+        V Gr[7], Gn[7], Kr[7], Kn[7];
         load_gr(0, Gr);
+        RQ_UNROLL
+        for (int c = 0; c < 7; ++c) Kr[c] = wld(o_kr, RQ_RW + c);
+        V kff = ld(l_u, rec(0));
         RQ_NOUNROLL
         for (int k = 0; k < N; ++k) {
             const int kn = k + 1 < N ? k + 1 : k;
             load_gr(kn, Gn);
-            V Kr[7];
             RQ_UNROLL
-            for (int c = 0; c < 7; ++c) Kr[c] = ld(o_u, (k + 1) * RQ_RS + RQ_K + 2 * c);     // lanes 7, 8: row j of K
-            const V kff = ld(o_u + RQ_U, (k + 1) * RQ_RS);
+            for (int c = 0; c < 7; ++c) Kn[c] = wld(o_kr, (kn + 1) * RQ_RW + c);
+            const V kfn = ld(l_u, rec(kn));
             V ddu = kff;
             X::template dotbc<7, 0>(Kr, z, ddu);
             const V zz = X::sel(is_x, z, ddu);
-            V zn = splat((T)0);
-            X::template dotbc<7, 2>(Gr, zz, zn);
-            zn = fma(zz, lt2f, zn);
-            const V u1 = X::template bc<8>(zz);
-            zn = X::sel(is6, fma(u1, splat(q.h), zz), zn);
-            st(o_u + RQ_U, (k + 1) * RQ_RS, ddu, is_u);
-            if (full) st(o_x + RQ_D, (k + 1) * RQ_RS, zn, is_x);
-            else if (k + 1 < N) st(X::isplat(0), (k + 2) * RQ_RS + RQ_Q1, zn, is6);     // predictor ddx6 of stage k+1, in ITS record
-            z = X::sel(is_x, zn, splat((T)0));
+            const V zn = apply_g(Gr, zz);
+            st(l_u, rec(k), ddu, is_u);
+            if (full) wst(o_x + RW_D, (k + 1) * RQ_RW, zn, is_x);
+            if (k + 1 < N) st(X::isplat(full ? RQ_X : RQ_Q1), rec(k + 1), zn, is6);
+            z = X::sel(is_x, zn, zero);
             RQ_UNROLL
-            for (int c = 0; c < 7; ++c) Gr[c] = Gn[c];
+            for (int c = 0; c < 7; ++c) { Gr[c] = Gn[c]; Kr[c] = Kn[c]; }
+            kff = kfn;
         }
     }
 
     // =================================================================================================================
-    // passes over the inequalities (lane = side, two stages per step)
+    // passes over the inequalities (lane = side, two stages per step; the loads of step s+1 are issued before step s is worked on)
     // =================================================================================================================
     struct Side {                 // what a side lane holds for its stage
         V tb, lb, ts, ls;         // slack / multiplier of the bound pair and of the slack pair (inputs)
-        V vabs, uref;             // ubar + du (inputs) or xbar6 + dx6 (steering); uref of the input
+        V vabs, uref;             // u_kj (inputs) or delta_k (steering); uref of the input
+        V sa, sc;                 // raw step slots: predictor (A | Q1) and corrector / trial (U | X)
         M act;                    // this side exists (stage < N, steering only on stages >= 1)
         M stv;                    // the even lane of the pair writes the stage outputs (stage < N)
         M inb;                    // valid side lane of a stage < N (whether or not the side exists)
-        int koff;                 // (k + 1) * RS of the EVEN stage of the step; lanes add sp * RS through kl
-        I kl;                     // per-lane record offset (clamped stage)
+        I kl;                     // LDS offset of the stage's record (clamped stage)
+        I kc;                     // clamped stage index
     };
 
-    RQ_FN void side_load(int s, Side& S, bool with_state) {
+    RQ_FN void side_load(int s, Side& S, bool with_state, bool with_steps) {
         const I k = sp + 2 * s;
         const M in = k < N;
-        const I kc = X::isel(in, k, X::isplat(N - 1));
-        S.kl = (kc + 1) * RQ_RS;
+        S.kc = X::isel(in, k, X::isplat(N - 1));
+        S.kl = S.kc * RQ_RS + RQ_HDR;
         S.act = e_valid & in & ((!e_isd) | (k >= 1));
         S.stv = e_valid & in & e_even;
         S.inb = e_valid & in;
-        const V ub = X::gld(io.ubar, iub + kc * 2 + jin), xb = X::gld(io.xbar, ixb + kc * 7 + 6);
-        S.uref = X::gld(io.yref, iyr + kc * 9 + 7 + jin);
-        const V vl = ld(S.kl + o_vl, 0);
-        S.vabs = X::sel(e_isd, xb, ub) + vl;
+        S.uref = X::gld(io.yref, iyr + S.kc * 9 + 7 + jin);
+        S.vabs = ld(S.kl + o_vl, 0);
         if (with_state) {
             S.tb = ld(S.kl + o_tb, RQ_T); S.lb = ld(S.kl + o_tb, RQ_LAM);
             S.ts = ld(S.kl + o_ts, RQ_T); S.ls = ld(S.kl + o_ts, RQ_LAM);
         }
+        if (with_steps) { S.sa = ld(S.kl + o_sa, 0); S.sc = ld(S.kl + o_sc, 0); }
     }
 
     struct Bar {                  // barrier quantities of a side
@@ -430,16 +463,20 @@ struct RowQp {
         const V ps = X::sel(S.act, sgn * B.psi, zero), rt = X::sel(S.act, B.Rtc, zero);
         const V gs = ps + X::swap1(ps), Rs = rt + X::swap1(rt);
         // inputs: U = R (u - uref) + gs, A = R + Rs ; steering: X = gs, Q1 = Qd6 + Rs
-        const V o1v = X::sel(e_isd, gs, fma(rjin, S.vabs - S.uref, gs));
-        const V o2v = X::sel(e_isd, splat(q.Qd[6]), rjin) + Rs;
-        st(S.kl + X::isel(e_isd, X::isplat(RQ_X), jin + RQ_U), 0, o1v, S.stv);
-        st(S.kl + X::isel(e_isd, X::isplat(RQ_Q1), jin + RQ_A), 0, o2v, S.stv);
+        st(S.kl + o_o1, 0, X::sel(e_isd, gs, fma(rjin, S.vabs - S.uref, gs)), S.stv);
+        st(S.kl + o_o2, 0, q6orr + Rs, S.stv);
     }
 
     RQ_FN void pass_e1(Red& R) {
         R.mu = splat((T)0); R.cmax = splat((T)0); R.rmax = splat((T)0);
+        Side S, Sn;
+        side_load(0, S, true, false);
         RQ_NOUNROLL
-        for (int s = 0; 2 * s < N; ++s) { Side S; side_load(s, S, true); e1_core(S, R); }
+        for (int s = 0; 2 * s < N; ++s) {
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, false);
+            e1_core(S, R);
+            S = Sn;
+        }
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);
     }
 
@@ -451,16 +488,18 @@ struct RowQp {
         P.dlb = -S.lb - B.Gb * P.dtb; P.dls = -S.ls - B.Gs * P.dts;
     }
 
-    // E2: after the predictor solve.  Ratio test + sum dt*dlam (per-lane partials), moves the predictor step out of U and
-    //     leaves the corrector right-hand side split as  gA - smu * gB  (U / D[0..1], X / D[2]).
+    // E2: after the predictor solve (ddu in U, ddx6 in Q1).  Ratio test + sum dt*dlam (per-lane partials), moves the predictor
+    //     step of the inputs to A and leaves the corrector right-hand side split as  gA - smu * gB  (U / UB, X / XB).
     RQ_FN void pass_e2(V& rr, V& s2) {
         const V zero = splat((T)0), one = splat((T)1);
         rr = zero; s2 = zero;
+        Side S, Sn;
+        side_load(0, S, true, true);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, true);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);
             Bar B; side_barrier(S, B);
-            const V stp = ld(S.kl + o_st, 0);                      // ddu_a (U) or ddx6_a (Q1)
+            const V stp = X::sel(e_isd, S.sa, S.sc);               // ddx6_a (Q1) | ddu_a (U)
             const V uua = sgn * stp;
             Step P; side_step_pred(S, B, uua, P);
             const V xb = P.dtb * B.itb, xs = P.dts * B.its;
@@ -475,16 +514,17 @@ struct RowQp {
             const V pa = X::sel(S.act, sgn * (B.psi + P1), zero), pb = X::sel(S.act, sgn * P2, zero);
             const V sa = pa + X::swap1(pa), sb = pb + X::swap1(pb);
             st(S.kl + jin + RQ_A, 0, stp, S.stv & e_in);                                              // predictor ddu
-            st(S.kl + X::isel(e_isd, X::isplat(RQ_X), jin + RQ_U), 0,
-               X::sel(e_isd, sa, fma(rjin, S.vabs - S.uref, sa)), S.stv);
-            st(S.kl + X::isel(e_isd, X::isplat(RQ_D + 2), jin + RQ_D), 0, sb, S.stv);
+            st(S.kl + o_o1, 0, X::sel(e_isd, sa, fma(rjin, S.vabs - S.uref, sa)), S.stv);
+            wst((S.kc + 1) * RQ_RW + X::isel(e_isd, X::isplat(RW_XB), jin + RW_UB), 0, sb, S.stv);
+            S = Sn;
         }
         rr = X::row_max(rr); s2 = X::row_sum(s2);
     }
 
     // corrector step of a side (predictor recomputed from its stored inputs)
-    RQ_FN void side_step_corr(const Side& S, const Bar& B, V uua, V uu, V smu, Step& C) {
+    RQ_FN void side_step_corr(const Side& S, const Bar& B, V smu, Step& C) {
         const V zero = splat((T)0);
+        const V uua = sgn * S.sa, uu = sgn * S.sc;
         Step P; side_step_pred(S, B, uua, P);
         const V mb = P.dtb * P.dlb, ms = P.dts * P.dls;
         const V cb = (mb - smu) * B.itb, cs = X::sel(e_isd, zero, (ms - smu) * B.its);
@@ -493,73 +533,75 @@ struct RowQp {
         C.dtb = uu + ds + B.rd; C.dts = ds;
         C.dlb = -(S.lb + cb) - B.Gb * C.dtb; C.dls = -(S.ls + cs) - B.Gs * C.dts;
     }
-    RQ_FN void side_steps_load(const Side& S, V& uua, V& uu) {
-        const V sa = ld(S.kl + X::isel(e_isd, X::isplat(RQ_Q1), jin + RQ_A), 0);               // predictor ddu / ddx6
-        const V sc = ld(S.kl + X::isel(e_isd, X::isplat(RQ_D + 6 - RQ_RS), jin + RQ_U), 0);    // corrector ddu / ddx6
-        uua = sgn * sa; uu = sgn * sc;
-    }
 
-    // E3a: ratio test of the corrector step
+    // E3a: ratio test of the corrector step (ddu in U, ddx6 in X; predictor steps in A, Q1)
     RQ_FN V pass_e3a(V smu) {
         const V zero = splat((T)0);
         V rr = zero;
+        Side S, Sn;
+        side_load(0, S, true, true);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, true);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);
             Bar B; side_barrier(S, B);
-            V uua, uu; side_steps_load(S, uua, uu);
-            Step C; side_step_corr(S, B, uua, uu, smu, C);
+            Step C; side_step_corr(S, B, smu, C);
             V r = X::vmax(-(C.dtb * B.itb), -(C.dlb * X::rcp(S.lb)));
             r = X::vmax(r, X::sel(e_isd, zero, X::vmax(-(C.dts * B.its), -(C.dls * X::rcp(S.ls)))));
             rr = X::vmax(rr, X::sel(S.act, r, zero));
+            S = Sn;
         }
         return X::row_max(rr);
     }
 
-    // dx += alpha ddx for every stage (lanes (sp, i < 7) <-> record 2s + sp)
+    // xa += alpha ddx for every stage (lanes (sp, i < 7) <-> record 2s + sp + 1); the steering angle is mirrored into the LDS record
     RQ_FN void pass_dx_update(V alpha, M rowact) {
+        const M go = rowact & (alpha > splat((T)0));
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             const I k = sp + 2 * s;
-            const M in = (k < N) & dxl;
-            const I kl = (X::isel(k < N, k, X::isplat(N - 1)) + 1) * RQ_RS + o_dxu;
-            const V dx = ld(kl, RQ_DX), dd = ld(kl, RQ_D);
-            st(kl, RQ_DX, fma(alpha, dd, dx), in & rowact & (alpha > splat((T)0)));
+            const M in = (k < N) & dxl & go;
+            const I kc = X::isel(k < N, k, X::isplat(N - 1));
+            const I wo = (kc + 1) * RQ_RW + o_dxu;
+            const V xa = wld(wo, RW_XA), dd = wld(wo, RW_D);
+            const V xn = fma(alpha, dd, xa);
+            wst(wo, RW_XA, xn, in);
+            st((kc + 1) * RQ_RS + RQ_HDR, RQ_X6, xn, in & (side == 6) & (k < N - 1));
         }
     }
 
-    // E3b + E1: apply the corrector step with step length alpha (0 on rows that are not iterating), then the quantities of
-    //     the next iteration from the updated state, still in registers.  Returns the per-lane max |alpha ddu| partial.
+    // E3b + E1: apply the corrector step with step length alpha on the rows of rowact, then the quantities of the next iteration
+    //     from the updated state, still in registers.  Returns the row's max |alpha ddu|.
     RQ_FN V pass_e3b_e1(V smu, V alpha, M rowact, Red& R) {
         const V zero = splat((T)0);
         V stp = zero;
         R.mu = zero; R.cmax = zero; R.rmax = zero;
+        Side S, Sn;
+        side_load(0, S, true, true);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, true);                         // old state, old dx6 (dx is stepped after this loop)
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);   // old state of the next step (its records are not written here)
             Bar B; side_barrier(S, B);
-            V uua, uu; side_steps_load(S, uua, uu);
-            Step C; side_step_corr(S, B, uua, uu, smu, C);
+            Step C; side_step_corr(S, B, smu, C);
             const V fl = splat(q.floor_);
             // rows that are not iterating keep their state bit for bit (their recomputed steps are never applied)
             S.tb = X::sel(rowact, X::vmax(fma(alpha, C.dtb, S.tb), fl), S.tb); S.lb = X::sel(rowact, X::vmax(fma(alpha, C.dlb, S.lb), fl), S.lb);
             S.ts = X::sel(rowact, X::vmax(fma(alpha, C.dts, S.ts), fl), S.ts); S.ls = X::sel(rowact, X::vmax(fma(alpha, C.dls, S.ls), fl), S.ls);
-            const V au = X::sel(rowact, alpha * (sgn * uu), zero);                               // alpha * ddu_j (inputs), alpha * ddx6 (steering)
+            const V au = X::sel(rowact, alpha * S.sc, zero);                 // alpha * ddu_j (inputs), alpha * ddx6 (steering)
             stp = X::vmax(stp, X::sel(S.act & e_in, X::vabs(au), zero));
             S.vabs = S.vabs + au;
-            const V dun = ld(S.kl + jin + RQ_DU, 0) + au;
-            st(S.kl + jin + RQ_DU, 0, dun, S.stv & e_in);
+            st(S.kl + jin + RQ_UA, 0, S.vabs, S.stv & e_in);
             st(S.kl + o_tb, RQ_T, S.tb, S.act); st(S.kl + o_tb, RQ_LAM, S.lb, S.act);
             st(S.kl + o_ts, RQ_T, S.ts, S.act & e_in); st(S.kl + o_ts, RQ_LAM, S.ls, S.act & e_in);
             e1_core(S, R);
+            S = Sn;
         }
         pass_dx_update(alpha, rowact);
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);
         return X::row_max(stp);
     }
 
-    // trial set-up: the QP without its inequalities from the start point (du = 0, rolled-out dx): U = R (ubar - uref), A = R,
-    // X = 0, Q1 = Qd6; also zeroes du
+    // trial set-up: the QP without its inequalities from the start point (ua = ubar, rolled-out states): U = R (ubar - uref), A = R,
+    // X = 0, Q1 = Qd6
     RQ_FN void pass_trial_setup() {
         const V zero = splat((T)0);
         RQ_NOUNROLL
@@ -567,45 +609,42 @@ struct RowQp {
             const I k = sp + 2 * s;
             const M in = k < N;
             const I kc = X::isel(in, k, X::isplat(N - 1));
-            const I kl = (kc + 1) * RQ_RS;
+            const I kl = kc * RQ_RS + RQ_HDR;
             const M stv = e_valid & in & e_even;
             const V ub = X::gld(io.ubar, iub + kc * 2 + jin), ur = X::gld(io.yref, iyr + kc * 9 + 7 + jin);
-            st(kl + X::isel(e_isd, X::isplat(RQ_X), jin + RQ_U), 0, X::sel(e_isd, zero, rjin * (ub - ur)), stv);
-            st(kl + X::isel(e_isd, X::isplat(RQ_Q1), jin + RQ_A), 0, X::sel(e_isd, splat(q.Qd[6]), rjin), stv);
-            st(kl + jin + RQ_DU, 0, zero, stv & e_in);
+            st(kl + o_o1, 0, X::sel(e_isd, zero, rjin * (ub - ur)), stv);
+            st(kl + o_o2, 0, q6orr, stv);
+            st(kl + jin + RQ_UA, 0, ub, stv & e_in);
         }
     }
 
-    // does the step in U / D respect every bound?  (trial: du = 0 before it)
+    // does the step in U / X respect every bound?
     RQ_FN M pass_trial_check() {
         M ok = X::mtrue();
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, false);
-            const V stp = ld(S.kl + X::isel(e_isd, X::isplat(RQ_D + 6 - RQ_RS), jin + RQ_U), 0);
-            const V qv = sgn * (S.vabs + stp - bound);
+            Side S; side_load(s, S, false, true);
+            const V qv = sgn * (S.vabs + S.sc - bound);
             ok = ok & ((!S.act) | (qv >= splat((T)0)));
         }
         return X::row_and(ok);
     }
 
-    // start of the interior point: du += a0 * ddu, dx += a0 * ddx (a0 = 1: from the trial's minimiser, 0: zero step), then
+    // start of the interior point: ua += a0 * ddu, xa += a0 * ddx (a0 = 1: from the trial's minimiser, 0: zero step), then
     // slacks and multipliers (th = clip level; warm: a violated input bound is absorbed by its slack).
     // Returns the max-norm of the stationarity residual of this start point, as the oracle's ipm_residuals() sees it: with the
     // zero step its dynamics multipliers are zero (ru = r - lam_l + lam_u, rx = Q dx + q + steering multipliers); from the
     // trial's minimiser they are that minimiser's exact multipliers, which leaves the inequality multipliers alone.
     RQ_FN V pass_init(V a0, V th, M warm) {
         const V zero = splat((T)0);
-        const V gsc = X::sel(a0 > zero, zero, splat((T)1));        // weight of the plain gradient in the residual
-        pass_dx_update(a0, X::mtrue());
+        const M step = a0 > zero;
+        const V gsc = X::sel(step, zero, splat((T)1));            // weight of the plain gradient in the residual
         V rs0 = zero;
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, false);
-            const V stp = ld(S.kl + X::isel(e_isd, X::isplat(RQ_D + 6 - RQ_RS), jin + RQ_U), 0);
-            const V au = X::sel(a0 > zero, stp, zero);
-            const V vabs = S.vabs + X::sel(e_isd, zero, au);       // steering: dx6 already updated
-            st(S.kl + jin + RQ_DU, 0, ld(S.kl + jin + RQ_DU, 0) + au, S.stv & e_in);
+            Side S; side_load(s, S, false, true);
+            const V vabs = S.vabs + X::sel(step, S.sc, zero);      // steering: X6 still holds the start point, X the trial's ddx6
+            st(S.kl + jin + RQ_UA, 0, vabs, S.stv & e_in);
             const V qv = sgn * (vabs - bound);
             const V ts = X::sel(warm, X::vmax(-qv, zero), zero) + th;
             const V tb = X::vmax(qv + X::sel(e_isd, zero, ts), th);
@@ -617,68 +656,60 @@ struct RowQp {
             st(S.kl + o_ts, RQ_LAM, X::sel(S.act, mu0 * X::rcp(ts), zero), S.inb & e_in);
             // stationarity row of the pair: plain gradient (zero step only) - lam_lower + lam_upper
             const V ml = -(sgn * lb);
-            const V ref6 = X::gld(io.yref, iyr + X::isel(S.inb, sp + 2 * s, X::isplat(N - 1)) * 9 + 6);
+            const V ref6 = X::gld(io.yref, iyr + S.kc * 9 + 6);
             const V gpl = X::sel(e_isd, splat(q.Qd[6]) * (vabs - ref6), rjin * (vabs - S.uref));
             const V row = fma(gsc, gpl, ml + X::swap1(ml));
             rs0 = X::vmaxnan(rs0, X::sel(S.stv & (e_in | S.act), X::vabs(row), zero));
         }
-        // the other state rows (zero step only): w (dx + xbar - ref), k = 1..N; component 6 of stages 1..N-1 is covered above
+        // the other state rows (zero step only): w (xa - ref), stages 1..N; component 6 of stages 1..N-1 is covered above
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            const I k1 = sp + (2 * s + 1);                         // stage index of the state row, 1..N
+            const I k1 = sp + (2 * s + 1);                         // stage of the state row, 1..N
             const M in = (k1 <= N) & dxl;
             const I kc = X::isel(k1 <= N, k1, X::isplat(N));
             const M term = kc == N;
-            const V xb = X::gld(io.xbar, ixb + kc * 7 + o_dxu), dx = ld(kc * RQ_RS + o_dxu, RQ_DX);
+            const V xa = wld(kc * RQ_RW + o_dxu, RW_XA);
             const V rr = X::gld(io.yref, iyr + X::isel(term, X::isplat(0), kc) * 9 + o_dxu), re = X::gld(io.yref_e, iye + o_dxu);
-            const V gx = X::sel(term, wesd, wsd) * (xb + dx - X::sel(term, re, rr));
+            const V gx = X::sel(term, wesd, wsd) * (xa - X::sel(term, re, rr));
             rs0 = X::vmaxnan(rs0, X::sel(in & (term | !(side == 6)), X::vabs(gsc * gx), zero));
         }
+        pass_dx_update(a0, X::mtrue());                            // after the loops above: they read the start point
         return X::row_maxnan(rs0);
     }
 
     // =================================================================================================================
-    // one instance: returns status / iterations / cost through the references (row-uniform)
+    // one instance
     // =================================================================================================================
-    struct Result { M failed; I iters; V cost; V rmax; };
+    struct Result { M failed; I iters; V rmax; };
 
     // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the dynamics multipliers of the returned
     // iterate, [B][N][7], to io.pi on the rows of pim.
     RQ_FN void solve(M valid, Result& res, bool want_pi, M pim) {
         const V zero = splat((T)0), one = splat((T)1);
-        // dx_0 = x0 - xbar_0 into rec(-1).DX ; rec(-1).D = 0
-        st(o_x + RQ_DX, 0, X::gld(io.x0, ix0 + o_x) - X::gld(io.xbar, ixb + o_x), is_x);
-        st(o_x + RQ_D, 0, zero, is_x);
-        X::lds_fence();
         sweep_rollout(false);
-        X::lds_fence();
+        X::fence();
         M active = valid, failed = X::mfalse();
         I iters = X::isplat(0);
         V rstat;                                                   // stationarity residual of the interior point's iterate (tracked)
+        pass_trial_setup();
+        X::fence();
         if (q.try_unc) {
-            pass_trial_setup();
-            X::lds_fence();
             sweep_factor();
-            X::lds_fence();
+            X::fence();
             sweep_forward(true);
-            X::lds_fence();
+            X::fence();
             const M ok = pass_trial_check();
             const M warm = (!ok) & X::mfrom(q.thw > (T)0);
             const V a0 = X::sel(ok | warm, one, zero);
             rstat = pass_init(a0, X::sel(warm, splat(q.thw), splat(q.thr)), warm);
             active = active & !ok;
         } else {
-            pass_trial_setup();                                    // zeroes du
-            X::lds_fence();
-            st(o_x + RQ_D, 0, zero, is_x);
-            for (int k = 0; k < N; ++k) { st(o_x + RQ_D, (k + 1) * RQ_RS, zero, is_x); st(o_u + RQ_U, (k + 1) * RQ_RS, zero, is_u); }
-            X::lds_fence();
             rstat = pass_init(zero, splat(q.thr), X::mfalse());
         }
-        X::lds_fence();
+        X::fence();
         Red R;
         pass_e1(R);
-        X::lds_fence();
+        X::fence();
         V step = splat((T)1e30), rmax_prev = zero, rmax_last = zero;
         RQ_NOUNROLL
         for (int guard = 0; guard <= q.itmax; ++guard) {
@@ -697,12 +728,12 @@ struct RowQp {
             if (!X::any(active)) break;
             // ---- predictor
             sweep_factor();
-            X::lds_fence();
+            X::fence();
             sweep_forward(false);
-            X::lds_fence();
+            X::fence();
             V rr, s2;
             pass_e2(rr, s2);
-            X::lds_fence();
+            X::fence();
             const V a_aff = X::sel(rr > one, X::rcp(rr), one);
             const V munq = R.mu;                                    // = mu * nineq
             const V mu_aff = ((one - a_aff) * munq + a_aff * a_aff * s2) * splat(q.inv_nineq);
@@ -711,17 +742,16 @@ struct RowQp {
             RQ_DBG("[emu] it mu=%.6e cmax=%.3e rmax=%.3e a_aff=%.6e mu_aff=%.6e sigma=%.6e\n", X::first(mu), X::first(R.cmax), X::first(rmax), X::first(a_aff), X::first(mu_aff), X::first(sigma));
             // ---- corrector
             sweep_backward(smu);
-            X::lds_fence();
+            X::fence();
             sweep_forward(true);
-            X::lds_fence();
+            X::fence();
             const V rc = pass_e3a(smu);
             const V amax = X::sel(rc > one, X::rcp(rc), one);
             V tau = one - mu_aff; tau = X::vmax(tau, splat((T)0.995)); tau = X::vmin(tau, splat((T)0.999999));
             const V alpha = X::sel(active, X::vmin(tau * amax, one), zero);
             RQ_DBG("[emu]      alpha=%.6e\n", X::first(alpha));
             const V stn = pass_e3b_e1(smu, alpha, active, R);
-            X::lds_fence();
-            RQ_DBG("[emu]      step=%.6e\n", X::first(stn));
+            X::fence();
             step = X::sel(active, stn, step);
             rstat = X::sel(active, (one - alpha) * rstat, rstat);
             iters = iters + X::isel(active, X::isplat(1), X::isplat(0));
@@ -729,7 +759,7 @@ struct RowQp {
         res.failed = failed; res.iters = iters; res.rmax = rmax_last;
         // ---- H6: expand the states from the input step through the linearised dynamics (as acados' expand step)
         sweep_rollout(true);
-        X::lds_fence();
+        X::fence();
         if (want_pi) (void)sweep_adjoint(true, pim);
     }
 
@@ -738,18 +768,17 @@ struct RowQp {
         const V zero = splat((T)0), half = splat((T)0.5);
         M bad = X::mfalse();
         V J = zero;
-        // states: lanes (sp, i < 7) <-> x_{k}, k = 2s + sp over 0..N (record k - 1)
         RQ_NOUNROLL
         for (int pass = 0; pass < 2; ++pass) {
             const M wr = write & !failed;
             if (pass == 1 && !X::any(wr)) break;
+            // states: lanes (sp, i < 7) <-> x_k, k = 2s + sp over 0..N
             RQ_NOUNROLL
             for (int s = 0; 2 * s < N + 1; ++s) {
                 const I k = sp + 2 * s;
                 const M in = (k <= N) & dxl;
                 const I kc = X::isel(k <= N, k, X::isplat(N));
-                const V xb = X::gld(io.xbar, ixb + kc * 7 + o_dxu), dx = ld(kc * RQ_RS + o_dxu, RQ_DX);
-                const V xn = xb + dx;
+                const V xn = wld(kc * RQ_RW + o_dxu, RW_XA);
                 if (pass == 0) {
                     const M term = kc == N;
                     const I kr = X::isel(term, X::isplat(0), kc);
@@ -766,14 +795,12 @@ struct RowQp {
                 const I k = sp + 2 * s;
                 const M in = (k < N) & e_in & e_even;
                 const I kc = X::isel(k < N, k, X::isplat(N - 1));
-                const V ub = X::gld(io.ubar, iub + kc * 2 + jin), du = ld((kc + 1) * RQ_RS + jin, RQ_DU);
-                const V un = ub + du;
+                const V un = ld(kc * RQ_RS + RQ_HDR + jin, RQ_UA);
                 if (pass == 0) {
                     const V ur = X::gld(io.yref, iyr + kc * 9 + 7 + jin);
                     const V e = un - ur;
-                    const V lb = lbj, ubd = ubj;
                     V j = half * rjin * e * e;
-                    j = j + X::sel(un < lb, splat(q.rho_l) * (lb - un), zero) + X::sel(un > ubd, splat(q.rho_u) * (un - ubd), zero);
+                    j = j + X::sel(un < lbj, splat(q.rho_l) * (lbj - un), zero) + X::sel(un > ubj, splat(q.rho_u) * (un - ubj), zero);
                     J = J + X::sel(in, j, zero);
                     bad = bad | (in & !(X::vabs(un) <= splat(q.big)));
                 } else {
@@ -794,7 +821,6 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     const bool f32 = sizeof(T) == 4;
     q.N = c.N; q.itmax = c.ipm_iter_max; q.try_unc = c.ipm_try_unconstrained != 0.0 ? 1 : 0;
     q.h = (T)c.Ts;
-    RQ_UNROLL
     for (int i = 0; i < 7; ++i) { q.Qd[i] = (T)(c.Ts * c.W[i]); q.Qe[i] = (T)c.We[i]; }
     for (int j = 0; j < 2; ++j) { q.Rd[j] = (T)(c.Ts * c.W[7 + j]); q.lbu[j] = (T)c.lbu[j]; q.ubu[j] = (T)c.ubu[j]; }
     q.lbd = (T)c.lbx_delta; q.ubd = (T)c.ubx_delta;

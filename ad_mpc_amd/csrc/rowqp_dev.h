@@ -43,8 +43,7 @@ struct DevCommon {
     RQ_FN static V vabs(V a) { return __builtin_fabs(a); }
     RQ_FN static V vmaxnan(V a, V b) { return (b > a || b != b) ? b : a; }
     // memory
-    // Masked stores are unconditional stores whose address is redirected to a dump slot of the lane (record -1 of the row keeps
-    // only DX and D: its first 20 values are never read) -- one v_cndmask instead of an EXEC save / branch / restore per store.
+    // Masked stores are unconditional stores whose address is redirected to a dump slot of the lane (the 16-value header of the row's LDS region) -- one v_cndmask instead of an EXEC save / branch / restore per store.
     RQ_FN static V lds_ld(const Lds& L, I off, int imm) { return L.base[off + imm]; }
     RQ_FN static void lds_st(const Lds& L, I off, int imm, V v, M m) { L.base[(m && L.ok) ? off + imm : (int)(threadIdx.x & 15u)] = v; }
     RQ_FN static void lds_ld2(const Lds& L, I off, int imm, V& a, V& b) { a = L.base[off + imm]; b = L.base[off + imm + 1]; }
@@ -52,14 +51,22 @@ struct DevCommon {
         const int o = (m && L.ok) ? off + imm : (int)(threadIdx.x & 14u);
         L.base[o] = a; L.base[o + 1] = b;
     }
-    RQ_FN static void lds_fence() {
+    // orders what one sweep / pass wrote (LDS records, workspace in global memory) before what the next one reads: one wave per
+    // workgroup, so a compiler-level fence plus the wave's own memory counters
+    RQ_FN static void fence() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     // global arrays: uniform base + 32-bit byte offset of the lane (global_load ... v_off, s[base:base+1]); the host splits
     // batches whose arrays would exceed 4 GB
     RQ_FN static const T* gaddr(const T* p, I off) { return (const T*)((const char*)p + (unsigned)off * (unsigned)sizeof(T)); }
     RQ_FN static V gld(const T* p, I off) { return *gaddr(p, off); }
     RQ_FN static void gst(T* p, I off, V v, M m) { if (m) *(T*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; }
+    // workspace accesses.  A wave reads back what it stored itself, several sweeps later; the CU's vector L1 keeps the line it
+    // loaded before that store (measured: stale states after the roll-out, run-to-run different results), so these loads are
+    // agent-scope relaxed loads (global_load ... sc1: served by the L2, which the write-through stores have updated).
+    RQ_FN static V wld(const T* p, I off) { return __hip_atomic_load(gaddr(p, off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    RQ_FN static void wst(T* p, I off, V v, M m) { if (m) *(T*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; }
     // row-uniform logic through the wave ballot
     RQ_FN static unsigned rowbits(M m) {
         const unsigned long long b = __ballot(m);

@@ -1,0 +1,24 @@
+"""Driver for profiling kernel R: python scripts/run_rowqp.py N B [steps] [dtype] -- repeated solves of one synthetic batch."""
+import os, sys, time, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+os.environ.setdefault("ADMPC_QP", "riccati")
+from ad_mpc_amd.config import default_config
+from ad_mpc_amd.engine import BatchSolver
+from ad_mpc_amd.scenarios import random_scenarios
+N = int(sys.argv[1]); B = int(sys.argv[2]); steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+cfg = default_config(N=N)
+s = random_scenarios(B, N=N, seed=1234)
+eng = BatchSolver(cfg, device=0)
+d = eng.to_device
+tx0, tyr, tye, tp = d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"])
+x0b, u0b = d(s["xbar"]), d(s["ubar"])
+cost = torch.empty(B, dtype=torch.float64, device="cuda"); st = torch.empty(B, dtype=torch.int32, device="cuda"); it = torch.empty(B, dtype=torch.int32, device="cuda")
+ts = []
+for rep in range(steps + 2):
+    x = x0b.clone(); u = u0b.clone()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.solve(tx0, tyr, tye, tp, x, u, cost, st, it)
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+t = np.median(ts[2:])
+itc = it.cpu().numpy()
+print("N %d B %d: %.3f ms/step %.3f M solves/s; iters mean %.2f max %d; quad-max mean %.2f" % (N, B, t * 1e3, B / t / 1e6, itc.mean(), itc.max(), itc[: B // 4 * 4].reshape(-1, 4).max(1).mean()))

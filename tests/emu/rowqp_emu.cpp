@@ -65,10 +65,12 @@ struct EmuX {
     static void lds_st(const Lds& L, const I& off, int imm, const V& v, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) { chk(L, off.v[l] + imm); L.base[off.v[l] + imm] = v.v[l]; } }
     static void lds_ld2(const Lds& L, const I& off, int imm, V& a, V& b) { a = lds_ld(L, off, imm); b = lds_ld(L, off, imm + 1); }
     static void lds_st2(const Lds& L, const I& off, int imm, const V& a, const V& b, const M& m) { lds_st(L, off, imm, a, m); lds_st(L, off, imm + 1, b, m); }
-    static void lds_fence() {}
+    static void fence() {}
     static V gld(const T* p, const I& off) { V r; for (int l = 0; l < NL; ++l) r.v[l] = p[off.v[l]]; return r; }
     static void gld6(const T* p, const I& off, V out[6]) { for (int i = 0; i < 6; ++i) for (int l = 0; l < NL; ++l) out[i].v[l] = p[off.v[l] + i]; }
     static void gst(T* p, const I& off, const V& v, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) p[off.v[l]] = v.v[l]; }
+    static V wld(const T* p, const I& off) { return gld(p, off); }
+    static void wst(T* p, const I& off, const V& v, const M& m) { gst(p, off, v, m); }
     // cross-lane
     template <int L> static V bc(const V& a) { return splat(a.v[L]); }
     static V swap1(const V& a) { V r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l ^ 1]; return r; }
@@ -110,13 +112,14 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
     typedef EmuX<T> X;
     const int N = cfg->N;
     RqParams<T> q; rq_make_params<T>(*cfg, q);
-    std::vector<T> lds((size_t)(N + 1) * RQ_RS);
+    std::vector<T> lds((size_t)RQ_HDR + (size_t)N * RQ_RS), ws((size_t)(N + 1) * RQ_RW);
     for (int b = 0; b < B; ++b) {
         for (auto& v : lds) v = std::nan("");                    // any read of an unwritten slot that matters shows up
+        for (auto& v : ws) v = std::nan("");
         RqArrays<T> io;
-        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi;
+        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi; io.ws = ws.data() - (size_t)b * (N + 1) * RQ_RW;
         typename X::Lds L{lds.data(), (int)lds.size()};
-        RowQp<X> S(q, io, L, X::isplat(b));
+        RowQp<X> S(q, io, L, X::isplat(b), X::mtrue());
         typename RowQp<X>::Result res;
         S.solve(X::mtrue(), res, pi != nullptr, X::mtrue());
         typename X::M failed = res.failed;
