@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmpc.so")
 
 EXPORTS = (
-    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_shoot_batch",
+    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_f32", "admpc_shoot_batch",
     "admpc_argmin", "admpc_argmin_pairs", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
 )
 
@@ -40,6 +40,8 @@ def load():
     L.admpc_reserve.argtypes = [C.c_void_p, C.c_int]; L.admpc_reserve.restype = C.c_int
     L.admpc_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     L.admpc_solve_batch.restype = C.c_int
+    L.admpc_solve_batch_f32.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
+    L.admpc_solve_batch_f32.restype = C.c_int
     L.admpc_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, vp]; L.admpc_shoot_batch.restype = C.c_int
     L.admpc_argmin.argtypes = [C.c_void_p, dp, C.c_int, C.c_int64, dp, ip, vp]; L.admpc_argmin.restype = C.c_int
     L.admpc_argmin_pairs.argtypes = [C.c_void_p, dp, C.c_int, dp, ip, vp]; L.admpc_argmin_pairs.restype = C.c_int

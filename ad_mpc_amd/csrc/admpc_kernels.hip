@@ -33,11 +33,12 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // model: f and the non-zero pattern of its Jacobians (ad_3d_optimizer.py:280-310)
 // ---------------------------------------------------------------------------------------------
-struct ModelEval {
-    double f[NX];
-    double j0[3], j1[3];      // rows 0,1 of Jx over (psi, vx, vy)
-    double a[3][4];           // rows 3,4,5 of Jx over (vx, vy, psi_dot, delta)
-    double bu[3][2];          // rows 3,4,5 of Ju
+template <class T>
+struct ModelEvalT {
+    T f[NX];
+    T j0[3], j1[3];           // rows 0,1 of Jx over (psi, vx, vy)
+    T a[3][4];                // rows 3,4,5 of Jx over (vx, vy, psi_dot, delta)
+    T bu[3][2];               // rows 3,4,5 of Ju
 };
 
 // sin and cos of a moderate argument (|x| < ~1e4: yaw angles, steering angles) in ~35 fp64 instructions: Cody-Waite reduction by
@@ -62,6 +63,8 @@ __device__ __forceinline__ void sincos_small(const double x, double* sn, double*
     *sn = (q & 2) ? -sq : sq;
     *cs = ((q + 1) & 2) ? -cq : cq;
 }
+// fp32: the library routine (1-2 ulp over the whole range)
+__device__ __forceinline__ void sincos_small(const float x, float* sn, float* cs) { sincosf(x, sn, cs); }
 
 // exp(x) for x <= 0 (the squared-exponential kernel): x = k ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (remainder
 // < 4e-18), v_ldexp_f64.  ~20 instructions; underflows to 0 like libm.
@@ -76,31 +79,39 @@ __device__ __forceinline__ double exp_nonpos(const double x) {
     p = fma(p, r, 1.6666666666666666e-01); p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
     return ldexp(p, (int)fmax(k, -1100.0));
 }
+__device__ __forceinline__ float exp_nonpos(const float x) { return expf(x); }
 
 // Mean and derivative of one 1-D squared-exponential GP.  The three threads of a stage (adjacent lanes 3m, 3m+1, 3m+2: the
 // kernel maps 63 tasks to a wave) integrate the same state, so they evaluate the same GP: each takes every third training
 // point and the partial sums are combined by lane shuffles, in the same order on all three lanes (identical results).
-__device__ __forceinline__ void gp_eval(const AdmpcGp& g, double z, double& mu, double& dmu) {
-    double m = 0.0, d = 0.0;
+template <class T>
+__device__ __forceinline__ void gp_eval(const AdmpcGp& g, T z, T& mu, T& dmu) {
+    T m = 0, d = 0;
     const int n = g.n_points;
     const int lane = threadIdx.x & 63, sub = lane - 3 * (int)(((unsigned)lane * 21846u) >> 16), base = lane - sub;   // lane % 3 without a narrow urem (see div7)
+    const T sf = (T)g.sigma_f, il2 = (T)g.inv_l2;
     for (int i = sub; i < n; i += 3) {
-        const double dz = z - g.Z[i];
-        const double k = g.sigma_f * exp_nonpos(-0.5 * dz * dz * g.inv_l2);
-        m += k * g.alpha[i];
-        d -= k * dz * g.inv_l2 * g.alpha[i];
+        const T dz = z - (T)g.Z[i];
+        const T k = sf * exp_nonpos((T)-0.5 * dz * dz * il2);
+        m += k * (T)g.alpha[i];
+        d -= k * dz * il2 * (T)g.alpha[i];
     }
-    const double m0 = __shfl(m, base), m1 = __shfl(m, base + 1), m2 = __shfl(m, base + 2);
-    const double d0 = __shfl(d, base), d1 = __shfl(d, base + 1), d2 = __shfl(d, base + 2);
-    mu = (m0 + m1) + m2 + g.ymean; dmu = (d0 + d1) + d2;
+    const T m0 = __shfl(m, base), m1 = __shfl(m, base + 1), m2 = __shfl(m, base + 2);
+    const T d0 = __shfl(d, base), d1 = __shfl(d, base + 1), d2 = __shfl(d, base + 2);
+    mu = (m0 + m1) + m2 + (T)g.ymean; dmu = (d0 + d1) + d2;
 }
 
-__device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, const double* x, const double* u, double p, ModelEval& e)
+// T = float: the reference's "+ 1e-99" in the slip-angle denominators (ad_3d_optimizer.py:290,296-297) is 0 in fp32, and with
+// v_x = 0 the dynamic branch would be inf * 0 = NaN even when the blend parameter p switches it off.  The fp32 instantiation
+// therefore drops the dynamic branch altogether when p == 0 (the shipped blend speeds: pure kinematic model) and keeps the
+// blended value for 0 < p <= 1 (hard parts).
+template <class T>
+__device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, const T* x, const T* u, T p, ModelEvalT<T>& e)
 {
-    const double psi = x[2], vx = x[3], vy = x[4], r = x[5], dl = x[6];
-    const double m = c->mass, LF = c->L_F, LR = c->L_R, Iz = c->Iz, Cf = c->Cf, Cr = c->Cr;
-    const double L = LR + LF;
-    double sp, cp, sd, cd;
+    const T psi = x[2], vx = x[3], vy = x[4], r = x[5], dl = x[6];
+    const T m = (T)c->mass, LF = (T)c->L_F, LR = (T)c->L_R, Iz = (T)c->Iz, Cf = (T)c->Cf, Cr = (T)c->Cr;
+    const T L = LR + LF;
+    T sp, cp, sd, cd;
     sincos_small(psi, &sp, &cp);
     sincos_small(dl, &sd, &cd);
     e.f[0] = vx * cp - vy * sp;
@@ -108,23 +119,24 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     e.f[2] = r;
     e.j0[0] = -vx * sp - vy * cp; e.j0[1] = cp; e.j0[2] = -sp;
     e.j1[0] = vx * cp - vy * sp;  e.j1[1] = sp; e.j1[2] = cp;
-    const double v = vx + 1e-99;
-    const double iv = 1.0 / v;
-    const double Ffy = 2 * Cf * (dl - (vy + LF * r) * iv);
-    const double Fry = 2 * Cr * (LR * r - vy) * iv;
-    const double im = 1.0 / m, iIz = 1.0 / Iz;
-    const double kk = u[1] * vx + dl * u[0];
-    const double dyn3 = u[0] - im * Ffy * sd + vy * r;
-    const double dyn4 = im * (Fry + Ffy * cd) - vx * r;
-    const double dyn5 = iIz * (LF * Ffy * cd - LR * Fry);
-    const double q = 1.0 - p;
+    const T v = vx + (T)1e-99;
+    T iv = (T)1 / v;
+    if constexpr (sizeof(T) == 4) iv = p == (T)0 ? (T)0 : iv;
+    const T Ffy = 2 * Cf * (dl - (vy + LF * r) * iv);
+    const T Fry = 2 * Cr * (LR * r - vy) * iv;
+    const T im = (T)1 / m, iIz = (T)1 / Iz;
+    const T kk = u[1] * vx + dl * u[0];
+    const T dyn3 = u[0] - im * Ffy * sd + vy * r;
+    const T dyn4 = im * (Fry + Ffy * cd) - vx * r;
+    const T dyn5 = iIz * (LF * Ffy * cd - LR * Fry);
+    const T q = (T)1 - p;
     e.f[3] = p * dyn3 + q * u[0];
     e.f[4] = p * dyn4 + q * (kk * LR / L);
     e.f[5] = p * dyn5 + q * (kk / L);
     e.f[6] = u[1];
-    const double gF[4] = { 2 * Cf * (vy + LF * r) * iv * iv, -2 * Cf * iv, -2 * Cf * LF * iv, 2 * Cf };
-    const double gR[4] = { -Fry * iv, -2 * Cr * iv, 2 * Cr * LR * iv, 0.0 };
-    double d3[4], d4[4], d5[4];
+    const T gF[4] = { 2 * Cf * (vy + LF * r) * iv * iv, -2 * Cf * iv, -2 * Cf * LF * iv, 2 * Cf };
+    const T gR[4] = { -Fry * iv, -2 * Cr * iv, 2 * Cr * LR * iv, (T)0 };
+    T d3[4], d4[4], d5[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         d3[i] = -gF[i] * sd * im;
@@ -134,15 +146,15 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     d3[1] += r;  d3[2] += vy;  d3[3] += -Ffy * cd * im;
     d4[0] += -r; d4[2] += -vx; d4[3] += -Ffy * sd * im;
     d5[3] += -LF * Ffy * sd * iIz;
-    const double k4[4] = { u[1] * LR / L, 0.0, 0.0, u[0] * LR / L };
-    const double k5[4] = { u[1] / L, 0.0, 0.0, u[0] / L };
+    const T k4[4] = { u[1] * LR / L, (T)0, (T)0, u[0] * LR / L };
+    const T k5[4] = { u[1] / L, (T)0, (T)0, u[0] / L };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         e.a[0][i] = p * d3[i];
         e.a[1][i] = p * d4[i] + q * k4[i];
         e.a[2][i] = p * d5[i] + q * k5[i];
     }
-    e.bu[0][0] = 1.0;              e.bu[0][1] = 0.0;
+    e.bu[0][0] = (T)1;              e.bu[0][1] = (T)0;
     e.bu[1][0] = q * dl * LR / L;  e.bu[1][1] = q * vx * LR / L;
     e.bu[2][0] = q * dl / L;       e.bu[2][1] = q * vx / L;
     const int ngp = c->n_gp;
@@ -150,72 +162,74 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
         const AdmpcGp& gp = c->gp[g];
         const int feat = gp.feat - 3, out = gp.out - 3;          // feat: 0..3 -> (vx,vy,r,delta), 4..5 -> (u0,u1)
         // static indexing only: runtime-indexed private arrays would live in scratch memory
-        const double z = feat == 0 ? vx : feat == 1 ? vy : feat == 2 ? r : feat == 3 ? dl : feat == 4 ? u[0] : u[1];
-        double mu, dmu;
-        gp_eval(gp, z, mu, dmu);
+        const T z = feat == 0 ? vx : feat == 1 ? vy : feat == 2 ? r : feat == 3 ? dl : feat == 4 ? u[0] : u[1];
+        T mu, dmu;
+        gp_eval<T>(gp, z, mu, dmu);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const bool so = out == o;
-            e.f[3 + o] += so ? mu : 0.0;
+            e.f[3 + o] += so ? mu : (T)0;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && feat == cc) ? dmu : 0.0;
-            e.bu[o][0] += (so && feat == 4) ? dmu : 0.0;
-            e.bu[o][1] += (so && feat == 5) ? dmu : 0.0;
+            for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && feat == cc) ? dmu : (T)0;
+            e.bu[o][0] += (so && feat == 4) ? dmu : (T)0;
+            e.bu[o][1] += (so && feat == 5) ? dmu : (T)0;
         }
     }
 }
 
 // d(column)/dt = Jx * s (+ Ju column for an input column)
-__device__ __forceinline__ void sens_rhs(const ModelEval& e, const double* s, int ucol, double* d)
+template <class T>
+__device__ __forceinline__ void sens_rhs(const ModelEvalT<T>& e, const T* s, int ucol, T* d)
 {
     d[0] = e.j0[0] * s[2] + e.j0[1] * s[3] + e.j0[2] * s[4];
     d[1] = e.j1[0] * s[2] + e.j1[1] * s[3] + e.j1[2] * s[4];
     d[2] = s[5];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        double a = e.a[r][0] * s[3] + e.a[r][1] * s[4] + e.a[r][2] * s[5] + e.a[r][3] * s[6];
-        a += ucol == 0 ? e.bu[r][0] : (ucol == 1 ? e.bu[r][1] : 0.0);
+        T a = e.a[r][0] * s[3] + e.a[r][1] * s[4] + e.a[r][2] * s[5] + e.a[r][3] * s[6];
+        a += ucol == 0 ? e.bu[r][0] : (ucol == 1 ? e.bu[r][1] : (T)0);
         d[3 + r] = a;
     }
-    d[6] = ucol == 1 ? 1.0 : 0.0;
+    d[6] = ucol == 1 ? (T)1 : (T)0;
 }
 
 // One ERK4 step of length h for the state and for the NC sensitivity columns of group g:
 //   g=0: x-columns 2,3,4   g=1: x-columns 5,6   g=2: u-columns 0,1
 // Results: phi[7] (all groups), col[c][7] = column c of the group of A (g<2) or B (g=2).
-__device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, const double* x, const double* u, double p, double h,
-                                          int g, double* phi, double col[3][NX])
+template <class T>
+__device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, const T* x, const T* u, T p, T h,
+                                          int g, T* phi, T col[3][NX])
 {
     const int xcol0 = g == 0 ? 2 : 5;
-    double kx[NX], accx[NX];
-    double kS[3][NX], accS[3][NX];
+    T kx[NX], accx[NX];
+    T kS[3][NX], accS[3][NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { kx[i] = 0.0; accx[i] = 0.0; }
+    for (int i = 0; i < NX; ++i) { kx[i] = (T)0; accx[i] = (T)0; }
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { kS[cc][i] = 0.0; accS[cc][i] = 0.0; }
+        for (int i = 0; i < NX; ++i) { kS[cc][i] = (T)0; accS[cc][i] = (T)0; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const double cs = (s == 0) ? 0.0 : (s == 3 ? 1.0 : 0.5);
-        const double ws = (s == 0 || s == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
-        double X[NX], S[3][NX];
+        const T cs = (s == 0) ? (T)0 : (s == 3 ? (T)1 : (T)0.5);
+        const T ws = (s == 0 || s == 3) ? (T)(1.0 / 6.0) : (T)(2.0 / 6.0);
+        T X[NX], S[3][NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) X[i] = x[i] + cs * h * kx[i];
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                double id = (g < 2 && i == xcol0 + cc) ? 1.0 : 0.0;
+                T id = (g < 2 && i == xcol0 + cc) ? (T)1 : (T)0;
                 S[cc][i] = id + cs * h * kS[cc][i];
             }
-        ModelEval e;
-        model_eval(c, X, u, p, e);
+        ModelEvalT<T> e;
+        model_eval<T>(c, X, u, p, e);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { kx[i] = e.f[i]; accx[i] += ws * e.f[i]; }
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
-            sens_rhs(e, S[cc], g == 2 ? cc : -1, kS[cc]);
+            sens_rhs<T>(e, S[cc], g == 2 ? cc : -1, kS[cc]);
 #pragma unroll
             for (int i = 0; i < NX; ++i) accS[cc][i] += ws * kS[cc][i];
         }
@@ -226,34 +240,33 @@ __device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, con
     for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            double id = (g < 2 && i == xcol0 + cc) ? 1.0 : 0.0;
+            T id = (g < 2 && i == xcol0 + cc) ? (T)1 : (T)0;
             col[cc][i] = id + h * accS[cc][i];
         }
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel A: shooting + linearisation, one thread per (instance, stage, column group).
-// Output, instance-major and packed exactly as kernel B keeps it in LDS:
+// kernel A: shooting + linearisation, one thread per (instance, stage, column group), T = double or float
+// (storage and arithmetic).  Output, instance-major and packed as the QP kernels read it:
 //   GTg [B][N][7][6]  stored columns c=0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each column.
 //                     Not stored because they are structural for this model (delta' = u1, positions
 //                     do not feed back): A[:,0]=e0, A[:,1]=e1, row 6 of [A B] = [e6, 0, h].
 //   blg [B][N][7]     defect b_k = phi(xbar_k,ubar_k) - xbar_{k+1}
 // ---------------------------------------------------------------------------------------------
-#define GTS 42           // doubles per stage of the packed linearisation
-#define PKS 28           // packed symmetric 7x7
-#define KLS 17           // K0[7] K1[7] i00 i01 i11
+#define GTS 42           // values per stage of the packed linearisation
 #define LIN_BLOCK 64     // threads per block of the linearisation kernel: single waves balance best over the CUs (256 registers each)
 #define LIN_TASKS 63     // tasks per block (multiple of 3)
 // work scheduler of the condensed path (int array): [0] ticket counter, [64 + q] number of instances in effort bucket q,
 // [SCHED_HDR + q * cap + j] j-th instance of bucket q.  Zeroed by the linearisation kernel, filled by the condensing kernel,
-// drained (highest bucket first) by the persistent interior-point waves.
+// drained (highest bucket first) by the persistent interior-point waves.  Kernel R uses [0] as its ticket counter.
 #define SCHED_NB 64
 #define SCHED_HDR 128
 
+template <class T>
 __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcConfig* __restrict__ cfg, int B,
-                                                              const double* __restrict__ xbarg, const double* __restrict__ ubarg,
-                                                              const double* __restrict__ pg, const int32_t* __restrict__ skip,
-                                                              double* __restrict__ GTg, double* __restrict__ blg, int* __restrict__ sched)
+                                                              const T* __restrict__ xbarg, const T* __restrict__ ubarg,
+                                                              const T* __restrict__ pg, const int32_t* __restrict__ skip,
+                                                              T* __restrict__ GTg, T* __restrict__ blg, int* __restrict__ sched)
 {
     const int N = cfg->N;
     const long total = (long)B * N * 3;
@@ -264,13 +277,13 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
         const long sk = tsk / 3; const int g = (int)(tsk % 3);
         const long inst = sk / N; const int k = (int)(sk % N);
         if (skip && skip[inst] != 0) continue;
-        double x[NX], u[NU], phi[NX], col[3][NX];
-        const double* xs = xbarg + (inst * (N + 1) + k) * NX;
+        T x[NX], u[NU], phi[NX], col[3][NX];
+        const T* xs = xbarg + (inst * (N + 1) + k) * NX;
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xs[i];
         u[0] = ubarg[(inst * N + k) * NU]; u[1] = ubarg[(inst * N + k) * NU + 1];
-        rk4_group(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
-        double* GT = GTg + sk * GTS;
+        rk4_group<T>(cfg, x, u, pg[inst], (T)cfg->Ts, g, phi, col);
+        T* GT = GTg + sk * GTS;
         const int c0 = g == 0 ? 0 : (g == 1 ? 3 : 5);
         const int nc = g == 0 ? 3 : 2;
 #pragma unroll
@@ -1364,7 +1377,7 @@ __global__ __launch_bounds__(WAVE) void admpc_shoot_kernel(const AdmpcConfig* __
         double x[NX], u[NU], phi[NX], col[3][NX];
         for (int i = 0; i < NX; ++i) x[i] = xbarg[(inst * (N + 1) + k) * NX + i];
         u[0] = ubarg[(inst * N + k) * NU]; u[1] = ubarg[(inst * N + k) * NU + 1];
-        rk4_group(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
+        rk4_group<double>(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
         double* A = Ag + sk * NX * NX; double* Bm = Bg + sk * NX * NU;
         if (g == 0) {
             for (int i = 0; i < NX; ++i) {
@@ -1396,7 +1409,7 @@ __global__ __launch_bounds__(WAVE) void admpc_shift_kernel(const AdmpcConfig* __
         double x[NX], u[NU], phi[NX], col[3][NX];
         for (int i = 0; i < NX; ++i) { x[i] = xb[N * NX + i]; phi[i] = x[i]; }
         u[0] = ub[(N - 1) * NU]; u[1] = ub[(N - 1) * NU + 1];
-        if (rollout) rk4_group(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
+        if (rollout) rk4_group<double>(cfg, x, u, pg[inst], cfg->Ts, g, phi, col);
         if (g == 0) {
             for (int i = 0; i < N * NX; ++i) xb[i] = xb[i + NX];
             for (int i = 0; i < NX; ++i) xb[N * NX + i] = phi[i];
@@ -1510,6 +1523,18 @@ struct AdmpcSolver {
     double* d_ws;            // [cap][N+1][36] workspace of the row kernel (sweep-private state, L2-resident)
 };
 
+// Every entry point runs on the solver's device and restores the caller's current device on return (a host with several GPUs
+// keeps its own current device: torch allocations and default-stream work of the caller are not redirected).
+struct DeviceGuard {
+    int prev; bool switched; bool good;
+    explicit DeviceGuard(int dev) : prev(-1), switched(false), good(true) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { good = hipSetDevice(dev) == hipSuccess; switched = good; }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    bool ok() const { return good; }
+};
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ADMPC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1572,7 +1597,8 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ADMPC_ENODEV, "no HIP device");
     if (device < 0 || device >= ndev) return fail(ADMPC_ENODEV, "device index out of range");
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     AdmpcSolver* s = new (std::nothrow) AdmpcSolver();
@@ -1605,7 +1631,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
 void admpc_destroy(AdmpcSolver* s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->device);
+    DeviceGuard guard(s->device);
 #ifdef ADMPC_PHASE_TIMERS
     {
         unsigned long long h[16] = {0};
@@ -1634,7 +1660,8 @@ int admpc_reserve(AdmpcSolver* s, int B)
 {
     if (!s || B < 0) return fail(ADMPC_EINVAL, "admpc_reserve: bad argument");
     if (B <= s->cap) return ADMPC_OK;
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     HIPCHK(hipDeviceSynchronize());                  // nothing may still be using the old workspace
     if (s->d_GT) (void)hipFree(s->d_GT);
     if (s->d_bl) (void)hipFree(s->d_bl);
@@ -1655,10 +1682,17 @@ int admpc_reserve(AdmpcSolver* s, int B)
         HIPCHK(hipMalloc((void**)&s->d_sched, ((size_t)SCHED_HDR + (size_t)SCHED_NB * B) * sizeof(int)));
     } else {
         HIPCHK(hipMalloc((void**)&s->d_sched, (size_t)SCHED_HDR * sizeof(int)));       // [0]: ticket counter of the row kernel
-        HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 36 * sizeof(double)));
     }
+    HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 36 * sizeof(double)));       // row kernel (every fp32 solve, fp64 for N != 20)
     s->cap = B;
     return ADMPC_OK;
+}
+
+// kernel R addresses its arrays with 32-bit byte offsets from the (64-bit) array bases
+static int rowqp_fits(int B, int N, int elem)
+{
+    const unsigned long long worst = (unsigned long long)B * (unsigned long long)(N + 1) * 42ull * (unsigned long long)elem;
+    return worst < (1ull << 32);
 }
 
 int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
@@ -1668,7 +1702,8 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     if (B < 0) return fail(ADMPC_EINVAL, "negative batch");
     if (B == 0) return ADMPC_OK;
     if (!x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     if (B > s->cap) { int rc = admpc_reserve(s, B); if (rc) return rc; }   // allocates: call admpc_reserve up front to keep this call allocation-free
     const int N = s->cfg.N;
     hipStream_t st = (hipStream_t)stream;
@@ -1679,7 +1714,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     for (int sq = 0; sq < nsqp; ++sq) {
         const int first = sq == 0 ? 1 : 0;
-        hipLaunchKernelGGL(admpc_linearize_kernel, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
+        hipLaunchKernelGGL(admpc_linearize_kernel<double>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->d_sched);
         if (s->use_dense) {
             constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + NX * 64) * (int)sizeof(double);
@@ -1705,9 +1740,42 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
         else {
             int rows, stride, ldsb, gridR;
             if (admpc_rowqp_plan(N, 8, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
+            if (!rowqp_fits(B, N, 8)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
             admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
                                    xbar, ubar, cost, stat, iters, (double*)nullptr, s->d_ws, first, s->d_sched);
         }
+    }
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+/* fp32 storage and arithmetic (BASELINE configs[4]): same arguments as admpc_solve_batch with float arrays. */
+int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* yref, const float* yref_e, const float* p,
+                          float* xbar, float* ubar, float* cost, int32_t* status, int32_t* iters, void* stream)
+{
+    if (!s) return fail(ADMPC_EINVAL, "null solver");
+    if (B < 0) return fail(ADMPC_EINVAL, "negative batch");
+    if (B == 0) return ADMPC_OK;
+    if (!x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    if (B > s->cap) { int rc = admpc_reserve(s, B); if (rc) return rc; }
+    const int N = s->cfg.N;
+    if (!rowqp_fits(B, N, 4)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* stat = status ? status : s->d_status;
+    const long totalA = (long)B * N * 3;
+    int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
+    if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
+    int rows, stride, ldsb, gridR;
+    if (admpc_rowqp_plan(N, 4, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
+    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
+    for (int sq = 0; sq < nsqp; ++sq) {
+        const int first = sq == 0 ? 1 : 0;
+        hipLaunchKernelGGL(admpc_linearize_kernel<float>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, (const float*)xbar, (const float*)ubar, p,
+                           first ? (const int32_t*)nullptr : (const int32_t*)stat, (float*)s->d_GT, (float*)s->d_bl, s->d_sched);
+        admpc_rowqp_launch_f32(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const float*)s->d_GT, (const float*)s->d_bl,
+                               xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)s->d_ws, first, s->d_sched);
     }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -1719,7 +1787,8 @@ int admpc_shoot_batch(AdmpcSolver* s, int B, const double* xbar, const double* u
     if (!s || B < 0) return fail(ADMPC_EINVAL, "bad argument");
     if (B == 0) return ADMPC_OK;
     if (!xbar || !ubar || !p || !phi || !A || !Bm) return fail(ADMPC_EINVAL, "null array argument");
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     long total = (long)B * s->cfg.N * 3;
     int grid = (int)((total + LIN_TASKS - 1) / LIN_TASKS); if (grid > s->num_cu * 32) grid = s->num_cu * 32;
     hipLaunchKernelGGL(admpc_shoot_kernel, dim3(grid), dim3(WAVE), 0, (hipStream_t)stream, s->d_cfg, B, xbar, ubar, p, phi, A, Bm);
@@ -1730,7 +1799,8 @@ int admpc_shoot_batch(AdmpcSolver* s, int B, const double* xbar, const double* u
 int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset, double* val, int64_t* idx, void* stream)
 {
     if (!s || !cost || !val || !idx || B <= 0) return fail(ADMPC_EINVAL, "bad argument");
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(admpc_argmin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cost, B, index_offset, val, idx);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -1740,7 +1810,8 @@ int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, 
 {
     if (!s || W <= 0) return fail(ADMPC_EINVAL, "bad argument");
     if (!pairs || !val || !idx) return fail(ADMPC_EINVAL, "null array argument");
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(admpc_argmin_pairs_kernel, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, pairs, W, val, idx);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -1751,7 +1822,8 @@ int admpc_shift_batch(AdmpcSolver* s, int B, double* xbar, double* ubar, const d
     if (!s || B < 0) return fail(ADMPC_EINVAL, "bad argument");
     if (B == 0) return ADMPC_OK;
     if (!xbar || !ubar || (rollout && !p)) return fail(ADMPC_EINVAL, "null array argument");
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     const long total = (long)B * 3;
     long grid = (total + LIN_TASKS - 1) / LIN_TASKS;
     if (grid > 65536) grid = 65536;
@@ -1766,7 +1838,8 @@ int admpc_epilogue_batch(AdmpcSolver* s, int B, const double* xopt, const double
     if (!s || B < 0) return fail(ADMPC_EINVAL, "bad argument");
     if (B == 0) return ADMPC_OK;
     if (!xopt || !uopt || !xref_xy || !ack || !valid) return fail(ADMPC_EINVAL, "null array argument");
-    HIPCHK(hipSetDevice(s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(admpc_epilogue_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->cfg.N, B, xopt, uopt, xref_xy, ack, valid);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -1782,7 +1855,8 @@ int admpc_waypoints_batch(int device, int M, int H, double dt, int B,
     if (B == 0) return ADMPC_OK;
     if (!vel || !x || !y || !psi || !psi_unwrapped || !cdist || !curv || !X_init || !Y_init || !psi_init || !out_ref || !out_err || !out_stop)
         return fail(ADMPC_EINVAL, "null array argument");
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     int grid = B < 4096 ? B : 4096;
     hipLaunchKernelGGL(admpc_waypoints_kernel, dim3(grid), dim3(WAVE), 0, (hipStream_t)stream, M, H, dt, B, vel, x, y, psi, psi_unwrapped, cdist, curv,
                        X_init, Y_init, psi_init, out_ref, out_err, out_stop);

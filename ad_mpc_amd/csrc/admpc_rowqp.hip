@@ -119,3 +119,17 @@ void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const Admpc
     hipLaunchKernelGGL((admpc_rowqp_kernel<float>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
                        xbar, ubar, cost, stat, iters, pi, ws, first, ticket);
 }
+
+#ifdef ADMPC_PHASE_TIMERS
+#include <cstdio>
+extern "C" void admpc_rowqp_dump_timers(void)
+{
+    unsigned long long h[16] = {0};
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rq_ticks), sizeof h) != hipSuccess) return;
+    static const char* nm[16] = {"-", "S0 rollout", "trial+init", "E1", "check", "S1 factor", "S2 forward", "E2", "S3 backward", "S4 forward", "E3a", "E3b+E1",
+                                 "-", "SF rollout", "-", "-"};
+    unsigned long long tot = 0; for (int i = 0; i < 16; ++i) tot += h[i];
+    for (int i = 1; i < 14; ++i) if (h[i]) fprintf(stderr, "[rowqp phase] %-12s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+}
+#endif

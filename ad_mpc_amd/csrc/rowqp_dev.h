@@ -14,11 +14,19 @@
 #include <stdint.h>
 
 #define RQ_FN __device__ __forceinline__
+#define RQ_UNROLL _Pragma("unroll")
+#define RQ_NOUNROLL _Pragma("unroll 1")
 #include "rowqp_core.h"
 
 #define RQ_DPPM " row_mask:0xf bank_mask:0xf\n\t"
 
 template <class T_> struct DevX;
+
+// optional in-kernel phase timers (-DADMPC_PHASE_TIMERS): s_memtime deltas between the stamps of RowQp::solve, summed over all waves
+#ifdef ADMPC_PHASE_TIMERS
+__device__ unsigned long long g_rq_ticks[16];
+__device__ unsigned long long g_rq_last[8192];
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // common part
@@ -75,6 +83,15 @@ struct DevCommon {
     RQ_FN static M row_and(M m) { return rowbits(m) == 0xffffu; }
     RQ_FN static M row_or(M m) { return rowbits(m) != 0u; }
     RQ_FN static bool any(M m) { return __any(m) != 0; }
+#ifdef ADMPC_PHASE_TIMERS
+    // the interval that ENDS at stamp(id) is charged to phase id
+    RQ_FN static void stamp(int id) {
+        unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+        if (threadIdx.x == 0) { if (id != 0) atomicAdd(&g_rq_ticks[id], t - g_rq_last[blockIdx.x]); g_rq_last[blockIdx.x] = t; }
+    }
+#else
+    RQ_FN static void stamp(int) {}
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

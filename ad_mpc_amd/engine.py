@@ -62,27 +62,33 @@ class BatchSolver:
 
     # -- the hot path --------------------------------------------------------------------------
     def solve(self, x0, yref, yref_e, p, xbar, ubar, cost=None, status=None, iters=None):
-        """One SQP-RTI step for every instance, in place on xbar/ubar (device tensors).  Asynchronous."""
+        """One SQP-RTI step for every instance, in place on xbar/ubar (device tensors).  Asynchronous.
+        The dtype of x0 selects the path: float64 (admpc_solve_batch) or float32 (admpc_solve_batch_f32, storage and compute)."""
         N = self.N
         B = x0.shape[0]
-        self._chk(x0, (B, NX)); self._chk(yref, (B, N, NY)); self._chk(yref_e, (B, NX)); self._chk(p, (B,))
-        self._chk(xbar, (B, N + 1, NX)); self._chk(ubar, (B, N, NU))
-        if cost is not None: self._chk(cost, (B,))
+        dt = x0.dtype
+        if dt not in (torch.float64, torch.float32):
+            raise ValueError("x0 must be float64 or float32")
+        self._chk(x0, (B, NX), dt); self._chk(yref, (B, N, NY), dt); self._chk(yref_e, (B, NX), dt); self._chk(p, (B,), dt)
+        self._chk(xbar, (B, N + 1, NX), dt); self._chk(ubar, (B, N, NU), dt)
+        if cost is not None: self._chk(cost, (B,), dt)
         if status is not None: self._chk(status, (B,), torch.int32)
         if iters is not None: self._chk(iters, (B,), torch.int32)
-        _lib.check(self.lib.admpc_solve_batch(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p), _ptr(xbar), _ptr(ubar),
-                                              _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
+        fn = self.lib.admpc_solve_batch if dt == torch.float64 else self.lib.admpc_solve_batch_f32
+        _lib.check(fn(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p), _ptr(xbar), _ptr(ubar),
+                      _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
 
-    def solve_numpy(self, x0, yref, yref_e, p, xbar, ubar):
+    def solve_numpy(self, x0, yref, yref_e, p, xbar, ubar, dtype=np.float64):
         """Convenience for tests / the single-instance shims: host arrays in, host arrays out
-        (x, u, cost, status, iters)."""
-        d = self.to_device
-        x0 = np.asarray(x0, dtype=np.float64).reshape(-1, NX)
+        (x, u, cost, status, iters).  dtype=np.float32 runs the fp32 path."""
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        d = lambda a: self.to_device(a, tdt)
+        x0 = np.asarray(x0, dtype=dtype).reshape(-1, NX)
         B, N = x0.shape[0], self.N
-        tx0 = d(x0); tyr = d(np.asarray(yref, dtype=np.float64).reshape(B, N, NY)); tye = d(np.asarray(yref_e, dtype=np.float64).reshape(B, NX))
-        tp = d(np.asarray(p, dtype=np.float64).reshape(B))
-        tx = d(np.asarray(xbar, dtype=np.float64).reshape(B, N + 1, NX)).clone(); tu = d(np.asarray(ubar, dtype=np.float64).reshape(B, N, NU)).clone()
-        cost = torch.empty(B, dtype=torch.float64, device=self.device)
+        tx0 = d(x0); tyr = d(np.asarray(yref, dtype=dtype).reshape(B, N, NY)); tye = d(np.asarray(yref_e, dtype=dtype).reshape(B, NX))
+        tp = d(np.asarray(p, dtype=dtype).reshape(B))
+        tx = d(np.asarray(xbar, dtype=dtype).reshape(B, N + 1, NX)).clone(); tu = d(np.asarray(ubar, dtype=dtype).reshape(B, N, NU)).clone()
+        cost = torch.empty(B, dtype=tdt, device=self.device)
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         iters = torch.empty(B, dtype=torch.int32, device=self.device)
         self.solve(tx0, tyr, tye, tp, tx, tu, cost, status, iters)

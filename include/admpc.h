@@ -131,12 +131,27 @@ int admpc_reserve(AdmpcSolver* s, int B);
  *   cost   [B]           objective of the returned iterate (+inf if status != 0)   (may be NULL)
  *   status [B]           acados-style status                                        (may be NULL)
  *   iters  [B]           interior-point iterations of the last QP                   (may be NULL)
- * Asynchronous on `stream`. */
+ * Asynchronous on `stream`.
+ * ONE in-flight solve per handle: the handle owns one linearisation / QP workspace and one scheduler array, which every call
+ * rewrites.  Use one handle per stream; a call that has to grow the workspace (B above anything reserved so far) synchronises
+ * the device first. */
 int admpc_solve_batch(AdmpcSolver* s, int B,
                       const double* x0, const double* yref, const double* yref_e, const double* p,
                       double* xbar, double* ubar,
                       double* cost, int32_t* status, int32_t* iters,
                       void* stream);
+
+/* The same step in fp32 storage AND arithmetic (BASELINE configs[4]: long horizons, large batches).  Arguments as above with
+ * float arrays.  The interior point of this entry stops at fp32 levels (complementarity 1e-3, residual 1e-2, last step 1e-3;
+ * tighter values in cfg are clipped to these) -- the result is the fp64 minimiser to about 1e-3 of the input range.
+ * The model's "+1e-99" denominators (ad_3d_optimizer.py:290,296-297) vanish in fp32: with p == 0 the dynamic branch is dropped
+ * instead of multiplied by 0 (it would be inf * 0 at v_x = 0); 0 < p <= 1 reproduces the blend.
+ * Every horizon runs the row kernel here (the condensed N = 20 pipeline is fp64 only). */
+int admpc_solve_batch_f32(AdmpcSolver* s, int B,
+                          const float* x0, const float* yref, const float* yref_e, const float* p,
+                          float* xbar, float* ubar,
+                          float* cost, int32_t* status, int32_t* iters,
+                          void* stream);
 
 /* Shooting only (H1): phi, A, B for every stage of every instance; used by the parity tests.
  *   xbar [B][N+1][7], ubar [B][N][2], p [B]  ->  phi [B][N][7], A [B][N][7][7] row-major,

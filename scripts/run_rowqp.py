@@ -2,6 +2,8 @@
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ.setdefault("ADMPC_QP", "riccati")
+import ad_mpc_amd._lib as _lib
+if os.environ.get("ADMPC_LIB"): _lib.LIB_PATH = os.path.join(ROOT, "ad_mpc_amd", os.environ["ADMPC_LIB"])
 from ad_mpc_amd.config import default_config
 from ad_mpc_amd.engine import BatchSolver
 from ad_mpc_amd.scenarios import random_scenarios
@@ -22,3 +24,7 @@ for rep in range(steps + 2):
 t = np.median(ts[2:])
 itc = it.cpu().numpy()
 print("N %d B %d: %.3f ms/step %.3f M solves/s; iters mean %.2f max %d; quad-max mean %.2f" % (N, B, t * 1e3, B / t / 1e6, itc.mean(), itc.max(), itc[: B // 4 * 4].reshape(-1, 4).max(1).mean()))
+if os.environ.get("ADMPC_LIB"):
+    import ctypes
+    try: ctypes.CDLL(_lib.LIB_PATH).admpc_rowqp_dump_timers()
+    except Exception as e: print("no timers:", e)

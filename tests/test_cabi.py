@@ -23,7 +23,7 @@ def lib():
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "admpc.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(admpc_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(admpc_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
