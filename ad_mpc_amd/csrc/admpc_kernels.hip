@@ -925,7 +925,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         WSYNC();
 
         bool failed = false;
-        double rmax_prev = 0.0, step = 1e300, stp_local = 1e300;
+        double rmax_prev = 0.0, step = 1e300, stp_local = 1e300, alpha_prev = 1.0;
         int it = 0;
         PHASE_STAMP(0);
         // ---------------- trial: the QP without its inequalities ----------------
@@ -1097,6 +1097,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     for (int i = 0; i < 2; ++i) s_aff += dact ? (Dt[i] + amax * Ddt[i]) * (Dlam[i] + amax * Ddlam[i]) : 0.0;
                     mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
                     double sigma = mu_aff * rcp_nr(mu); sigma = sigma * sigma * sigma;
+                    if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;      // centring safeguard (admpc.h)
                     const double smu = sigma * mu;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
@@ -1105,6 +1106,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 } else {
                     double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
                     const double alpha = fmin(tau * amax, 1.0);
+                    alpha_prev = alpha;
                     stp_local = uact ? fabs(alpha * ddu) : 0.0;
                     // idle lanes carry harmless finite values (their steps are computed from finite data)
 #pragma unroll

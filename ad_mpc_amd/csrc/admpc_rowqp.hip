@@ -14,8 +14,8 @@
 //   Registers: the Riccati matrix P (7 values per lane), the stage data of the current and the next stage, lane constants.
 // Waves draw quadruples of instances from a ticket counter (zeroed by the linearisation kernel).  The four instances of a wave
 // iterate until the last of them has converged; finished rows are frozen by masks (their state is not rewritten).
-#include "rowqp_dev.h"
 #include "../../include/admpc.h"
+#include "rowqp_dev.h"
 
 namespace {
 

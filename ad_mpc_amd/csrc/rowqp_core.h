@@ -70,6 +70,7 @@ struct RqParams {              // wave-uniform scalars
     T inv_nineq;               // 1 / (8N + 2(N-1))
     T big;                     // |value| above this (or NaN) = failed step
     T floor_;                  // lower clamp of t, lam
+    T blocked;                 // centring safeguard: step length below which the next iteration centres (ADMPC_IPM_BLOCKED_STEP)
 };
 
 template <class T>
@@ -727,7 +728,7 @@ struct RowQp {
         pass_e1(R);
         X::fence();
         X::stamp(3);
-        V step = splat((T)1e30), rmax_prev = zero, rmax_last = zero;
+        V step = splat((T)1e30), rmax_prev = zero, rmax_last = zero, alpha_prev = one;
         RQ_NOUNROLL
         for (int guard = 0; guard <= q.itmax; ++guard) {
             // every linear residual of a Newton iteration in residual form shrinks by (1 - alpha) per step; the inequality rows are
@@ -759,6 +760,7 @@ struct RowQp {
             const V munq = R.mu;                                    // = mu * nineq
             const V mu_aff = ((one - a_aff) * munq + a_aff * a_aff * s2) * splat(q.inv_nineq);
             V sigma = mu_aff * X::rcp(mu); sigma = sigma * sigma * sigma;
+            sigma = X::sel(alpha_prev < splat(q.blocked), one, sigma);   // after a blocked step: centre
             const V smu = sigma * mu;
             RQ_DBG("[emu] it mu=%.6e cmax=%.3e rmax=%.3e a_aff=%.6e mu_aff=%.6e sigma=%.6e\n", X::first(mu), X::first(R.cmax), X::first(rmax), X::first(a_aff), X::first(mu_aff), X::first(sigma));
             // ---- corrector
@@ -778,6 +780,7 @@ struct RowQp {
             X::fence();
             X::stamp(11);
             step = X::sel(active, stn, step);
+            alpha_prev = X::sel(active, alpha, alpha_prev);
             rstat = X::sel(active, (one - alpha) * rstat, rstat);
             iters = iters + X::isel(active, X::isplat(1), X::isplat(0));
         }
@@ -864,4 +867,5 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     q.inv_nineq = (T)(1.0 / (double)(8 * c.N + 2 * (c.N - 1)));
     q.big = f32 ? (T)1e30 : (T)1e300;
     q.floor_ = f32 ? (T)1e-8 : (T)1e-40;
+    q.blocked = (T)ADMPC_IPM_BLOCKED_STEP;
 }

@@ -50,6 +50,11 @@ extern "C" {
 #define ADMPC_EHIP        (-3)   /* HIP runtime error (see admpc_last_error)  */
 #define ADMPC_ENOMEM      (-4)
 
+/* Safeguard of the Mehrotra predictor-corrector (oracle and every device path): after an iteration whose step length was below
+ * this value the next iteration is a pure centring step (sigma = 1).  Without it the method can fall into a limit cycle on a
+ * badly centred iterate (seen on one of 16384 config-5 scenarios: mu cycling with period 4 until iter_max). */
+#define ADMPC_IPM_BLOCKED_STEP 0.05
+
 /* status per instance (acados enum values used by the reference) */
 #define ADMPC_STATUS_SUCCESS     0
 #define ADMPC_STATUS_QP_FAILURE  4

@@ -504,6 +504,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
     }
     int it;
     real rmax_prev = 0, step = 1e300;   /* step: max-norm of the last applied input step */
+    real alpha_prev = 1;                /* step length of the previous iteration (centring safeguard, admpc.h) */
     for (it = 0; it < c->ipm_iter_max; ++it) {
         real mu = 0, cmax = 0;
         for (int k = 0; k < N; ++k) {
@@ -533,6 +534,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         }
         mu_aff /= n_ineq;
         real sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+        if (alpha_prev < (real)ADMPC_IPM_BLOCKED_STEP) sigma = 1;       /* blocked step: centre (breaks the method's limit cycles) */
         /* corrector: centring + second-order term */
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i)
@@ -546,6 +548,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         real a_max = ipm_max_step(qp, s, w);
         real tau = 1 - mu_aff; if (tau < (real)0.995) tau = (real)0.995; if (tau > (real)0.999999) tau = (real)0.999999;
         real alpha = tau * a_max; if (alpha > 1) alpha = 1;
+        alpha_prev = alpha;
         step = 0;
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < NU; ++j) {

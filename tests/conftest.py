@@ -24,6 +24,14 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_omp():
+    """The same oracle built with OpenMP over instances (full-size batches stay fast); identical arithmetic per instance."""
+    from oracle.oracle import Oracle, build
+    build(omp=True)
+    return Oracle(omp=True)
+
+
+@pytest.fixture(scope="session")
 def golden_shooting():
     with open(os.path.join(GOLDEN, "shooting.json")) as f:
         return json.load(f)

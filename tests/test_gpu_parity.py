@@ -1,9 +1,16 @@
 """Parity tests proper: the HIP path, called through the C ABI (libadmpc.so), against the CPU oracle on
 identical seeded inputs, against the committed golden fixtures, and through size-independent properties
-at BASELINE's full batch size.
+at BASELINE's full batch sizes.
 
-Stated fp64 tolerance: |u - u_oracle|, |x - x_oracle| <= 1e-8 absolute (measured ~1e-12); shooting
-quantities <= 1e-11 relative.
+Stated tolerances (written in the assertions below):
+  shooting quantities         <= 1e-11 relative (reference golden vectors)
+  fp64 solve, N <= 32         |u - u_oracle|, |x - x_oracle| <= 1e-8 absolute   (measured 1e-13 .. 2e-12)
+  fp64 solve, N  > 32         <= 1e-7 absolute                                   (measured 2e-10 .. 4e-8)
+  fp32 solve (configs[4])     <= 2e-3 absolute on inputs of size 10 (2e-4 of the input range; measured 5e-4)
+  status identical, interior-point iteration counts IDENTICAL on every committed input (fp64).
+Why the long horizons get 1e-7: the last iterations of the interior point run with slacks of active hard bounds at the
+rounding level of the states (1e-16); the ratio test of those iterations amplifies last-bit differences between two correct
+evaluation orders into a step length of 0.90 instead of 0.999999 on an update of size 2e-7.
 """
 import ctypes as C
 import os
@@ -18,28 +25,28 @@ from ad_mpc_amd.config import default_config, set_gp, AdmpcConfig  # noqa: E402
 from ad_mpc_amd.scenarios import random_scenarios, straight_scenario, assemble, grid_gp  # noqa: E402
 
 TOL = 1e-8
+TOL_LONG = 1e-7
 
 
-def _solve_both(eng, oracle, cfg, s):
+def tol_for(N):
+    return TOL if N <= 32 else TOL_LONG
+
+
+def _solve_both(eng, oracle, cfg, s, nthreads=1):
     g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=nthreads)
     return g, o
 
 
 def _assert_parity(g, o, tol=TOL):
-    """Same algorithm on both sides: instances that take the same number of interior-point iterations must agree to `tol`
-    (measured: 1e-11); an instance whose stopping test is borderline may take one iteration more or less on one side, and then
-    the two answers differ by the size of that last step, which the stopping rule bounds by cfg.ipm_tol_step = 1e-6."""
+    """Same Newton steps on both sides: identical status, identical interior-point iteration counts, solutions within `tol`."""
     x, u, cost, st, it = g; xo, uo, co, so, io = o
     np.testing.assert_array_equal(st, so)
-    assert np.abs(it - io).max(initial=0) <= 1          # at most one borderline extra iteration
-    ok = (so == 0) & (it == io)
+    ok = so == 0
+    np.testing.assert_array_equal(it[ok], io[ok])
     assert np.abs(u[ok] - uo[ok]).max(initial=0.0) <= tol, np.abs(u[ok] - uo[ok]).max()
     assert np.abs(x[ok] - xo[ok]).max(initial=0.0) <= tol, np.abs(x[ok] - xo[ok]).max()
     np.testing.assert_allclose(cost[ok], co[ok], rtol=1e-9, atol=1e-9)
-    flip = (so == 0) & (it != io)
-    assert flip.mean() <= 0.01
-    assert np.abs(u[flip] - uo[flip]).max(initial=0.0) <= 1e-6 and np.abs(x[flip] - xo[flip]).max(initial=0.0) <= 1e-6
 
 
 def test_shooting_against_reference_golden_vectors(gpu_engine_factory, golden_shooting):
@@ -72,12 +79,12 @@ def test_solve_parity_with_oracle(gpu_engine_factory, oracle, N, B, blend, init)
     s = random_scenarios(B, N=N, seed=1234, blend=blend, init=init)
     g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
     assert (o[3] == 0).all()
-    _assert_parity(g, o)
+    _assert_parity(g, o, tol_for(N))
 
 
 def test_both_qp_kernels_agree_at_n20(gpu_engine_factory, oracle, monkeypatch):
-    """N = 20 has two device paths: the condensed dense-Cholesky kernel (default) and the stage-wise Riccati
-    kernel (ADMPC_QP=riccati, also the path of every other horizon).  Both must match the oracle."""
+    """N = 20 has two device paths: the condensed dense-LDL' pipeline (default) and the row-mapped Riccati kernel R
+    (ADMPC_QP=riccati, the path of every other horizon and of every fp32 solve).  Both must match the oracle."""
     cfg = default_config(N=20)
     s = random_scenarios(512, N=20, seed=77, blend=(3.0, 5.0))
     o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
@@ -120,7 +127,7 @@ def test_warm_start_from_the_unconstrained_minimiser(gpu_engine_factory, oracle,
     assert warm.ipm_warm_thr == 0.01
     g_w, o_w = _solve_both(gpu_engine_factory(warm), oracle, warm, s)
     g_c, o_c = _solve_both(gpu_engine_factory(cold), oracle, cold, s)
-    _assert_parity(g_w, o_w); _assert_parity(g_c, o_c)
+    _assert_parity(g_w, o_w, tol_for(N)); _assert_parity(g_c, o_c, tol_for(N))
     np.testing.assert_array_equal(g_w[4] == 0, g_c[4] == 0)                 # the trial decides the same way
     assert np.abs(g_w[1] - g_c[1]).max() <= 1e-7 and np.abs(g_w[0] - g_c[0]).max() <= 1e-7
     ipm = g_c[4] > 0
@@ -158,11 +165,12 @@ def test_bitwise_repeatability(gpu_engine_factory):
                 np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("N,B", [(24, 300), (40, 64), (40, 1500), (64, 600)])
-def test_riccati_path_repeatable_and_ticket_order_free(gpu_engine_factory, oracle, N, B):
-    """The stage-wise kernel (N != 20) draws its instances from a counter: more instances than resident waves (B = 1500 at
-    four waves per CU would not fit 1024 slots at N = 40) must give the same bits as any other draw order, run after run,
-    and the oracle's answer.  (A -O2/-O3 build of the ticket loop failed exactly this at N = 40; the kernel is built at -O1.)"""
+@pytest.mark.parametrize("N,B", [(24, 300), (40, 64), (40, 1500), (64, 600), (20, 5000)])
+def test_row_kernel_repeatable_and_ticket_order_free(gpu_engine_factory, oracle_omp, N, B, monkeypatch):
+    """Kernel R draws quadruples of instances from a ticket counter and runs one to four instances per wave depending on the
+    batch: more instances than resident row slots must give the same bits as any other draw order, run after run, and the
+    oracle's answer.  (N = 20 forced onto kernel R as well.)"""
+    monkeypatch.setenv("ADMPC_QP", "riccati")
     cfg = default_config(N=N)
     s = random_scenarios(B, N=N, seed=77, blend=(3.0, 5.0))
     eng = gpu_engine_factory(cfg)
@@ -171,9 +179,103 @@ def test_riccati_path_repeatable_and_ticket_order_free(gpu_engine_factory, oracl
         g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
         for a, b in zip(g, ref):
             np.testing.assert_array_equal(a, b)
-    n = min(B, 256)
-    o = oracle.solve_batch(cfg, s["x0"][:n], s["yref"][:n], s["yref_e"][:n], s["p"][:n], s["xbar"][:n], s["ubar"][:n])
-    _assert_parity(tuple(a[:n] for a in ref), o)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    _assert_parity(ref, o, tol_for(N))
+
+
+@pytest.mark.parametrize("N", [2, 3, 7, 19, 21, 27, 28, 32, 33, 40, 45, 46, 64, 65, 80, 96, 97, 128])
+def test_horizon_sweep_row_kernel(gpu_engine_factory, oracle_omp, N):
+    """Every horizon class of kernel R (odd and even, the LDS budgets of 4, 2 and 1 instances per wave, the maximum N = 128):
+    status and iteration counts equal to the oracle's for every instance, solutions within the stated tolerance, bit-wise
+    repeatable.  (The former scripts/sweep_horizons.py, now a test; the old stage-wise kernel this replaces gave run-to-run
+    different results on some of these horizons.)"""
+    B = 600 if N <= 46 else (200 if N <= 80 else 64)
+    cfg = default_config(N=N)
+    s = random_scenarios(B, N=N, seed=1000 + N, blend=(3.0, 5.0))
+    eng = gpu_engine_factory(cfg)
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    g2 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    for a, b in zip(g, g2):
+        np.testing.assert_array_equal(a, b)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    assert (o[3] == 0).all()
+    _assert_parity(g, o, tol_for(N))
+
+
+def test_full_size_n40_b4096_every_instance(gpu_engine_factory, oracle_omp):
+    """The reference's shipped horizon (launch/gp_ad_mpc.launch:6-7, N = 40, T = 2 s) at the full batch size: every one of
+    the 4096 instances against the oracle."""
+    cfg = default_config(N=40)
+    s = random_scenarios(4096, N=40, seed=1234, blend=(3.0, 5.0))
+    g = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    assert (o[3] == 0).all() and g[4].max() < cfg.ipm_iter_max
+    _assert_parity(g, o, TOL_LONG)
+
+
+def test_full_size_shard_8192_every_instance(gpu_engine_factory, oracle_omp):
+    """BASELINE configs[3] on one of its eight GPUs: the 8192-instance shard of the 65536 scenarios (shard 5), N = 20, every
+    instance against the oracle; the generator gives instance i the same data whatever the sharding."""
+    from ad_mpc_amd.dist import shard_range
+    cfg = default_config(N=20)
+    lo, hi = shard_range(65536, 5, 8)
+    assert hi - lo == 8192
+    s = random_scenarios(hi - lo, N=20, seed=1234, start=lo)
+    g = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    assert (o[3] == 0).all()
+    _assert_parity(g, o, TOL)
+
+
+def test_fp32_config5_full_size(gpu_engine_factory, oracle_omp):
+    """BASELINE configs[4]: N = 80, B = 16384, fp32 storage and arithmetic, against the fp64 oracle: identical status, every
+    instance converged before iter_max, |u - u_oracle| and |x - x_oracle| <= 2e-3 absolute (inputs range over [-10, 5],
+    states over tens of metres: about 2e-4 relative), costs to 1e-3 relative; bit-wise repeatable."""
+    N, B = 80, 16384
+    cfg = default_config(N=N)
+    s = random_scenarios(B, N=N, seed=1234)
+    eng = gpu_engine_factory(cfg)
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], dtype=np.float32)
+    g2 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], dtype=np.float32)
+    for a, b in zip(g, g2):
+        np.testing.assert_array_equal(a, b)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    np.testing.assert_array_equal(g[3], o[3])
+    assert (g[3] == 0).all()
+    assert g[4].max() < cfg.ipm_iter_max and o[4].max() < cfg.ipm_iter_max
+    assert np.abs(g[1] - o[1]).max() <= 2e-3, np.abs(g[1] - o[1]).max()
+    assert np.abs(g[0] - o[0]).max() <= 2e-3, np.abs(g[0] - o[0]).max()
+    np.testing.assert_allclose(g[2], o[2], rtol=1e-3)
+    np.testing.assert_array_equal(g[0][:, 0, :], s["x0"].astype(np.float32))          # x_0 pinned to the measured state
+    assert np.abs(g[0][:, 1:N, 6]).max() <= 0.52 + 2e-3                                # steering inside its hard bound
+
+
+@pytest.mark.parametrize("N,blend", [(20, (3.0, 5.0)), (40, (100.0, 110.0)), (5, (3.0, 5.0))])
+def test_fp32_small_cases(gpu_engine_factory, oracle, N, blend):
+    """fp32 path on small batches of both model branches (p = 1 dynamic, p = 0 kinematic where the fp32 build drops the
+    1e-99-guarded dynamic terms), tolerance as above."""
+    cfg = default_config(N=N)
+    s = random_scenarios(96, N=N, seed=1234, blend=blend)
+    g = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], dtype=np.float32)
+    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    np.testing.assert_array_equal(g[3], o[3])
+    assert np.abs(g[1] - o[1]).max() <= 2e-3 and np.abs(g[0] - o[0]).max() <= 2e-3
+
+
+def test_mehrotra_limit_cycle_instance(gpu_engine_factory, oracle):
+    """Scenario 10474 of the config-5 batch drove the unguarded predictor-corrector into a limit cycle (mu with period 4 until
+    iter_max = 50, in the oracle and on the device alike).  With the centring safeguard (ADMPC_IPM_BLOCKED_STEP, include/admpc.h)
+    it converges in 14 iterations: same count and same answer on the device, fp64 and fp32."""
+    N = 80
+    cfg = default_config(N=N)
+    s = random_scenarios(1, N=N, seed=1234, start=10474)
+    eng = gpu_engine_factory(cfg)
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert o[3][0] == 0 and o[4][0] < 20
+    _assert_parity(g, o, TOL_LONG)
+    g32 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], dtype=np.float32)
+    assert g32[3][0] == 0 and g32[4][0] < 30 and np.abs(g32[1] - o[1]).max() <= 2e-3
 
 
 def test_full_size_batch_4096(gpu_engine_factory, oracle):
@@ -454,33 +556,13 @@ def test_epilogue_kernel_matches_host_logic(gpu_engine_factory):
     assert not valid[3] and not valid[7] and 0 < valid.sum() < 64
 
 
-_LONG_CHILD = r'''
-import sys, json, numpy as np
-sys.path.insert(0, %r)
-from ad_mpc_amd.config import default_config
-from ad_mpc_amd.engine import BatchSolver
-from ad_mpc_amd.scenarios import random_scenarios
-from oracle.oracle import Oracle
-out = []
-for N, B in [(80, 32), (128, 4)]:
-    cfg = default_config(N=N)                       # Ts = 0.05 -> T = 4 s at N = 80 (BASELINE configs[4] horizon)
-    s = random_scenarios(B, N=N, seed=1234, blend=(3.0, 5.0))
-    x, u, c, st, it = BatchSolver(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-    xo, uo, co, so, io = Oracle().solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-    out.append(dict(N=N, status_equal=bool((st == so).all()), ok=int((so == 0).sum()), du=float(np.abs(u - uo).max()), dx=float(np.abs(x - xo).max()),
-                    diters=int(np.abs(it - io).max())))
-print("RESULT " + json.dumps(out))
-'''
-
-
-def test_long_horizons_fp64_in_child_process():
-    """Horizon of BASELINE configs[4] (N = 80, T = 4 s) and the maximum N = 128, in fp64.  Run in a process of its own:
-    these builds of the Riccati kernel carry a large private segment (see the scratch note in DESIGN.md 4)."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _LONG_CHILD % root], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
-    for rec in json.loads(line[7:]):
-        assert rec["status_equal"] and rec["ok"] > 0, rec
-        assert rec["du"] <= TOL and rec["dx"] <= TOL and rec["diters"] <= 1, rec
+def test_long_horizons_fp64(gpu_engine_factory, oracle_omp):
+    """Horizon of BASELINE configs[4] (N = 80, T = 4 s) and the maximum N = 128, in fp64, in this process (kernel R has no
+    private segment: the child process the old stage-wise kernel needed is gone)."""
+    for N, B in [(80, 512), (128, 128)]:
+        cfg = default_config(N=N)
+        s = random_scenarios(B, N=N, seed=1234, blend=(3.0, 5.0))
+        g = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+        assert (o[3] == 0).all()
+        _assert_parity(g, o, TOL_LONG)

@@ -1,0 +1,105 @@
+"""The product's QP algorithm source (ad_mpc_amd/csrc/rowqp_core.h, the text the gfx950 row kernel is built from) compiled for a
+16-lane CPU emulator (tests/emu) and checked against the oracle.  Covers what the GPU cannot be asked about here: the lane
+mapping, the record aliasing schedule in LDS / workspace, masks of odd horizons, the fp32 instantiation's stopping levels.
+The linearisation fed to it is packed from the oracle's RK4 exactly as the linearisation kernel packs it."""
+import numpy as np
+import pytest
+
+from ad_mpc_amd.config import default_config
+from ad_mpc_amd.scenarios import random_scenarios, straight_scenario, assemble
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu.emu import Emu
+    return Emu()
+
+
+def _both(emu, oracle, cfg, s, dtype=np.float64):
+    from emu.emu import pack_linearisation
+    o = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    GT, bl = pack_linearisation(oracle, cfg, s["xbar"], s["ubar"], s["p"])
+    g = emu.solve(cfg, s["x0"], s["yref"], s["yref_e"], GT, bl, s["xbar"], s["ubar"], dtype=dtype)
+    return g, o
+
+
+def _strict(g, o, tol):
+    np.testing.assert_array_equal(g[3], o[3])
+    ok = o[3] == 0
+    np.testing.assert_array_equal(g[4][ok], o[4][ok])
+    assert np.abs(g[1][ok] - o[1][ok]).max(initial=0) <= tol and np.abs(g[0][ok] - o[0][ok]).max(initial=0) <= tol
+    np.testing.assert_allclose(g[2][ok], o[2][ok], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,B", [(2, 6), (3, 6), (5, 8), (19, 16), (20, 96), (33, 16), (40, 48), (64, 8), (80, 6), (128, 3)])
+def test_emulated_kernel_matches_oracle_over_horizons(emu, oracle, N, B):
+    cfg = default_config(N=N)
+    g, o = _both(emu, oracle, cfg, random_scenarios(B, N=N, seed=1234, blend=(3.0, 5.0)))
+    assert (o[3] == 0).all()
+    _strict(g, o, 1e-8 if N <= 32 else 1e-7)
+
+
+def test_emulated_kernel_option_paths(emu, oracle):
+    """Zero iterate, no trial, cold start, all state weights: every start-up path of the interior point."""
+    _strict(*_both(emu, oracle, default_config(N=20), random_scenarios(48, N=20, seed=7, init="zeros")), 1e-8)
+    c = default_config(N=20); c.ipm_try_unconstrained = 0.0
+    _strict(*_both(emu, oracle, c, random_scenarios(48, N=20, seed=77, blend=(3.0, 5.0))), 1e-8)
+    c = default_config(N=24); c.ipm_warm_thr = 0.0
+    _strict(*_both(emu, oracle, c, random_scenarios(48, N=24, seed=4321, blend=(3.0, 5.0))), 1e-8)
+    c = default_config(N=24, q=(10.0, 10.0, 100.0, 1.0, 2.0, 3.0, 4.0))
+    _strict(*_both(emu, oracle, c, random_scenarios(48, N=24, seed=99, blend=(3.0, 5.0))), 1e-8)
+
+
+def test_emulated_kernel_active_slacks_steering_bound_and_failure(emu, oracle):
+    cfg = default_config()
+    x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
+    rows = []
+    for y, d0, v in [(-10.0, 0.5, 3.0), (6.0, 0.5, 14.0), (4.0, -0.5, 6.0), (-6.0, 0.5, 14.0), (0.0, 0.6, 5.0), (0.0, -0.7, 9.0)]:
+        x = x0.copy(); x[1] = y; x[6] = d0; x[3] = v; rows.append(x)
+    X0 = np.array(rows); B = len(rows)
+    s = assemble(X0, np.repeat(xref[None], B, 0), np.repeat(uref[None], B, 0))
+    g, o = _both(emu, oracle, cfg, s)
+    _strict(g, o, 1e-8)
+    assert (g[1][:, :, 0] > 6.0).any() and np.abs(g[0][:, 1:20, 6]).max() <= 0.52 + 1e-8
+    s = random_scenarios(4, N=20, seed=5); s["yref"][1, 3, 0] = np.nan                  # non-finite data: status 4, iterate untouched
+    g, o = _both(emu, oracle, default_config(N=20), s)
+    np.testing.assert_array_equal(g[3], [0, 4, 0, 0]); np.testing.assert_array_equal(o[3], [0, 4, 0, 0])
+    assert np.array_equal(g[0][1], s["xbar"][1]) and np.isinf(g[2][1])
+
+
+def test_emulated_kernel_multipliers_are_the_adjoint(emu, oracle):
+    """want_pi: the dynamics multipliers written for the iterate snapshot satisfy the stationarity of the states they belong to:
+    pi_{k-1} = W (x_k - ref_k) + A_k' pi_k on the unconstrained components."""
+    from emu.emu import pack_linearisation
+    N = 12
+    cfg = default_config(N=N)
+    s = random_scenarios(4, N=N, seed=31, blend=(3.0, 5.0))
+    GT, bl = pack_linearisation(oracle, cfg, s["xbar"], s["ubar"], s["p"])
+    x, u, cost, st, it, pi, _ = emu.solve(cfg, s["x0"], s["yref"], s["yref_e"], GT, bl, s["xbar"], s["ubar"], want_pi=True)
+    W = cfg.Ts * np.array(cfg.W[:7]); We = np.array(cfg.We[:7])
+    for b in range(4):
+        np.testing.assert_allclose(pi[b, N - 1], We * (x[b, N] - s["yref_e"][b]), rtol=1e-9, atol=1e-12)
+        for k in range(N - 1, 0, -1):
+            _, A, _ = oracle.rk4_sens(cfg, s["xbar"][b, k], s["ubar"][b, k], s["p"][b], cfg.Ts)
+            rhs = W * (x[b, k] - s["yref"][b, k, :7]) + A.T @ pi[b, k]
+            np.testing.assert_allclose(pi[b, k - 1][:6], rhs[:6], rtol=1e-8, atol=1e-9)      # component 6 carries the steering multipliers
+
+
+def test_emulated_fp32_instantiation_converges_near_the_fp64_minimiser(emu, oracle):
+    """The float instantiation with its own stopping levels (rq_make_params): every instance converges before iter_max and lands
+    within 2e-3 (absolute) of the fp64 oracle."""
+    for N, B in [(20, 96), (80, 48)]:
+        cfg = default_config(N=N)
+        g, o = _both(emu, oracle, cfg, random_scenarios(B, N=N, seed=1234), dtype=np.float32)
+        np.testing.assert_array_equal(g[3], o[3])
+        assert g[4].max() < cfg.ipm_iter_max
+        assert np.abs(g[1] - o[1]).max() <= 2e-3 and np.abs(g[0] - o[0]).max() <= 2e-3
+
+
+def test_centring_safeguard_breaks_the_limit_cycle(emu, oracle):
+    """Scenario 10474 of the config-5 batch: without ADMPC_IPM_BLOCKED_STEP both sides ran to iter_max (mu cycling, period 4)."""
+    cfg = default_config(N=80)
+    s = random_scenarios(1, N=80, seed=1234, start=10474)
+    g, o = _both(emu, oracle, cfg, s)
+    assert o[3][0] == 0 and o[4][0] < 20
+    _strict(g, o, 1e-7)
