@@ -6,11 +6,14 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (admpc_solve_batch: shooting + QP + full step for every
-instance; at N = 20 four kernel launches) over one batch of synthetic scenarios that is already resident in HBM.  Every step starts
-from the same initial iterate (pre-staged copies), so all steps do identical work.  Workload at
-N=1 = BASELINE.json configs[1]: batch 4096 random (x0, curved reference) scenarios, horizon N=20,
-fp64.  With more GPUs every rank solves its own 4096-instance shard (weak scaling, no data-path
-collective) and the step ends with the RCCL arg-min over the scenario costs.
+instance; at N = 20 fp64 four kernel launches, otherwise two) over one batch of synthetic scenarios that is already resident
+in HBM.  Every step starts from the same initial iterate (pre-staged copies), so all steps do identical work.
+Workloads (BASELINE.json):
+  --gpus 1 (default)                                   configs[1]: batch 4096 random (x0, curved reference) scenarios, N = 20, fp64
+  --gpus N > 1 (default 8192 per GPU)                  configs[3]: 65536 scenarios at 8 GPUs, every rank its own contiguous shard
+                                                       (weak scaling, no data-path collective), RCCL arg-min at the end of the step
+  --dtype f32 --horizon 80 --batch-per-gpu 16384       configs[4]: long horizon, fp32 storage and arithmetic
+  --gp                                                 configs[2]: GP residual dynamics active
 
 Rank 0 prints ONE JSON line.
 """
@@ -33,14 +36,15 @@ from ad_mpc_amd.scenarios import random_scenarios, grid_gp  # noqa: E402
 from ad_mpc_amd import dist as adist  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector = matrix peak (AMD datasheet)
+FP32_PEAK_TFLOPS = 157.3         # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (vector)
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def algorithmic_bytes_per_solve(N):
-    """in x0 + yref + yref_e + iterate + p ; out iterate + cost + status(4 B)."""
+def algorithmic_bytes_per_solve(N, elem=8):
+    """in x0 + yref + yref_e + iterate + p ; out iterate + cost + status(4 B).  N = 20 fp64: 4564 B; N = 80 fp32: 8764 B."""
     n_in = NX + (N * NY + NX) + ((N + 1) * NX + N * NU) + 1
     n_out = (N + 1) * NX + N * NU + 1
-    return 8 * (n_in + n_out) + 4
+    return elem * (n_in + n_out) + 4
 
 
 def algorithmic_flops_per_solve(N, mean_ipm_iters, trial):
@@ -49,24 +53,24 @@ def algorithmic_flops_per_solve(N, mean_ipm_iters, trial):
     return N * 4360.0 + N * 1900.0 * (mean_ipm_iters + (0.7 if trial else 0.0))
 
 
-def measured_traffic(N, B):
-    """HBM bytes of one step from the committed PMC passes (profiles/*/..._pmc_summary.json, written by scripts/profile.sh on
+def measured_traffic(N, B, dtype):
+    """HBM bytes of one step from the committed PMC passes (profiles/rN/*pmc_summary.json, written by scripts/profile.sh on
     the same workload: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as the microarchitecture guide
-    prescribes for gfx950).  Counters cannot be read inside this process; None unless the profile matches this workload."""
-    if N != 20 or B != 4096:
-        return None
+    prescribes for gfx950).  Counters cannot be read inside this process; None unless a profile of exactly this workload exists."""
     import glob
-    best = None
     import re
-    def order(f):            # profiles/rN/vM_...: newest round, then newest build
-        m = re.search(r"r(\d+)[/\\]v(\d+)_", f)
-        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    best = None
+    def order(f):            # newest round, then newest build
+        m = re.search(r"r(\d+)[/\\]", f)
+        return (int(m.group(1)) if m else 0, os.path.getmtime(f))
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json")), key=order):
         try:
-            t = json.load(open(f)).get("_step_traffic")
+            js = json.load(open(f))
         except Exception:
-            t = None
-        if t:
+            continue
+        w = js.get("_workload", {"horizon": 20, "batch": 4096, "dtype": "f64"})      # round-1 summaries carry no tag: configs[1]
+        t = js.get("_step_traffic")
+        if t and (w.get("horizon"), w.get("batch"), w.get("dtype")) == (N, B, dtype):
             best = {"bytes": t["bytes"], "source": os.path.relpath(f, ROOT)}
     return best
 
@@ -90,7 +94,7 @@ def cpu_baseline(cfg, scen, target_seconds=12.0):
         o.solve_batch(cfg, scen["x0"], scen["yref"], scen["yref_e"], scen["p"], scen["xbar"], scen["ubar"], nthreads=nthreads)
     dt = time.perf_counter() - t
     return {"value": reps * B / dt, "unit": "solves/s", "cores": nthreads, "kind": "port",
-            "sample": "%d x the same %d-instance batch (N=%d, fp64) on %d OpenMP threads; single-thread rate %.0f solves/s"
+            "sample": "%d x the same %d-instance batch (N=%d; the oracle is fp64 whatever the GPU dtype) on %d OpenMP threads; single-thread rate %.0f solves/s"
                       % (reps, B, cfg.N, nthreads, 1.0 / t1)}
 
 
@@ -99,8 +103,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default: 4096 on one GPU (configs[1]), 8192 per GPU on several (configs[3])")
     ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64", help="f32: storage and arithmetic (configs[4] with --horizon 80 --batch-per-gpu 16384)")
     ap.add_argument("--gp", action="store_true", help="config 3: GP residual dynamics active")
     ap.add_argument("--dynamic", action="store_true", help="blend speeds 3/5 m/s so that the dynamic bicycle branch is active")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,20 +129,25 @@ def main():
     dev_index = local_rank if launched else 0
     torch.cuda.set_device(dev_index)
 
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 4096 if world == 1 else 8192
     N, B, K, Wm = args.horizon, args.batch_per_gpu, args.steps, args.warmup
+    f32 = args.dtype == "f32"
+    tdt = torch.float32 if f32 else torch.float64
+    elem = 4 if f32 else 8
     cfg = default_config(N=N, Ts=0.05)
     if args.gp:
         set_gp(cfg, grid_gp())
     blend = (3.0, 5.0) if args.dynamic else (100.0, 110.0)
     scen = random_scenarios(B, N=N, Ts=0.05, seed=1234, start=rank * B, blend=blend)
     eng = BatchSolver(cfg, device=dev_index)
-    d = eng.to_device
+    d = lambda a: eng.to_device(a, tdt)
     x0, yref, yref_e, p = d(scen["x0"]), d(scen["yref"]), d(scen["yref_e"]), d(scen["p"])
     xinit, uinit = d(scen["xbar"]), d(scen["ubar"])
     # one pre-staged iterate per step: every step starts from the same initial iterate
     xb = [xinit.clone() for _ in range(K + Wm)]
     ub = [uinit.clone() for _ in range(K + Wm)]
-    cost = torch.empty(B, dtype=torch.float64, device=eng.device)
+    cost = torch.empty(B, dtype=tdt, device=eng.device)
     status = torch.empty(B, dtype=torch.int32, device=eng.device)
     iters = torch.empty(B, dtype=torch.int32, device=eng.device)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
@@ -150,7 +160,7 @@ def main():
         eng.solve(x0, yref, yref_e, p, xb[i], ub[i], cost, status, iters)
         if timed_idx is not None: ev1[timed_idx].record()
         if launched:             # config 4: per-GPU arg-min, 16 B/rank all-gather over RCCL, second-level arg-min -- three device
-            return adist.global_argmin_device(eng, cost, index_offset=rank * B, gathered=gathered)   # operations, no host sync
+            return adist.global_argmin_device(eng, cost.double() if f32 else cost, index_offset=rank * B, gathered=gathered)   # operations, no host sync
         return None
 
     for i in range(Wm):
@@ -180,25 +190,36 @@ def main():
         value = total / elapsed
         trial = cfg.ipm_try_unconstrained != 0.0
         flops = algorithmic_flops_per_solve(N, mean_iters, trial) * B
-        byts = algorithmic_bytes_per_solve(N) * B
-        traffic = None if (args.gp or args.dynamic) else measured_traffic(N, B)
+        byts = algorithmic_bytes_per_solve(N, elem) * B
+        traffic = None if (args.gp or args.dynamic) else measured_traffic(N, B, args.dtype)
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
+        peak_tf = FP32_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS
+        if f32 and N == 80 and B == 16384:
+            wl = "BASELINE configs[4]: long horizon N=80, fp32 storage and arithmetic, batch 16384"
+        elif world > 1 or B == 8192:
+            wl = "BASELINE configs[3]: %d scenarios sharded over %d GPU(s), %d per GPU (shard of the 65536-scenario batch), N=%d, %s, RCCL arg-min" % (world * B, world, B, N, args.dtype)
+        elif args.gp:
+            wl = "BASELINE configs[2]: batch %d, N=%d, %s, GP residual-dynamics correction active" % (B, N, args.dtype)
+        else:
+            wl = "BASELINE configs[1]: batch %d random (x0, curved ref) scenarios, N=%d, %s" % (B, N, args.dtype)
+        dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
         out = {
-            "metric": "MPC solves/sec (N=%d, nx=7, nu=2, fp64)" % N, "value": value, "unit": "solves/s",
+            "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch %d/GPU random (x0, curved ref) scenarios, N=%d, fp64, one SQP-RTI step%s%s"
-                                   % (B, N, ", GP residual active" if args.gp else "", ", dynamic branch (blend 3/5)" if args.dynamic else ""),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": wl + ", one SQP-RTI step" + (", dynamic branch (blend 3/5)" if args.dynamic else ""),
                        "batch_per_gpu": B, "horizon": N, "seed": 1234,
                        "collective": "RCCL all-gather arg-min (16 B/rank)" if launched else "none"},
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": (traffic or {}).get("bytes"),
+            "roofline": {"bound": "fp32-valu" if f32 else "fp64-valu", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": ach_tf / peak_tf, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
-                         "kernel": "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>" if N == 20 else "one step = admpc_linearize_kernel + admpc_qp_kernel (stage-wise Riccati)", "kernel_ms": kern_ms,
-                         "note": "fp64 compute roof (vector = matrix peak 78.6 TFLOP/s); algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"},
+                         "kernel": ("one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
+                                    if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point)"),
+                         "kernel_ms": kern_ms,
+                         "note": "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt); roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)" % ("fp32" if f32 else "fp64", peak_tf)},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                             "bytes_per_solve": algorithmic_bytes_per_solve(N)},
+                             "bytes_per_solve": algorithmic_bytes_per_solve(N, elem)},
             "host_enqueue_ms_per_step": t_enq / K * 1e3, "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
             "unconstrained_trial": {"enabled": bool(trial), "fraction_solved_without_interior_point": float((it_host == 0).mean())},
         }

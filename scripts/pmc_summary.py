@@ -12,13 +12,18 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("linearize", "condense", "qp_dense", "expand", "qp_kernel", "argmin", "epilogue", "waypoints", "shoot"):
+    for key in ("linearize", "condense", "qp_dense", "expand", "rowqp", "argmin", "epilogue", "waypoints", "shoot"):
         if key in name:
             return key
     return None
 
 
 def main(dirs):
+    workload = None
+    if dirs and dirs[0].startswith("--workload="):            # --workload=N,B,dtype : tags the summary so that bench.py can match it
+        n, b, dt = dirs[0].split("=", 1)[1].split(",")
+        workload = {"horizon": int(n), "batch": int(b), "dtype": dt}
+        dirs = dirs[1:]
     acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))     # kernel -> counter -> dispatch -> value
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -33,11 +38,13 @@ def main(dirs):
         out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v)} for c, v in sorted(counters.items())}
     # HBM traffic of one step = sum over the step's kernels, per launch: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
     # counts 32-byte requests as 16 for wide coalesced reads and is doubled (MI355X_MICROARCH.md, HBM section)
-    step = [k for k in ("linearize", "condense", "qp_dense", "expand", "qp_kernel") if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
+    step = [k for k in ("linearize", "condense", "qp_dense", "expand", "rowqp") if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
     if step:
         fetch = sum(out[k]["FETCH_SIZE"]["mean_per_launch"] for k in step) * 1024.0 * 2.0
         write = sum(out[k]["WRITE_SIZE"]["mean_per_launch"] for k in step) * 1024.0
         out["_step_traffic"] = {"kernels": step, "fetch_bytes_corrected": fetch, "write_bytes": write, "bytes": fetch + write}
+    if workload:
+        out["_workload"] = workload
     json.dump(out, sys.stdout, indent=1)
     print()
 
