@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmpc.so")
 
 EXPORTS = (
-    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_f32", "admpc_shoot_batch",
-    "admpc_argmin", "admpc_argmin_pairs", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
+    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_ex", "admpc_solve_batch_f32", "admpc_shoot_batch",
+    "admpc_argmin", "admpc_argmin_pairs", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_actuation_batch", "admpc_resample_vel_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
 )
 
 _lib = None
@@ -40,6 +40,8 @@ def load():
     L.admpc_reserve.argtypes = [C.c_void_p, C.c_int]; L.admpc_reserve.restype = C.c_int
     L.admpc_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     L.admpc_solve_batch.restype = C.c_int
+    L.admpc_solve_batch_ex.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, dp, vp]
+    L.admpc_solve_batch_ex.restype = C.c_int
     L.admpc_solve_batch_f32.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     L.admpc_solve_batch_f32.restype = C.c_int
     L.admpc_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, vp]; L.admpc_shoot_batch.restype = C.c_int
@@ -47,6 +49,8 @@ def load():
     L.admpc_argmin_pairs.argtypes = [C.c_void_p, dp, C.c_int, dp, ip, vp]; L.admpc_argmin_pairs.restype = C.c_int
     L.admpc_shift_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, C.c_int, vp]; L.admpc_shift_batch.restype = C.c_int
     L.admpc_epilogue_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, ip, vp]; L.admpc_epilogue_batch.restype = C.c_int
+    L.admpc_actuation_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, ip, dp, ip, C.c_int, dp, dp, ip, ip, vp]; L.admpc_actuation_batch.restype = C.c_int
+    L.admpc_resample_vel_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp, vp]; L.admpc_resample_vel_batch.restype = C.c_int
     L.admpc_waypoints_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [dp] * 13 + [vp]
     L.admpc_waypoints_batch.restype = C.c_int
     L.admpc_last_error.restype = C.c_char_p

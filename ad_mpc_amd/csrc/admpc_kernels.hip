@@ -1496,6 +1496,75 @@ __global__ void admpc_epilogue_kernel(int N, int B, const double* __restrict__ x
     ack[b * 4 + 0] = (float)x[6]; ack[b * 4 + 1] = (float)u[1]; ack[b * 4 + 2] = (float)x[3]; ack[b * 4 + 3] = (float)u[0];
 }
 
+// Speed-reference clamp in front of the solve: gp_ad_mpc_node.py:344-349 resample_vel -- the reference speed of
+// slot i may not exceed |v| + i * (acc_max * dt * 0.8), the bound growing by repeated addition as in the reference (same rounding).
+// One thread per vehicle; vel_ref [B] rows of H values, `ld` values apart (e.g. row 3 of admpc_waypoints_batch's out_ref: ld = 6 H).
+__global__ void admpc_resample_vel_kernel(int B, int H, int ld, const double* __restrict__ vx, const double* __restrict__ vy,
+                                          double acc_max, double dt, double* __restrict__ vel_ref)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double bound = sqrt(__dadd_rn(__dmul_rn(vx[b], vx[b]), __dmul_rn(vy[b], vy[b])));
+    const double inc = __dmul_rn(__dmul_rn(acc_max, dt), 0.8);
+    double* v = vel_ref + (size_t)b * ld;
+    for (int i = 0; i < H; ++i) {
+        if (v[i] > bound) v[i] = bound;
+        bound = __dadd_rn(bound, inc);
+    }
+}
+
+// Post-solve safety and actuation, one thread per vehicle slot / candidate:
+//   check_pred_trj                          gp_ad_mpc_node.py:248-257 (same formula as is_valid_command, ad_3d_optimizer.py:385-394)
+//   consecutive-success gate                :206-213  (status > 0 resets the counter; fewer than `threshold` successes: no MPC command)
+//   steering command                        :222-223  clip(clip(rate) * 0.1 + measured steering)
+//   fallback (auxiliary controller)         :455-476  steering held at the measured value, acceleration -1e5 (hard brake)
+//   Ackermann record                        create_ros_ad_mpc.py:95-98 (float32 message fields)
+// cost_io (may be null): +inf for every candidate that does not produce an MPC command, so that an arg-min over it picks
+// a valid candidate only.
+__global__ void admpc_actuation_kernel(int N, int B, const double* __restrict__ xopt, const double* __restrict__ uopt,
+                                       const double* __restrict__ xref_xy, const int32_t* __restrict__ status,
+                                       const double* __restrict__ steer_meas, int32_t* __restrict__ safe_count, int threshold,
+                                       double rate_min, double rate_max, double steer_min, double steer_max,
+                                       double* __restrict__ cost_io, float* __restrict__ ack, int32_t* __restrict__ mode, int32_t* __restrict__ valid)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* x = xopt + (size_t)b * (N + 1) * NX;
+    const double* r = xref_xy + (size_t)b * (N + 1) * 2;
+    const int n = N + 1;
+    double sm = 0.0, mx = 0.0;
+    for (int i = 0; i < n - 1; ++i) {
+        const double dxv = r[i * 2] - x[i * 7], dyv = r[i * 2 + 1] - x[i * 7 + 1];
+        const double d = sqrt(dxv * dxv + dyv * dyv);
+        sm += d; mx = fmax(mx, d);
+    }
+    const double mean = sm / n;
+    double var = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double d = 0.0;
+        if (i < n - 1) { const double dxv = r[i * 2] - x[i * 7], dyv = r[i * 2 + 1] - x[i * 7 + 1]; d = sqrt(dxv * dxv + dyv * dyv); }
+        var += (d - mean) * (d - mean);
+    }
+    var /= (n - 1);
+    const int healthy = (mean < 3.0 && var < 2.0 && mx < 4.0) ? 1 : 0;
+    const int cnt = status[b] > 0 ? 0 : safe_count[b] + 1;
+    safe_count[b] = cnt;
+    const int ok = (cnt >= threshold && healthy) ? 1 : 0;
+    const double* u = uopt + (size_t)b * N * NU;
+    const double sth = steer_meas[b];
+    if (ok) {
+        const double rate_msg = (double)(float)u[1];                 // the value travels through a float32 message field
+        const double sv = fmax(fmin(rate_max, rate_msg), rate_min);
+        const double ang = fmax(fmin(steer_max, __dadd_rn(__dmul_rn(sv, 0.1), sth)), steer_min);
+        ack[b * 4 + 0] = (float)ang; ack[b * 4 + 1] = (float)u[1]; ack[b * 4 + 2] = (float)x[3]; ack[b * 4 + 3] = (float)u[0];
+    } else {
+        ack[b * 4 + 0] = (float)sth; ack[b * 4 + 1] = 0.0f; ack[b * 4 + 2] = 0.0f; ack[b * 4 + 3] = (float)(-1e5);
+    }
+    mode[b] = ok;
+    valid[b] = healthy;
+    if (cost_io && !ok) cost_io[b] = INFINITY;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1546,10 +1615,10 @@ extern "C" int admpc_rowqp_plan(int N, int elem, int B, int num_cu, int* rows, i
 extern "C" void admpc_rowqp_prepare(void);
 extern "C" void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ws, int first, int* ticket);
+        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ineq, double* ws, int first, int* ticket);
 extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
-        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ws, int first, int* ticket);
+        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ineq, float* ws, int first, int* ticket);
 
 extern "C" {
 
@@ -1697,9 +1766,24 @@ static int rowqp_fits(int B, int N, int elem)
     return worst < (1ull << 32);
 }
 
+int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
+                         double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, double* pi, double* ineq, void* stream);
+
 int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
                       double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
 {
+    return admpc_solve_batch_ex(s, B, x0, yref, yref_e, p, xbar, ubar, cost, status, iters, nullptr, nullptr, stream);
+}
+
+/* admpc_solve_batch plus the multipliers of the returned iterate (acados store_iterate contents).  With pi / ineq given the step
+ * runs on the row kernel at every horizon (the condensed N = 20 pipeline eliminates the states and carries no multipliers of the
+ * dynamics). */
+int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
+                         double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters,
+                         double* pi, double* ineq, void* stream)
+{
+    const bool snap = pi != nullptr || ineq != nullptr;
+    if (snap && !(pi && ineq)) return fail(ADMPC_EINVAL, "pi and ineq must be given together");
     if (!s) return fail(ADMPC_EINVAL, "null solver");
     if (B < 0) return fail(ADMPC_EINVAL, "negative batch");
     if (B == 0) return ADMPC_OK;
@@ -1718,7 +1802,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
         const int first = sq == 0 ? 1 : 0;
         hipLaunchKernelGGL(admpc_linearize_kernel<double>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->d_sched);
-        if (s->use_dense) {
+        if (s->use_dense && !snap) {
             constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + NX * 64) * (int)sizeof(double);
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
             if (s->qmask == 7)
@@ -1744,7 +1828,7 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
             if (admpc_rowqp_plan(N, 8, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
             if (!rowqp_fits(B, N, 8)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
             admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
-                                   xbar, ubar, cost, stat, iters, (double*)nullptr, s->d_ws, first, s->d_sched);
+                                   xbar, ubar, cost, stat, iters, pi, ineq, s->d_ws, first, s->d_sched);
         }
     }
     HIPCHK(hipGetLastError());
@@ -1777,7 +1861,7 @@ int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* y
         hipLaunchKernelGGL(admpc_linearize_kernel<float>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, (const float*)xbar, (const float*)ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, (float*)s->d_GT, (float*)s->d_bl, s->d_sched);
         admpc_rowqp_launch_f32(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const float*)s->d_GT, (const float*)s->d_bl,
-                               xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)s->d_ws, first, s->d_sched);
+                               xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, (float*)s->d_ws, first, s->d_sched);
     }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
@@ -1843,6 +1927,34 @@ int admpc_epilogue_batch(AdmpcSolver* s, int B, const double* xopt, const double
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(admpc_epilogue_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->cfg.N, B, xopt, uopt, xref_xy, ack, valid);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_actuation_batch(AdmpcSolver* s, int B, const double* xopt, const double* uopt, const double* xref_xy, const int32_t* status,
+                          const double* steer_meas, int32_t* safe_count, int threshold, double* cost_io,
+                          float* ack, int32_t* mode, int32_t* valid, void* stream)
+{
+    if (!s || B < 0 || threshold < 0) return fail(ADMPC_EINVAL, "bad argument");
+    if (B == 0) return ADMPC_OK;
+    if (!xopt || !uopt || !xref_xy || !status || !steer_meas || !safe_count || !ack || !mode || !valid) return fail(ADMPC_EINVAL, "null array argument");
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(admpc_actuation_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->cfg.N, B, xopt, uopt, xref_xy, status,
+                       steer_meas, safe_count, threshold, s->cfg.lbu[1], s->cfg.ubu[1], s->cfg.lbx_delta, s->cfg.ubx_delta, cost_io, ack, mode, valid);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_resample_vel_batch(int device, int B, int H, int ld, const double* vx, const double* vy, double acc_max, double dt,
+                             double* vel_ref, void* stream)
+{
+    if (B < 0 || H < 1 || ld < H) return fail(ADMPC_EINVAL, "admpc_resample_vel_batch: need H >= 1, ld >= H");
+    if (B == 0) return ADMPC_OK;
+    if (!vx || !vy || !vel_ref) return fail(ADMPC_EINVAL, "null array argument");
+    DeviceGuard guard(device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(admpc_resample_vel_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, H, ld, vx, vy, acc_max, dt, vel_ref);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

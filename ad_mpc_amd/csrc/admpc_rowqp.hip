@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
                                                          const T* __restrict__ GTg, const T* __restrict__ blg,
                                                          T* __restrict__ xbarg, T* __restrict__ ubarg,
                                                          T* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
-                                                         T* __restrict__ pig, T* __restrict__ wsg, int first_pass, int* __restrict__ ticket)
+                                                         T* __restrict__ pig, T* __restrict__ ineqg, T* __restrict__ wsg, int first_pass, int* __restrict__ ticket)
 {
     typedef DevX<T> X;
     extern __shared__ double smem_raw[];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
     RqParams<T> q;
     rq_make_params<T>(*cfg, q);
     RqArrays<T> io;
-    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig; io.ws = wsg;
+    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig; io.ineq = ineqg; io.ws = wsg;
     const int nquads = (B + rows - 1) / rows;
     const bool has_lds = row < rows;
     typename X::Lds lds{ smem + (has_lds ? row : 0) * inst_stride, has_lds };
@@ -105,19 +105,19 @@ void admpc_rowqp_prepare(void)
 extern "C" __attribute__((visibility("hidden")))
 void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                             const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-                            double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ws, int first, int* ticket)
+                            double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ineq, double* ws, int first, int* ticket)
 {
     hipLaunchKernelGGL((admpc_rowqp_kernel<double>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                       xbar, ubar, cost, stat, iters, pi, ws, first, ticket);
+                       xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket);
 }
 
 extern "C" __attribute__((visibility("hidden")))
 void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                             const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
-                            float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ws, int first, int* ticket)
+                            float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ineq, float* ws, int first, int* ticket)
 {
     hipLaunchKernelGGL((admpc_rowqp_kernel<float>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                       xbar, ubar, cost, stat, iters, pi, ws, first, ticket);
+                       xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket);
 }
 
 #ifdef ADMPC_PHASE_TIMERS

@@ -76,7 +76,9 @@ struct RqParams {              // wave-uniform scalars
 template <class T>
 struct RqArrays {              // wave-uniform array bases (device: kernel arguments, SGPR-addressed accesses with 32-bit lane offsets)
     const T *x0, *yref, *yref_e, *GT, *bl;
-    T *xbar, *ubar, *pi;
+    T *xbar, *ubar;
+    T *pi;                     // optional snapshot: [B][N+1][7] dynamics multipliers pi_0..pi_{N-1}, row N = multiplier of the x0 equality
+    T *ineq;                   // optional snapshot: [B][N][20] slacks T[10] and multipliers LAM[10] of every stage (record order)
     T *ws;                     // [B][N+1][RQ_RW]
 };
 
@@ -90,7 +92,7 @@ struct RowQp {
 
     const RqParams<T>& q;
     const RqArrays<T>& io;
-    I ix0, iyr, iye, igt, ibl, ixb, iub, iws;   // element offsets of the row's instance in the arrays
+    I ix0, iyr, iye, igt, ibl, ixb, iub, iws, ipi, iiq;   // element offsets of the row's instance in the arrays
     Lds lds;
     const int N;
     M owns;                    // the row works on an instance of its own (rows that only shadow another row's instance never write its workspace)
@@ -117,7 +119,7 @@ struct RowQp {
     RQ_FN RowQp(const RqParams<T>& q_, const RqArrays<T>& io_, Lds lds_, I inst, M owns_) : q(q_), io(io_), lds(lds_), N(q_.N), owns(owns_)
     {
         ix0 = inst * 7; iye = ix0; iyr = inst * (N * 9); igt = inst * (N * RQ_GTS); ibl = inst * (N * 7); ixb = inst * ((N + 1) * 7);
-        iub = inst * (N * 2); iws = inst * ((N + 1) * RQ_RW);
+        iub = inst * (N * 2); iws = inst * ((N + 1) * RQ_RW); ipi = ixb; iiq = inst * (N * 20);
         lane = X::lane();
         is_x = lane < 7; is_u = (lane == 7) | (lane == 8); is6 = lane == 6; is7 = lane == 7; lt2 = lane < 2;
         const V one = splat((T)1), zero = splat((T)0);
@@ -360,7 +362,7 @@ struct RowQp {
             const int kn = k > 0 ? k - 1 : 0;
             load_gc(kn, Gn);
             const V xn = wld(o_x + RW_XA, kn * RQ_RW), rn = X::gld(io.yref, iyr + o_y + kn * 9);
-            if (want_pi) X::gst(io.pi, ibl + o_x + k * 7, lam, is_x & pim);   // pi_k multiplies dx_{k+1} = A dx_k + B du_k + b_k
+            if (want_pi) X::gst(io.pi, ipi + o_x + k * 7, lam, is_x & pim);   // pi_k multiplies dx_{k+1} = A dx_k + B du_k + b_k
             const V ua = ld(l_ua, rec(k));
             const V l0 = ld(l_l0, rec(k)), l1 = ld(l_l0, rec(k) + 1);        // lane 6: steering pair; lanes 7, 8: bound pair of input j
             fix_gc(Gc);
@@ -377,6 +379,7 @@ struct RowQp {
             for (int l = 0; l < 6; ++l) Gc[l] = Gn[l];
             xk = xn; rk = rn;
         }
+        if (want_pi) X::gst(io.pi, ipi + o_x + N * 7, lam, is_x & pim);       // adjoint at stage 0 = multiplier of dx_0 = x0 - xbar_0
         return X::row_maxnan(rg);
     }
 
@@ -649,7 +652,7 @@ struct RowQp {
     // Returns the max-norm of the stationarity residual of this start point, as the oracle's ipm_residuals() sees it: with the
     // zero step its dynamics multipliers are zero (ru = r - lam_l + lam_u, rx = Q dx + q + steering multipliers); from the
     // trial's minimiser they are that minimiser's exact multipliers, which leaves the inequality multipliers alone.
-    RQ_FN V pass_init(V a0, V th, M warm) {
+    RQ_FN V pass_init(V a0, V th, M warm, M solved) {
         const V zero = splat((T)0);
         const M step = a0 > zero;
         const V gsc = X::sel(step, zero, splat((T)1));            // weight of the plain gradient in the residual
@@ -663,11 +666,13 @@ struct RowQp {
             const V ts = X::sel(warm, X::vmax(-qv, zero), zero) + th;
             const V tb = X::vmax(qv + X::sel(e_isd, zero, ts), th);
             const V mu0 = splat(q.mu0);
-            const V lb = X::sel(S.act, mu0 * X::rcp(tb), zero);
-            st(S.kl + o_tb, RQ_T, X::sel(S.act, tb, splat((T)1)), S.inb);
+            // rows whose trial minimiser is feasible are done: no bound is active (multiplier 0, slack = distance to the bound), the
+            // slack pairs carry the L1 weight (multiplier rho, slack 0) -- what the iterate snapshot reports for them
+            const V lb = X::sel(S.act & !solved, mu0 * X::rcp(tb), zero);
+            st(S.kl + o_tb, RQ_T, X::sel(S.act, X::sel(solved, qv, tb), splat((T)1)), S.inb);
             st(S.kl + o_tb, RQ_LAM, lb, S.inb);
-            st(S.kl + o_ts, RQ_T, X::sel(S.act, ts, splat((T)1)), S.inb & e_in);
-            st(S.kl + o_ts, RQ_LAM, X::sel(S.act, mu0 * X::rcp(ts), zero), S.inb & e_in);
+            st(S.kl + o_ts, RQ_T, X::sel(S.act, X::sel(solved, zero, ts), splat((T)1)), S.inb & e_in);
+            st(S.kl + o_ts, RQ_LAM, X::sel(S.act, X::sel(solved, rho, mu0 * X::rcp(ts)), zero), S.inb & e_in);
             // stationarity row of the pair: plain gradient (zero step only) - lam_lower + lam_upper
             const V ml = -(sgn * lb);
             const V ref6 = X::gld(io.yref, iyr + S.kc * 9 + 6);
@@ -691,13 +696,24 @@ struct RowQp {
         return X::row_maxnan(rs0);
     }
 
+    // iterate snapshot: slacks and multipliers of every stage, record order (lanes 0..9 <-> pairs)
+    RQ_FN void pass_snapshot(M pim) {
+        const M m = (lane < 10) & pim;
+        const I l10 = X::isel(lane < 10, lane, X::isplat(0));
+        RQ_NOUNROLL
+        for (int k = 0; k < N; ++k) {
+            X::gst(io.ineq, iiq + l10 + k * 20, ld(l10 + RQ_T, rec(k)), m);
+            X::gst(io.ineq, iiq + l10 + (k * 20 + 10), ld(l10 + RQ_LAM, rec(k)), m);
+        }
+    }
+
     // =================================================================================================================
     // one instance
     // =================================================================================================================
     struct Result { M failed; I iters; V rmax; };
 
-    // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the dynamics multipliers of the returned
-    // iterate, [B][N][7], to io.pi on the rows of pim.
+    // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the multipliers of the returned iterate
+    // (io.pi, io.ineq) on the rows of pim.
     RQ_FN void solve(M valid, Result& res, bool want_pi, M pim) {
         const V zero = splat((T)0), one = splat((T)1);
         X::stamp(0);
@@ -717,11 +733,11 @@ struct RowQp {
             const M ok = pass_trial_check();
             const M warm = (!ok) & X::mfrom(q.thw > (T)0);
             const V a0 = X::sel(ok | warm, one, zero);
-            rstat = pass_init(a0, X::sel(warm, splat(q.thw), splat(q.thr)), warm);
+            rstat = pass_init(a0, X::sel(warm, splat(q.thw), splat(q.thr)), warm, ok);
             active = active & !ok;
             X::stamp(2);
         } else {
-            rstat = pass_init(zero, splat(q.thr), X::mfalse());
+            rstat = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());
         }
         X::fence();
         Red R;
@@ -790,7 +806,7 @@ struct RowQp {
         sweep_rollout(true);
         X::fence();
         X::stamp(13);
-        if (want_pi) (void)sweep_adjoint(true, pim);
+        if (want_pi) { (void)sweep_adjoint(true, pim); pass_snapshot(pim); }
     }
 
     // full step, cost, outputs.  Call after solve(); `write`: rows whose iterate may be overwritten when the step is finite.

@@ -78,6 +78,18 @@ class BatchSolver:
         _lib.check(fn(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p), _ptr(xbar), _ptr(ubar),
                       _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
 
+    def solve_with_multipliers(self, x0, yref, yref_e, p, xbar, ubar, cost=None, status=None, iters=None):
+        """admpc_solve_batch_ex (float64): the step plus pi [B,N+1,7] and ineq [B,N,20] (see include/admpc.h)."""
+        N = self.N
+        B = x0.shape[0]
+        self._chk(x0, (B, NX)); self._chk(yref, (B, N, NY)); self._chk(yref_e, (B, NX)); self._chk(p, (B,))
+        self._chk(xbar, (B, N + 1, NX)); self._chk(ubar, (B, N, NU))
+        pi = torch.empty((B, N + 1, NX), dtype=torch.float64, device=self.device)
+        ineq = torch.empty((B, N, 20), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.admpc_solve_batch_ex(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p), _ptr(xbar), _ptr(ubar),
+                                                 _ptr(cost), _ptr(status), _ptr(iters), _ptr(pi), _ptr(ineq), self._stream()))
+        return pi, ineq
+
     def solve_numpy(self, x0, yref, yref_e, p, xbar, ubar, dtype=np.float64):
         """Convenience for tests / the single-instance shims: host arrays in, host arrays out
         (x, u, cost, status, iters).  dtype=np.float32 runs the fp32 path."""
@@ -160,3 +172,29 @@ class BatchSolver:
         valid = torch.empty(B, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.admpc_epilogue_batch(self._h, B, _ptr(xopt), _ptr(uopt), _ptr(xref_xy), _ptr(ack), _ptr(valid), self._stream()))
         return ack, valid
+
+    def actuation(self, xopt, uopt, xref_xy, status, steer_meas, safe_count, threshold=10, cost=None):
+        """The node's post-solve branch per slot: validity, consecutive-success gate (safe_count is updated in
+        place), steering command or brake fallback.  Returns (ack float32 [B,4], mode int32 [B], valid int32 [B]); with `cost`
+        given, the cost of every slot that issues no MPC command is set to +inf in place (arg-min over valid candidates)."""
+        N = self.N
+        B = xopt.shape[0]
+        self._chk(xopt, (B, N + 1, NX)); self._chk(uopt, (B, N, NU)); self._chk(xref_xy, (B, N + 1, 2))
+        self._chk(status, (B,), torch.int32); self._chk(steer_meas, (B,)); self._chk(safe_count, (B,), torch.int32)
+        if cost is not None: self._chk(cost, (B,))
+        ack = torch.empty((B, 4), dtype=torch.float32, device=self.device)
+        mode = torch.empty(B, dtype=torch.int32, device=self.device)
+        valid = torch.empty(B, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.admpc_actuation_batch(self._h, B, _ptr(xopt), _ptr(uopt), _ptr(xref_xy), _ptr(status), _ptr(steer_meas), _ptr(safe_count),
+                                                  int(threshold), _ptr(cost), _ptr(ack), _ptr(mode), _ptr(valid), self._stream()))
+        return ack, mode, valid
+
+    def resample_vel(self, vel_ref, vx, vy, acc_max, dt):
+        """gp_ad_mpc_node.py:344-349 on B rows at once, in place: vel_ref float64 [B,H] (may be a strided row view with unit inner stride)."""
+        B, H = vel_ref.shape
+        if vel_ref.dtype != torch.float64 or vel_ref.stride(1) != 1 or vel_ref.device != self.device:
+            raise ValueError("vel_ref: float64 [B,H] on the solver's device with unit inner stride")
+        self._chk(vx, (B,)); self._chk(vy, (B,))
+        ld = vel_ref.stride(0) if B > 1 else H
+        _lib.check(self.lib.admpc_resample_vel_batch(self.device_index, B, H, int(ld), _ptr(vx), _ptr(vy), float(acc_max), float(dt),
+                                                     C.c_void_p(vel_ref.data_ptr()), self._stream()))

@@ -53,3 +53,28 @@ def fallback_command(prev_w):
 def ackermann_fields(x_opt, w_opt):
     """create_ros_ad_mpc.py:95-98 -> (steering_angle, steering_angle_velocity, speed, acceleration)."""
     return float(x_opt[0, 6]), float(w_opt[1]), float(x_opt[0, 3]), float(w_opt[0])
+
+
+def resample_vel(vel_ref, vx, vy, acc_max, dt):
+    """gp_ad_mpc_node.py:344-349: acceleration-limited clamp of the speed reference (returns a new list)."""
+    out = [float(v) for v in vel_ref]
+    bound = math.sqrt(vx ** 2 + vy ** 2)
+    for i in range(len(out)):
+        if out[i] > bound:
+            out[i] = bound
+        bound = bound + acc_max * dt * 0.8
+    return out
+
+
+def actuation(status, healthy, safe_count, threshold, ack_fields, steer_meas, rate_min, rate_max, steer_min, steer_max):
+    """The node's branch after optimize() (gp_ad_mpc_node.py:199-235, :455-476) for one slot.
+    ack_fields = ackermann_fields(...) as they sit in the float32 message.  Returns (safe_count, mode, record) with record =
+    (steering_angle, steering_angle_velocity, speed, acceleration) as float32 values."""
+    safe_count = 0 if status > 0 else safe_count + 1
+    f32 = lambda v: float(np.float32(v))
+    if safe_count >= threshold and healthy:
+        rate = f32(ack_fields[1])
+        sv = max(min(rate_max, rate), rate_min)
+        ang = max(min(steer_max, sv * 0.1 + steer_meas), steer_min)
+        return safe_count, 1, (f32(ang), rate, f32(ack_fields[2]), f32(ack_fields[3]))
+    return safe_count, 0, (f32(steer_meas), 0.0, 0.0, f32(-1e5))

@@ -102,10 +102,17 @@ class AdmpcOcpSolver:
             tx, tu, tp = d(self._x[None]).clone(), d(self._u[None]).clone(), d(np.array([self._p[0]]))
             self._eng.shift(tx, tu, tp, rollout=self.shift_iterate == "rollout")
             self._x, self._u = tx[0].cpu().numpy(), tu[0].cpu().numpy()
-        x, u, cost, st, it = self._eng.solve_numpy(self._lbx0[None], self._yref[None], self._yref_e[None],
-                                                   np.array([self._p[0]]), self._x[None], self._u[None])
+        d = self._eng.to_device
+        tx, tu = d(self._x[None]).clone(), d(self._u[None]).clone()
+        cost = torch.empty(1, dtype=torch.float64, device=self._eng.device)
+        st = torch.empty(1, dtype=torch.int32, device=self._eng.device); it = torch.empty_like(st)
+        pi, ineq = self._eng.solve_with_multipliers(d(self._lbx0[None]), d(self._yref[None]), d(self._yref_e[None]), d(np.array([self._p[0]])),
+                                                    tx, tu, cost, st, it)
+        torch.cuda.synchronize(self._eng.device)
+        st, it, cost = st.cpu().numpy(), it.cpu().numpy(), cost.cpu().numpy()
         if st[0] == 0:          # acados leaves the iterate untouched only if the QP failed outright
-            self._x, self._u = x[0], u[0]
+            self._x, self._u = tx[0].cpu().numpy(), tu[0].cpu().numpy()
+            self._pi, self._ineq = pi[0].cpu().numpy(), ineq[0].cpu().numpy()
         self._status, self._qp_iter, self._cost = int(st[0]), int(it[0]), float(cost[0])
         return self._status
 
@@ -115,12 +122,38 @@ class AdmpcOcpSolver:
             filename = "admpc_iterate.json"
         if not overwrite and os.path.isfile(filename):
             raise Exception("AdmpcOcpSolver.store_iterate(): file %s exists (use overwrite=True)" % filename)
+        N = self.N
+        pi = getattr(self, "_pi", None)
+        iq = getattr(self, "_ineq", None)
         d = {}
-        for k in range(self.N + 1):
+        for k in range(N + 1):
             d["x_%d" % k] = self._x[k].tolist()
-            d["u_%d" % k] = self._u[k].tolist() if k < self.N else []
-            for f in ("pi", "lam", "t", "sl", "su", "z"):
-                d["%s_%d" % (f, k)] = []
+            d["u_%d" % k] = self._u[k].tolist() if k < N else []
+            d["z_%d" % k] = []
+            if pi is None or k == N:                     # no solve yet (multipliers all zero in acados too) / terminal stage: no constraints
+                zero = pi is None and k < N
+                nb = 7 if k == 0 else 1
+                d["pi_%d" % k] = [0.0] * NX if zero else []
+                d["lam_%d" % k] = [0.0] * (8 + 2 * nb) if zero else []
+                d["t_%d" % k] = [0.0] * (8 + 2 * nb) if zero else []
+                d["sl_%d" % k] = [0.0] * NU if zero else []
+                d["su_%d" % k] = [0.0] * NU if zero else []
+                continue
+            t, lam = iq[k, :10], iq[k, 10:]
+            # acados order per stage: [lbu(2), lbx(nbx), ubu(2), ubx(nbx), ls(2), us(2)], nbx = 7 at stage 0 (initial-state equality, whose
+            # multiplier is split by sign) and 1 (steering angle) afterwards (SURVEY 8c pin 2 (iii)); record order see include/admpc.h
+            if k == 0:
+                nu0 = pi[N]
+                lbx_l, ubx_l = np.maximum(nu0, 0.0).tolist(), np.maximum(-nu0, 0.0).tolist()
+                lbx_t, ubx_t = [0.0] * NX, [0.0] * NX
+            else:
+                lbx_l, ubx_l, lbx_t, ubx_t = [lam[4]], [lam[5]], [t[4]], [t[5]]
+            d["pi_%d" % k] = pi[k].tolist()
+            d["lam_%d" % k] = [lam[0], lam[2]] + lbx_l + [lam[1], lam[3]] + ubx_l + [lam[6], lam[8]] + [lam[7], lam[9]]
+            d["t_%d" % k] = [t[0], t[2]] + lbx_t + [t[1], t[3]] + ubx_t + [t[6], t[8]] + [t[7], t[9]]
+            d["sl_%d" % k] = [t[6], t[8]]
+            d["su_%d" % k] = [t[7], t[9]]
+        d = {k: [float(v) for v in vals] for k, vals in d.items()}
         with open(filename, "w") as f:
             json.dump(d, f, indent=4, sort_keys=True)
 

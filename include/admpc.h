@@ -146,6 +146,20 @@ int admpc_solve_batch(AdmpcSolver* s, int B,
                       double* cost, int32_t* status, int32_t* iters,
                       void* stream);
 
+/* admpc_solve_batch plus the multipliers of the returned iterate -- what acados' store_iterate writes next to x and u
+ * (format of src/ad_mpc/sim_car_iterate.json; SURVEY 8c pin 2):
+ *   pi   [B][N+1][7]  rows 0..N-1: multipliers pi_k of x_{k+1} = phi(x_k, u_k); row N: multiplier of the initial-state equality
+ *                     (acados splits it into the lbx / ubx multipliers of stage 0: positive part -> lbx, negative part -> ubx)
+ *   ineq [B][N][20]   per stage: slacks t[10] then multipliers lam[10] of the pairs
+ *                     {lbu0, ubu0, lbu1, ubu1, lbx(delta), ubx(delta), sl0>=0, su0>=0, sl1>=0, su1>=0}
+ *                     (stage 0 has no steering bound: slack 1, multiplier 0 there)
+ * Both NULL: identical to admpc_solve_batch.  Both given: the step runs on the row kernel at every horizon. */
+int admpc_solve_batch_ex(AdmpcSolver* s, int B,
+                         const double* x0, const double* yref, const double* yref_e, const double* p,
+                         double* xbar, double* ubar,
+                         double* cost, int32_t* status, int32_t* iters,
+                         double* pi, double* ineq, void* stream);
+
 /* The same step in fp32 storage AND arithmetic (BASELINE configs[4]: long horizons, large batches).  Arguments as above with
  * float arrays.  The interior point of this entry stops at fp32 levels (complementarity 1e-3, residual 1e-2, last step 1e-3;
  * tighter values in cfg are clipped to these) -- the result is the fp64 minimiser to about 1e-3 of the input range.
@@ -192,6 +206,26 @@ int admpc_shift_batch(AdmpcSolver* s, int B, double* xbar, double* ubar, const d
 int admpc_epilogue_batch(AdmpcSolver* s, int B,
                          const double* xopt, const double* uopt, const double* xref_xy,
                          float* ack, int32_t* valid, void* stream);
+
+/* Post-solve safety and actuation, the whole branch the node runs after optimize() -- one record per vehicle slot
+ * (or per candidate of a scenario batch):
+ *   check_pred_trj (gp_ad_mpc_node.py:248-257)  -> valid [B]
+ *   consecutive-success gate (:206-213): safe_count [B] is in/out -- status > 0 resets it, otherwise it is incremented; an MPC
+ *     command is issued only with safe_count >= threshold (the node uses 10) AND a healthy prediction
+ *   steering command (:222-223): steering_angle = clip(clip(u1, rate bounds) * 0.1 + steer_meas, steering bounds)
+ *   otherwise the auxiliary controller's record (:455-476): steering held at steer_meas, acceleration -1e5, the rest 0
+ *   -> ack [B][4] = {steering_angle, steering_angle_velocity, speed, acceleration} (float32 message fields), mode [B] 1 = MPC, 0 = brake
+ *   cost_io [B] (may be NULL): set to +inf wherever mode == 0, so that admpc_argmin over it picks among valid candidates only.
+ * Bounds come from cfg (lbu[1] / ubu[1] = steering-rate bounds, lbx_delta / ubx_delta = steering bounds: ad_3d.py:66-71). */
+int admpc_actuation_batch(AdmpcSolver* s, int B, const double* xopt, const double* uopt, const double* xref_xy, const int32_t* status,
+                          const double* steer_meas, int32_t* safe_count, int threshold, double* cost_io,
+                          float* ack, int32_t* mode, int32_t* valid, void* stream);
+
+/* Speed-reference clamp in front of the solve: gp_ad_mpc_node.py:344-349 resample_vel, in place:
+ *   bound = sqrt(vx^2 + vy^2); for i < H: vel_ref[i] = min(vel_ref[i], bound); bound += acc_max * dt * 0.8
+ * vel_ref: B rows of H values, consecutive rows `ld` values apart (row 3 of admpc_waypoints_batch's out_ref: ld = 6 * H). */
+int admpc_resample_vel_batch(int device, int B, int H, int ld, const double* vx, const double* vy, double acc_max, double dt,
+                             double* vel_ref, void* stream);
 
 /* Local reference generator: batched RefTrajectory.get_waypoints (src/ad_mpc/ref_traj.py:89-171) for B vehicle
  * poses against ONE global trajectory of M waypoints (columns as built by RefTrajectory.set_traj, ref_traj.py:67-86, plus the

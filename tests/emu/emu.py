@@ -43,11 +43,12 @@ class Emu:
         yref = c(yref).reshape(B, N, NY); yref_e = c(yref_e).reshape(B, NX); GT = c(GT).reshape(B, N, 42); bl = c(bl).reshape(B, N, 7)
         x = c(xbar).reshape(B, N + 1, NX).copy(); u = c(ubar).reshape(B, N, NU).copy()
         cost = np.empty(B, dtype=dtype); st = np.empty(B, dtype=np.int32); it = np.empty(B, dtype=np.int32)
-        pi = np.zeros((B, N, NX), dtype=dtype) if want_pi else None
+        pi = np.zeros((B, N + 1, NX), dtype=dtype) if want_pi else None
+        ineq = np.zeros((B, N, 20), dtype=dtype) if want_pi else None
         rmax = np.zeros(B, dtype=dtype)
         f = self.lib.rowqp_emu_solve_f64 if dtype == np.float64 else self.lib.rowqp_emu_solve_f32
         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
-        f.argtypes = [C.POINTER(AdmpcConfig), C.c_int] + [C.c_void_p] * 12
-        rc = f(C.byref(cfg), B, vp(x0), vp(yref), vp(yref_e), vp(GT), vp(bl), vp(x), vp(u), vp(cost), vp(st), vp(it), vp(pi), vp(rmax))
+        f.argtypes = [C.POINTER(AdmpcConfig), C.c_int] + [C.c_void_p] * 13
+        rc = f(C.byref(cfg), B, vp(x0), vp(yref), vp(yref_e), vp(GT), vp(bl), vp(x), vp(u), vp(cost), vp(st), vp(it), vp(pi), vp(ineq), vp(rmax))
         assert rc == 0
-        return (x, u, cost, st, it) + ((pi,) if want_pi else ()) + (rmax,)
+        return (x, u, cost, st, it) + ((pi, ineq) if want_pi else ()) + (rmax,)

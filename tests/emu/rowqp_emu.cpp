@@ -108,7 +108,7 @@ struct EmuX {
 
 template <class T>
 int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T* yref_e, const T* GT, const T* bl,
-              T* xbar, T* ubar, T* cost, int32_t* status, int32_t* iters, T* pi, T* rmax)
+              T* xbar, T* ubar, T* cost, int32_t* status, int32_t* iters, T* pi, T* ineq, T* rmax)
 {
     typedef EmuX<T> X;
     const int N = cfg->N;
@@ -118,7 +118,7 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
         for (auto& v : lds) v = std::nan("");                    // any read of an unwritten slot that matters shows up
         for (auto& v : ws) v = std::nan("");
         RqArrays<T> io;
-        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi; io.ws = ws.data() - (size_t)b * (N + 1) * RQ_RW;
+        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi; io.ineq = ineq; io.ws = ws.data() - (size_t)b * (N + 1) * RQ_RW;
         typename X::Lds L{lds.data(), (int)lds.size()};
         RowQp<X> S(q, io, L, X::isplat(b), X::mtrue());
         typename RowQp<X>::Result res;
@@ -137,9 +137,9 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
 
 extern "C" {
 int rowqp_emu_solve_f64(const AdmpcConfig* cfg, int B, const double* x0, const double* yref, const double* yref_e, const double* GT,
-                        const double* bl, double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, double* pi, double* rmax)
-{ return emu_solve<double>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, rmax); }
+                        const double* bl, double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, double* pi, double* ineq, double* rmax)
+{ return emu_solve<double>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, ineq, rmax); }
 int rowqp_emu_solve_f32(const AdmpcConfig* cfg, int B, const float* x0, const float* yref, const float* yref_e, const float* GT,
-                        const float* bl, float* xbar, float* ubar, float* cost, int32_t* status, int32_t* iters, float* pi, float* rmax)
-{ return emu_solve<float>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, rmax); }
+                        const float* bl, float* xbar, float* ubar, float* cost, int32_t* status, int32_t* iters, float* pi, float* ineq, float* rmax)
+{ return emu_solve<float>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, ineq, rmax); }
 }

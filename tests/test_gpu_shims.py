@@ -133,3 +133,38 @@ def test_shift_iterate_option_of_the_seam(oracle):
     sol = AdmpcOcpSolver(cfg); sol.shift_iterate = "yes"
     with pytest.raises(Exception, match="shift_iterate"):
         sol.solve()
+
+
+def test_store_iterate_carries_the_acados_multipliers(golden_kat, tmp_path):
+    """AdmpcOcpSolver.store_iterate writes pi / lam / t / sl / su in the layout of the reference's sim_car_iterate.json
+    (stage 0: 22 multipliers, later stages 10, terminal stage none): solve one RTI step from the reference's converged
+    acados iterate, store, and compare with the PI / LAM acados stored (<= 1e-7); a load_iterate of the file round-trips."""
+    import json
+    from ad_mpc_amd.ocp_solver import AdmpcOcpSolver
+    k = golden_kat
+    N = k["N"]
+    cfg = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"])
+    sol = AdmpcOcpSolver(cfg)
+    X, U = np.array(k["X"]), np.array(k["U"])
+    for j in range(N + 1):
+        sol.set(j, "x", X[j])
+        if j < N:
+            sol.set(j, "u", U[j]); sol.set(j, "yref", np.array(k["yref"][j])); sol.set(j, "p", np.array([0.0]))
+    sol.set(N, "yref", np.array(k["yref_e"])); sol.set(N, "p", np.array([0.0]))
+    sol.set(0, "lbx", np.array(k["x0"])); sol.set(0, "ubx", np.array(k["x0"]))
+    assert sol.solve() == 0
+    f = str(tmp_path / "it.json")
+    sol.store_iterate(f)
+    d = json.load(open(f))
+    assert len(d["lam_0"]) == 22 and len(d["t_0"]) == 22 and len(d["lam_1"]) == 10 and d["lam_%d" % N] == [] and d["pi_%d" % N] == []
+    for j in range(N):
+        assert np.abs(np.array(d["pi_%d" % j]) - np.array(k["PI"][j])).max() <= 1e-7
+        dl = np.abs(np.array(d["lam_%d" % j]) - np.array(k["LAM"][j]))
+        if j == 0:
+            dl[[4, 13]] = 0.0       # psi entry of the x0-equality multiplier: depends on yref_0[psi], which the fixture cannot know (see tests/test_rowqp_emu.py)
+        assert dl.max() <= 1e-7
+        assert np.abs(np.array(d["u_%d" % j]) - U[j]).max() <= 1e-8
+        assert len(d["sl_%d" % j]) == 2 and len(d["su_%d" % j]) == 2
+    sol2 = AdmpcOcpSolver(cfg)
+    sol2.load_iterate(f)
+    assert np.abs(sol2.get(3, "x") - sol.get(3, "x")).max() == 0.0
