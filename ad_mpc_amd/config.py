@@ -55,6 +55,7 @@ class AdmpcConfig(C.Structure):
         ("ipm_tol_step", C.c_double),
         ("ipm_try_unconstrained", C.c_double),
         ("ipm_warm_thr", C.c_double),
+        ("sqp_tol", C.c_double),
         ("gp", AdmpcGp * GP_MAX),
     ]
 
@@ -100,7 +101,7 @@ IPM_TOL_RES = 1e-9
 IPM_TOL_STEP = 1e-6
 
 
-def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TERMINAL_SCALE, sqp_iters=1):
+def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TERMINAL_SCALE, sqp_iters=1, sqp_tol=0.0):
     """The reference's shipped OCP for horizon ``N`` and sampling time ``Ts``."""
     if not (2 <= N <= MAX_N):
         raise ValueError("N must be in [2, %d]" % MAX_N)
@@ -108,6 +109,7 @@ def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TER
     c.N = int(N)
     c.ipm_iter_max = IPM_ITER_MAX
     c.sqp_iters = int(sqp_iters)
+    c.sqp_tol = float(sqp_tol)
     c.n_gp = 0
     c.Ts = float(Ts)
     for i in range(NX):

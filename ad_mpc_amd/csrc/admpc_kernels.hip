@@ -1174,8 +1174,9 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
     const double wq = lane < NX ? Ts * cfg->W[r7] : 0.0, wqe = lane < NX ? cfg->We[r7] : 0.0;
     const double Rj = Ts * cfg->W[NX + ji];
     const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
+    const double sqp_tol = (cfg->sqp_iters > 1 && cfg->sqp_tol > 0.0) ? cfg->sqp_tol : 0.0;
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
-        if (statusg[inst] != 0) continue;                   // failed in the interior-point kernel (or in an earlier SQP iteration)
+        if (statusg[inst] != 0) continue;                   // failed in the interior-point kernel (or failed / converged in an earlier SQP iteration)
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
         const double* ubg = ubarg + (size_t)inst * N * NU;
         const double* yrg = yrefg + (size_t)inst * N * NY;
@@ -1190,12 +1191,13 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         double dx = lane < NX ? x0g[(size_t)inst * NX + r7] - xbg[r7] : 0.0;      // dx_0 (lanes 0..6)
         WSYNC();
         bool bad = false;
-        double J = 0.0;
+        double J = 0.0, snorm = 0.0;                       // snorm: max |full step| and |shooting defect| of this SQP step (cfg.sqp_tol)
         static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double e = dx + dq[k * 7 + r7];
             J += 0.5 * (k < N ? wq : wqe) * e * e;
             if (!(fabs(dx) <= 1e300)) bad = true;
+            if (lane < NX) { snorm = OpMaxNan::f(snorm, fabs(dx)); if constexpr (k < N) snorm = OpMaxNan::f(snorm, fabs(bl[k * 7 + r7])); }
             if (lane < NX) dq[k * 7 + lane] = dx;            // slot k now holds dx_k
             if constexpr (k < N) {
                 const double* Gk = GT + k * GTS;
@@ -1214,10 +1216,12 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         });
         const double unew = ubar_i + du;
         if (uact && !(fabs(unew) <= 1e300)) bad = true;
-        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+        if (uact) snorm = OpMaxNan::f(snorm, fabs(du));
+        const bool conv = sqp_tol > 0.0 && wave_reduce<OpMaxNan>(snorm) <= sqp_tol;
+        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : (conv ? -1 : ADMPC_STATUS_SUCCESS);     // -1: converged, see admpc_solve_batch
         double Ju = 0.0;
         WSYNC();
-        if (status == ADMPC_STATUS_SUCCESS) {
+        if (status <= 0) {
             double* xo = xbarg + (size_t)inst * (N + 1) * NX;
             double* uo = ubarg + (size_t)inst * N * NU;
 #pragma unroll
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         const double Jt = wave_reduce<OpSum>(J + Ju);
         if (lane == 0) {
 #ifndef ADMPC_TRACE_SCHED
-            if (costg) costg[inst] = status == ADMPC_STATUS_SUCCESS ? Jt : INFINITY;
+            if (costg) costg[inst] = status <= 0 ? Jt : INFINITY;
 #endif
             statusg[inst] = status;
         }
@@ -1496,20 +1500,33 @@ __global__ void admpc_epilogue_kernel(int N, int B, const double* __restrict__ x
     ack[b * 4 + 0] = (float)x[6]; ack[b * 4 + 1] = (float)u[1]; ack[b * 4 + 2] = (float)x[3]; ack[b * 4 + 3] = (float)u[0];
 }
 
+// end of an SQP solve with a tolerance: -1 (converged in some step) -> 0, still 0 after the last step -> ADMPC_STATUS_MAXITER
+__global__ void admpc_sqp_finalize_kernel(int B, int32_t* __restrict__ status)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int st = status[b];
+    status[b] = st == -1 ? ADMPC_STATUS_SUCCESS : (st == 0 ? ADMPC_STATUS_MAXITER : st);
+}
+
 // Speed-reference clamp in front of the solve: gp_ad_mpc_node.py:344-349 resample_vel -- the reference speed of
 // slot i may not exceed |v| + i * (acc_max * dt * 0.8), the bound growing by repeated addition as in the reference (same rounding).
 // One thread per vehicle; vel_ref [B] rows of H values, `ld` values apart (e.g. row 3 of admpc_waypoints_batch's out_ref: ld = 6 H).
 __global__ void admpc_resample_vel_kernel(int B, int H, int ld, const double* __restrict__ vx, const double* __restrict__ vy,
                                           double acc_max, double dt, double* __restrict__ vel_ref)
 {
+#pragma clang fp contract(off)      // every product and sum rounded on its own, as the host's Python arithmetic does (hipcc contracts by default)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double bound = sqrt(__dadd_rn(__dmul_rn(vx[b], vx[b]), __dmul_rn(vy[b], vy[b])));
-    const double inc = __dmul_rn(__dmul_rn(acc_max, dt), 0.8);
+    // plain operators under the pragma above (the __dmul_rn / __dadd_rn wrappers of the HIP headers are inlined WITH the translation
+    // unit's contraction flag and would be fused into an FMA)
+    const double sx = vx[b] * vx[b], sy = vy[b] * vy[b];
+    double bound = __dsqrt_rn(sx + sy);
+    const double inc = (acc_max * dt) * 0.8;
     double* v = vel_ref + (size_t)b * ld;
     for (int i = 0; i < H; ++i) {
         if (v[i] > bound) v[i] = bound;
-        bound = __dadd_rn(bound, inc);
+        bound = bound + inc;
     }
 }
 
@@ -1527,6 +1544,7 @@ __global__ void admpc_actuation_kernel(int N, int B, const double* __restrict__ 
                                        double rate_min, double rate_max, double steer_min, double steer_max,
                                        double* __restrict__ cost_io, float* __restrict__ ack, int32_t* __restrict__ mode, int32_t* __restrict__ valid)
 {
+#pragma clang fp contract(off)      // the steering command is two separately rounded operations in the reference (:223)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double* x = xopt + (size_t)b * (N + 1) * NX;
@@ -1555,7 +1573,8 @@ __global__ void admpc_actuation_kernel(int N, int B, const double* __restrict__ 
     if (ok) {
         const double rate_msg = (double)(float)u[1];                 // the value travels through a float32 message field
         const double sv = fmax(fmin(rate_max, rate_msg), rate_min);
-        const double ang = fmax(fmin(steer_max, __dadd_rn(__dmul_rn(sv, 0.1), sth)), steer_min);
+        const double scaled = sv * 0.1;
+        const double ang = fmax(fmin(steer_max, scaled + sth), steer_min);
         ack[b * 4 + 0] = (float)ang; ack[b * 4 + 1] = (float)u[1]; ack[b * 4 + 2] = (float)x[3]; ack[b * 4 + 3] = (float)u[0];
     } else {
         ack[b * 4 + 0] = (float)sth; ack[b * 4 + 1] = 0.0f; ack[b * 4 + 2] = 0.0f; ack[b * 4 + 3] = (float)(-1e5);
@@ -1571,6 +1590,7 @@ __global__ void admpc_actuation_kernel(int N, int B, const double* __restrict__ 
 // C ABI (include/admpc.h)
 // =============================================================================================
 #include <string>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -1592,6 +1612,7 @@ struct AdmpcSolver {
     int* d_sched;            // [SCHED_HDR + SCHED_NB * cap] work scheduler of the persistent interior-point waves
     int qmask;               // 7 when only x, y, psi carry tracking weights (specialised condensing kernel), else 127
     double* d_ws;            // [cap][N+1][36] workspace of the row kernel (sweep-private state, L2-resident)
+    double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
 };
 
 // Every entry point runs on the solver's device and restores the caller's current device on return (a host with several GPUs
@@ -1657,6 +1678,7 @@ static int validate(const AdmpcConfig* c)
     }
     if (!(c->W[NX] > 0 && c->W[NX + 1] > 0)) return fail(ADMPC_EINVAL, "input weights must be positive (strict convexity)");
     if (c->ipm_iter_max < 1) return fail(ADMPC_EINVAL, "ipm_iter_max < 1");
+    if (!(c->sqp_tol >= 0)) return fail(ADMPC_EINVAL, "sqp_tol must be >= 0");
     if (!(c->ipm_mu0 > 0) || !(c->ipm_thr0 > 0) || !(c->ipm_warm_thr >= 0)) return fail(ADMPC_EINVAL, "ipm_mu0, ipm_thr0 must be > 0 and ipm_warm_thr >= 0");
     return ADMPC_OK;
 }
@@ -1679,7 +1701,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         int r_, st_, lb_, g_;
         if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     }
-    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr;
+    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr;
     {   // ADMPC_QP=riccati forces the stage-wise Riccati kernel (A/B tests); default: condensed kernel where instantiated
         const char* e = getenv("ADMPC_QP");
         s->use_dense = (cfg->N == 20) && !(e && strcmp(e, "riccati") == 0);
@@ -1724,6 +1746,7 @@ void admpc_destroy(AdmpcSolver* s)
     if (s->d_H) (void)hipFree(s->d_H);
     if (s->d_aux) (void)hipFree(s->d_aux);
     if (s->d_ws) (void)hipFree(s->d_ws);
+    if (s->d_pairs) (void)hipFree(s->d_pairs);
     delete s;
 }
 
@@ -1831,6 +1854,8 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
                                    xbar, ubar, cost, stat, iters, pi, ineq, s->d_ws, first, s->d_sched);
         }
     }
+    if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
+        hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }
@@ -1863,6 +1888,8 @@ int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* y
         admpc_rowqp_launch_f32(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const float*)s->d_GT, (const float*)s->d_bl,
                                xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, (float*)s->d_ws, first, s->d_sched);
     }
+    if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
+        hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }
@@ -1899,6 +1926,40 @@ int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, 
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(admpc_argmin_pairs_kernel, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, pairs, W, val, idx);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+// RCCL is resolved at the first call (dlopen): the library loads and every other entry point works on a host without it.
+namespace {
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*nccl_count_t)(void*, int*);
+struct RcclApi { nccl_allgather_t all_gather; nccl_count_t comm_count; bool tried; };
+RcclApi g_rccl = { nullptr, nullptr, false };
+}
+
+int admpc_argmin_global(AdmpcSolver* s, const double* cost, int B, int64_t index_offset, void* nccl_comm,
+                        double* val, int64_t* idx, void* stream)
+{
+    if (!s || !cost || !val || !idx || B <= 0 || !nccl_comm) return fail(ADMPC_EINVAL, "bad argument");
+    if (!g_rccl.tried) {
+        g_rccl.tried = true;
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (h) { g_rccl.all_gather = (nccl_allgather_t)dlsym(h, "ncclAllGather"); g_rccl.comm_count = (nccl_count_t)dlsym(h, "ncclCommCount"); }
+    }
+    if (!g_rccl.all_gather || !g_rccl.comm_count) return fail(ADMPC_ENODEV, "librccl.so (ncclAllGather, ncclCommCount) not available");
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    int nranks = 0;
+    if (g_rccl.comm_count(nccl_comm, &nranks) != 0 || nranks < 1 || nranks > 256) return fail(ADMPC_EINVAL, "ncclCommCount failed or more than 256 ranks");
+    if (!s->d_pairs) HIPCHK(hipMalloc((void**)&s->d_pairs, (size_t)(1 + 256) * 2 * sizeof(double)));
+    hipStream_t st = (hipStream_t)stream;
+    double* mine = s->d_pairs;                       // (cost, index bits)
+    double* all = s->d_pairs + 2;
+    hipLaunchKernelGGL(admpc_argmin_kernel, dim3(1), dim3(256), 0, st, cost, B, index_offset, mine, (int64_t*)(mine + 1));
+    if (g_rccl.all_gather(mine, all, 2, 8 /* ncclFloat64 */, nccl_comm, st) != 0) return fail(ADMPC_EHIP, "ncclAllGather failed");
+    hipLaunchKernelGGL(admpc_argmin_pairs_kernel, dim3(1), dim3(WAVE), 0, st, (const double*)all, nranks, val, idx);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

@@ -49,18 +49,38 @@ def global_argmin(val, idx, group=None):
     return pick_min(vals, idxs)
 
 
-def global_argmin_device(engine, cost, index_offset=0, group=None, gathered=None):
-    """The N-GPU arg-min in three device operations and no host synchronisation: admpc_argmin into a 16-byte record,
-    all-gather of the records (RCCL), admpc_argmin_pairs.  Returns a float64[2] device tensor
-    (value, bits of the int64 global index); `unpack_pair` reads it on the host."""
-    pair = engine.argmin_pair(cost, index_offset)
+def pack_pair(val, idx):
+    """The 16-byte record of the exchange: float64[2] = (value, bit pattern of the int64 global index)."""
+    return torch.cat([val.reshape(1).to(torch.float64), idx.reshape(1).to(torch.int64).view(torch.float64)])
+
+
+def pairs_min_torch(pairs):
+    """torch restatement of admpc_argmin_pairs (NaN -> +inf, ties -> lowest global index) on float64[W,2] records; used as the
+    reducer of the gloo CPU tests, where the record path below runs without a GPU."""
+    vals = pairs[:, 0].contiguous()
+    idxs = pairs[:, 1].contiguous().view(torch.int64)
+    v, i = pick_min(vals, idxs)
+    return pack_pair(v, i)
+
+
+def global_argmin_records(pair, reduce_pairs, group=None, gathered=None):
+    """The record path of the N-GPU arg-min, whatever the backend: this rank's 16-byte record, all-gather of the records (one
+    collective, 16 B per rank), second-level arg-min `reduce_pairs` over the gathered float64[W,2] records.  Every rank returns
+    the same float64[2] record."""
     if not (dist.is_available() and dist.is_initialized()):
         return pair
     world = dist.get_world_size(group)
     if gathered is None:
         gathered = torch.empty((world, 2), dtype=torch.float64, device=pair.device)
     dist.all_gather_into_tensor(gathered.view(-1), pair, group=group)
-    return engine.argmin_pairs(gathered)
+    return reduce_pairs(gathered)
+
+
+def global_argmin_device(engine, cost, index_offset=0, group=None, gathered=None):
+    """The N-GPU arg-min in three device operations and no host synchronisation: admpc_argmin into a 16-byte record,
+    all-gather of the records (RCCL), admpc_argmin_pairs.  Returns a float64[2] device tensor
+    (value, bits of the int64 global index); `unpack_pair` reads it on the host."""
+    return global_argmin_records(engine.argmin_pair(cost, index_offset), engine.argmin_pairs, group=group, gathered=gathered)
 
 
 def unpack_pair(pair):

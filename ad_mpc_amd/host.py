@@ -58,7 +58,7 @@ def ackermann_fields(x_opt, w_opt):
 def resample_vel(vel_ref, vx, vy, acc_max, dt):
     """gp_ad_mpc_node.py:344-349: acceleration-limited clamp of the speed reference (returns a new list)."""
     out = [float(v) for v in vel_ref]
-    bound = math.sqrt(vx ** 2 + vy ** 2)
+    bound = math.sqrt(vx * vx + vy * vy)          # the reference writes **2 (libm pow: machine-dependent last bit); see oracle/actuation_oracle.py
     for i in range(len(out)):
         if out[i] > bound:
             out[i] = bound

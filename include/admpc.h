@@ -57,6 +57,7 @@ extern "C" {
 
 /* status per instance (acados enum values used by the reference) */
 #define ADMPC_STATUS_SUCCESS     0
+#define ADMPC_STATUS_MAXITER     2   /* SQP mode with sqp_tol > 0: not converged within sqp_iters steps (iterate and cost are valid) */
 #define ADMPC_STATUS_QP_FAILURE  4
 
 /* One 1-D squared-exponential residual GP: f[out] += mu(z),  z = [x;u][feat]
@@ -107,6 +108,10 @@ typedef struct AdmpcConfig {
                                 * from it instead of from the zero step -- inputs, states and dynamics multipliers of the
                                 * minimiser, input slacks sl/su = violation + ipm_warm_thr, every inequality slack clipped
                                 * below at ipm_warm_thr, multipliers ipm_mu0 / slack.  0: cold start.  Default 0.01. */
+    double  sqp_tol;           /* sqp_iters > 1 only (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): > 0 stops an instance as soon
+                                * as a full step is no longer than sqp_tol (max-norm over states and inputs) from a linearisation point
+                                * whose shooting defects are below sqp_tol too; an instance that has not got there after sqp_iters
+                                * steps returns status 2 (acados ACADOS_MAXITER) with its last iterate.  0: always sqp_iters steps. */
     AdmpcGp gp[ADMPC_GP_MAX];
 } AdmpcConfig;
 
@@ -190,6 +195,14 @@ int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset
  * each other by every GPU, all-gathered into one array -- reduced with the same rules to the device scalars val/idx.
  * (val and idx of admpc_argmin may point into one such 16-byte pair; the index travels as the bit pattern of an int64.) */
 int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, int64_t* idx, void* stream);
+
+/* The whole cross-GPU arg-min for a host that is not Python (one process per GPU): local admpc_argmin into a 16-byte
+ * (cost, global index) record, ncclAllGather of the records over `nccl_comm` (an ncclComm_t of RCCL, passed as void*; 16 B per rank:
+ * the only collective of the whole path), admpc_argmin_pairs over the gathered records -- three operations on `stream`, no host
+ * synchronisation.  Every rank receives the winner in val / idx (device scalars).  RCCL is looked up at the first call (dlopen of
+ * librccl.so); ADMPC_ENODEV when it is not installed. */
+int admpc_argmin_global(AdmpcSolver* s, const double* cost, int B, int64_t index_offset, void* nccl_comm,
+                        double* val, int64_t* idx, void* stream);
 
 /* Receding-horizon shift of the iterate between two solves.  The reference never shifts its iterate
  * (the acados capsule keeps it as it is, acados_solver_sim_car.c:705-731; reset_mpc_optimizer is a stub,

@@ -579,7 +579,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
 typedef struct { StageQP qp; IpmState st; IpmWork wk; RicFactor F; real dx[MAXN + 1][NX]; } Workspace;
 
 static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const double* yref, const double* yref_e,
-                    double p, double* xbar, double* ubar, int* iters)
+                    double p, double* xbar, double* ubar, int* iters, double* step_norm, double* defect_norm)
 {
     const int N = c->N;
     StageQP* qp = &W->qp;
@@ -616,6 +616,15 @@ static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const 
             for (int l = 0; l < NU; ++l) a += qp->B[k][i][l] * W->st.du[k][l];
             W->dx[k + 1][i] = a;
         }
+    if (step_norm && defect_norm) {           /* SQP mode with a tolerance (cfg.sqp_tol): size of the full step and of the defects it starts from */
+        real sn = 0, dn = 0;
+        for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real a = R_FABS(W->dx[k][i]); if (a > sn || !(a == a)) sn = a; }
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < NU; ++j) { real a = R_FABS(W->st.du[k][j]); if (a > sn || !(a == a)) sn = a; }
+            for (int i = 0; i < NX; ++i) { real a = R_FABS(qp->b[k][i]); if (a > dn || !(a == a)) dn = a; }
+        }
+        *step_norm = (double)sn; *defect_norm = (double)dn;
+    }
     int bad = 0;      /* a non-finite step is a QP failure: the iterate is left untouched (acados returns before the update) */
     for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real v = (real)xbar[k * NX + i] + W->dx[k][i]; if (!(R_FABS(v) <= 1e300)) bad = 1; }
     for (int k = 0; k < N; ++k) for (int j = 0; j < NU; ++j) { real v = (real)ubar[k * NU + j] + W->st.du[k][j]; if (!(R_FABS(v) <= 1e300)) bad = 1; }
@@ -734,10 +743,17 @@ int oracle_solve_batch(const AdmpcConfig* c, int B, const double* x0, const doub
                 const double* yr = yref + (size_t)b * N * NY;
                 const double* ye = yref_e + (size_t)b * NX;
                 int st = 0, it = 0;
-                for (int s = 0; s < nsqp && st == 0; ++s) st = rti_step(c, W, x0 + (size_t)b * NX, yr, ye, p[b], xb, ub, &it);
+                const int tol_on = nsqp > 1 && c->sqp_tol > 0;      /* reference solver_type "SQP": stop on tolerance, status 2 at the limit */
+                int conv = 0;
+                for (int s = 0; s < nsqp && st == 0 && !conv; ++s) {
+                    double sn = 0, dn = 0;
+                    st = rti_step(c, W, x0 + (size_t)b * NX, yr, ye, p[b], xb, ub, &it, &sn, &dn);
+                    if (st == 0 && tol_on && sn <= c->sqp_tol && dn <= c->sqp_tol) conv = 1;
+                }
+                if (st == 0 && tol_on && !conv) st = ADMPC_STATUS_MAXITER;
                 if (status) status[b] = st;
                 if (iters) iters[b] = it;
-                if (cost) cost[b] = st == 0 ? eval_cost(c, yr, ye, xb, ub) : INFINITY;
+                if (cost) cost[b] = (st == 0 || st == ADMPC_STATUS_MAXITER) ? eval_cost(c, yr, ye, xb, ub) : INFINITY;
             }
             free(W);
         }
@@ -759,7 +775,7 @@ int oracle_qp_debug(const AdmpcConfig* c, const double* x0, const double* yref, 
     memcpy(xb, xbar_in, sizeof(double) * (N + 1) * NX);
     memcpy(ub, ubar_in, sizeof(double) * N * NU);
     int it = 0;
-    int st = rti_step(c, W, x0, yref, yref_e, p, xb, ub, &it);
+    int st = rti_step(c, W, x0, yref, yref_e, p, xb, ub, &it, NULL, NULL);
     if (iters) *iters = it;
     for (int k = 0; k < N; ++k) {
         for (int j = 0; j < NU; ++j) {

@@ -125,7 +125,8 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
         S.solve(X::mtrue(), res, pi != nullptr, X::mtrue());
         typename X::M failed = res.failed;
         typename X::V J;
-        S.finish(X::mtrue(), failed, J);
+        typename X::M conv;
+        S.finish(X::mtrue(), failed, J, conv);
         status[b] = failed.v[0] ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
         iters[b] = res.iters.v[0];
         cost[b] = failed.v[0] ? (T)INFINITY : J.v[0];

@@ -73,7 +73,7 @@ def test_actuation_kernel_exact_and_argmin_over_valid_candidates(gpu_engine_fact
     u[20, 0, 1] = 7.5; u[21, 0, 1] = -9.0                                 # rate clips
     rng = np.random.default_rng(2)
     steer = rng.uniform(-0.5, 0.5, 96)
-    cnt = rng.integers(0, 20, 96).astype(np.int32); cnt[:4] = 9; cnt[3] = 30
+    cnt = rng.integers(0, 20, 96).astype(np.int32); cnt[:4] = 9; cnt[3] = 30; cnt[[20, 21]] = 15
     ref = s["xref"][:, :, :2].copy()
     tcnt = torch.as_tensor(cnt, device=eng.device)
     tcost = eng.to_device(cost)

@@ -476,6 +476,62 @@ def test_two_level_argmin_through_a_process_group(gpu_engine_factory):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("N", [20, 40])
+def test_sqp_mode_stops_on_tolerance(gpu_engine_factory, oracle, N):
+    """cfg.sqp_tol on the device (condensed pipeline at N = 20, kernel R at N = 40): per-instance stop inside one
+    admpc_solve_batch call, same statuses as the oracle (0 converged, 2 at the step limit, 4 failed), same iterates."""
+    s = random_scenarios(48, N=N, seed=11, blend=(3.0, 5.0))
+    bad = random_scenarios(4, N=N, seed=3, blend=(3.0, 5.0), init="zeros")          # non-finite model: status 4 in the first step
+    s = {k: np.concatenate([s[k][:20], bad[k], s[k][20:]]) for k in s}
+    good_idx = np.r_[0:20, 24:52]
+    for iters in (30, 2):
+        cfg = default_config(N=N, sqp_iters=iters, sqp_tol=1e-6)
+        g, o = _solve_both(gpu_engine_factory(cfg), oracle, cfg, s)
+        np.testing.assert_array_equal(g[3], o[3])
+        assert set(np.unique(g[3][good_idx])) <= ({0, 4} if iters == 30 else {2, 4}) and (g[3][good_idx] != 4).sum() >= 40
+        okm = g[3] != 4
+        good = np.ones(len(okm), dtype=bool); good[20:24] = False      # the four non-finite-model instances carry garbage until they fail
+        good &= okm & (np.abs(o[0]).max(axis=(1, 2)) < 1e3) & (np.abs(o[1]).max(axis=(1, 2)) < 1e3)   # full Newton steps without a line search
+        assert good.sum() >= 40                                        # may diverge: finite garbage on both sides, not comparable
+        assert np.abs(g[1][good] - o[1][good]).max() <= 1e-7 and np.abs(g[0][good] - o[0][good]).max() <= 1e-7
+        assert np.isfinite(g[2][good]).all() and np.isinf(g[2][~okm]).all()
+        first = ~okm & (o[0] == s["xbar"]).all(axis=(1, 2))          # failed in the very first step (in the oracle): iterate untouched
+        np.testing.assert_array_equal(g[0][first], s["xbar"][first])
+        if N == 20:
+            assert first.sum() == (~okm).sum() == 4
+
+
+def test_argmin_global_through_the_c_abi_with_an_rccl_communicator(gpu_engine_factory):
+    """admpc_argmin_global: what a C++ host binds for the cross-GPU winner -- an ncclComm_t goes in, the library
+    does local arg-min, ncclAllGather (16 B per rank) and the second-level arg-min on the caller's stream.  One-rank communicator
+    built here through RCCL's own C API."""
+    import torch
+    eng = gpu_engine_factory(default_config())
+    rccl = C.CDLL("librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p(0)
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        rng = np.random.default_rng(3)
+        cost = rng.uniform(1.0, 2.0, size=8192); cost[[17, 4000]] = 0.5; cost[100] = np.nan
+        tc = eng.to_device(cost)
+        val = torch.empty(1, dtype=torch.float64, device=eng.device); idx = torch.empty(1, dtype=torch.int64, device=eng.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = eng.lib.admpc_argmin_global(eng._h, C.c_void_p(tc.data_ptr()), 8192, 5 * 8192, comm, C.c_void_p(val.data_ptr()), C.c_void_p(idx.data_ptr()), st)
+        assert rc == 0, eng.lib.admpc_last_error()
+        torch.cuda.synchronize()
+        assert val.item() == 0.5 and idx.item() == 5 * 8192 + 17
+        assert eng.lib.admpc_argmin_global(eng._h, C.c_void_p(tc.data_ptr()), 8192, 0, C.c_void_p(0), C.c_void_p(val.data_ptr()), C.c_void_p(idx.data_ptr()), st) == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 @pytest.mark.parametrize("with_gp", [False, True])
 def test_iterate_shift_matches_oracle(gpu_engine_factory, oracle, with_gp):
     """admpc_shift_batch (SURVEY 8f-3 option): the moved stages are copies (bit-exact), the rolled-out terminal state

@@ -136,3 +136,23 @@ def test_zero_iterate_with_dynamic_branch_reports_qp_failure(oracle):
     bad = s["p"] > 0
     assert (st[bad] == 4).all() and np.isinf(cost[bad]).all()
     assert np.array_equal(x[bad], s["xbar"][bad]) and np.array_equal(u[bad], s["ubar"][bad])
+
+
+def test_sqp_mode_stops_on_tolerance_and_reports_maxiter(oracle, golden_kat):
+    """cfg.sqp_tol (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): a cold-started SQP with a step / defect tolerance stops
+    at the reference's acados iterate with status 0; with too few steps allowed it returns status 2 (acados MAXITER), a finite cost
+    and its last iterate; sqp_tol = 0 keeps the fixed step count."""
+    k = golden_kat
+    N = k["N"]
+    X, U = np.array(k["X"]), np.array(k["U"])
+    x0, yref, ye = np.array(k["x0"])[None], np.array(k["yref"])[None], np.array(k["yref_e"])[None]
+    z = (np.zeros((1, N + 1, 7)), np.zeros((1, N, 2)))
+    cfg = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"], sqp_iters=100, sqp_tol=1e-6)
+    x, u, cost, st, it = oracle.solve_batch(cfg, x0, yref, ye, np.array([0.0]), *z)
+    assert st[0] == 0 and np.abs(u[0] - U).max() < 1e-6 and np.abs(x[0] - X).max() < 1e-6 and abs(cost[0] - 11.5810534473) < 1e-6
+    cfg3 = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"], sqp_iters=3, sqp_tol=1e-6)
+    x3, u3, cost3, st3, _ = oracle.solve_batch(cfg3, x0, yref, ye, np.array([0.0]), *z)
+    assert st3[0] == 2 and np.isfinite(cost3[0]) and np.abs(u3[0] - U).max() > 1e-6
+    cfg0 = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"], sqp_iters=3)
+    x0_, u0_, _, st0, _ = oracle.solve_batch(cfg0, x0, yref, ye, np.array([0.0]), *z)
+    assert st0[0] == 0 and np.array_equal(u0_, u3)
