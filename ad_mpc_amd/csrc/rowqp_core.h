@@ -50,7 +50,7 @@
 #endif
 
 #ifndef RQ_PF
-#define RQ_PF 2        // stages in flight in the light sweeps (measured on MI355X: 1, 2, 3, 4 run at the same speed)
+#define RQ_PF 3        // stages in flight in the light sweeps (fp64: 4 would spill to scratch; 2 -> 3 gains 1 % at N = 40)
 #endif
 #define RQ_HDR 16
 #define RQ_RS 30
@@ -315,37 +315,41 @@ struct RowQp {
         B.vb = wld(o_ub, (k + 1) * RQ_RW); B.k0 = wld(o_x + RW_K0, (k + 1) * RQ_RW); B.k1 = wld(o_x + RW_K1, (k + 1) * RQ_RW);
         B.i00 = wld(X::isplat(RW_LI), (k + 1) * RQ_RW); B.i01 = wld(X::isplat(RW_LI + 1), (k + 1) * RQ_RW); B.i11 = wld(X::isplat(RW_LI + 2), (k + 1) * RQ_RW);
     }
-    RQ_FN void sweep_backward(V smu) {
+    RQ_FN void bwd_stage(int k, BwdIn& c, V smu, V& p) {
         const V zero = splat((T)0);
+        fix_gc(c.Gc);
+        const V K0 = X::sel(is_x, c.k0, zero), K1 = X::sel(is_x, c.k1, zero);
+        const V g = X::sel(is_x, fma(wq, c.xk - c.rk, X::sel(is6, c.va - smu * c.vb, zero)), c.vu - smu * c.vb);
+        V G7[7];
+        RQ_UNROLL
+        for (int l = 0; l < 6; ++l) G7[l] = c.Gc[l];
+        G7[6] = g6c;
+        V hv = g;
+        X::template dotbc<7, 0>(G7, p, hv);
+        const V hu0 = X::template bc<7>(hv), hu1 = X::template bc<8>(hv);
+        const V pn = fma(K1, hu1, fma(K0, hu0, hv));
+        const V kff = X::sel(is7, -(c.i00 * hu0 + c.i01 * hu1), -(c.i01 * hu0 + c.i11 * hu1));
+        st(l_u, rec(k), kff, is_u);
+        p = X::sel(is_x, pn, zero);
+    }
+    RQ_FN void sweep_backward(V smu) {
         V p = terminal_gx();
         BwdIn buf[RQ_PF];
         RQ_UNROLL
         for (int j = 0; j < RQ_PF; ++j) bwd_load(N - 1 - j > 0 ? N - 1 - j : 0, buf[j]);
+        int k0 = N - 1;
         RQ_NOUNROLL
-        for (int k0 = N - 1; k0 >= 0; k0 -= RQ_PF) {
-            RQ_UNROLL
+        for (; k0 - (RQ_PF - 1) >= 0; k0 -= RQ_PF) {                // full groups: straight-line code, the ring slots are consumed in
+            RQ_UNROLL                                               // place and reloaded (no register rotation, exact wait counts)
             for (int j = 0; j < RQ_PF; ++j) {
                 const int k = k0 - j;
-                if (k >= 0) {
-                    BwdIn& c = buf[j];                              // consumed in place, reloaded below: no register rotation
-                    fix_gc(c.Gc);
-                    const V K0 = X::sel(is_x, c.k0, zero), K1 = X::sel(is_x, c.k1, zero);
-                    const V g = X::sel(is_x, fma(wq, c.xk - c.rk, X::sel(is6, c.va - smu * c.vb, zero)), c.vu - smu * c.vb);
-                    V G7[7];
-                    RQ_UNROLL
-                    for (int l = 0; l < 6; ++l) G7[l] = c.Gc[l];
-                    G7[6] = g6c;
-                    V hv = g;
-                    X::template dotbc<7, 0>(G7, p, hv);
-                    const V hu0 = X::template bc<7>(hv), hu1 = X::template bc<8>(hv);
-                    const V pn = fma(K1, hu1, fma(K0, hu0, hv));
-                    const V kff = X::sel(is7, -(c.i00 * hu0 + c.i01 * hu1), -(c.i01 * hu0 + c.i11 * hu1));
-                    st(l_u, rec(k), kff, is_u);
-                    p = X::sel(is_x, pn, zero);
-                    bwd_load(k - RQ_PF > 0 ? k - RQ_PF : 0, buf[j]);
-                }
+                bwd_stage(k, buf[j], smu, p);
+                bwd_load(k - RQ_PF > 0 ? k - RQ_PF : 0, buf[j]);
             }
         }
+        RQ_UNROLL
+        for (int j = 0; j < RQ_PF - 1; ++j)                         // the last N mod RQ_PF stages (their data is in the first slots)
+            if (k0 - j >= 0) bwd_stage(k0 - j, buf[j], smu, p);
     }
 
     // SA: exact adjoint of the current point: returns the max-norm of the reduced gradient and, with want_pi, writes the adjoint
@@ -394,31 +398,34 @@ struct RowQp {
         for (int c = 0; c < 7; ++c) F.Kr[c] = wld(o_kr, (k + 1) * RQ_RW + c);
         F.kff = ld(l_u, rec(k));
     }
+    RQ_FN void fwd_stage(int k, FwdIn& c, bool full, V& z) {
+        V ddu = c.kff;
+        X::template dotbc<7, 0>(c.Kr, z, ddu);
+        const V zz = X::sel(is_x, z, ddu);
+        const V zn = apply_g(c.Gr, zz);
+        st(l_u, rec(k), ddu, is_u);
+        if (full) wst(o_x + RW_D, (k + 1) * RQ_RW, zn, is_x);
+        st(X::isplat(full ? RQ_X : RQ_Q1), rec(k + 1 < N ? k + 1 : k), zn, is6 & X::mfrom(k + 1 < N));
+        z = X::sel(is_x, zn, splat((T)0));
+    }
     RQ_FN void sweep_forward(bool full) {
-        const V zero = splat((T)0);
-        V z = zero;
+        V z = splat((T)0);
         FwdIn buf[RQ_PF];
         RQ_UNROLL
         for (int j = 0; j < RQ_PF; ++j) fwd_load(j < N ? j : N - 1, buf[j]);
+        int k0 = 0;
         RQ_NOUNROLL
-        for (int k0 = 0; k0 < N; k0 += RQ_PF) {
+        for (; k0 + RQ_PF <= N; k0 += RQ_PF) {                      // full groups: straight-line code (see sweep_backward)
             RQ_UNROLL
             for (int j = 0; j < RQ_PF; ++j) {
                 const int k = k0 + j;
-                if (k < N) {
-                    FwdIn& c = buf[j];                              // consumed in place, reloaded below: no register rotation
-                    V ddu = c.kff;
-                    X::template dotbc<7, 0>(c.Kr, z, ddu);
-                    const V zz = X::sel(is_x, z, ddu);
-                    const V zn = apply_g(c.Gr, zz);
-                    st(l_u, rec(k), ddu, is_u);
-                    if (full) wst(o_x + RW_D, (k + 1) * RQ_RW, zn, is_x);
-                    if (k + 1 < N) st(X::isplat(full ? RQ_X : RQ_Q1), rec(k + 1), zn, is6);
-                    z = X::sel(is_x, zn, zero);
-                    fwd_load(k + RQ_PF < N ? k + RQ_PF : N - 1, buf[j]);
-                }
+                fwd_stage(k, buf[j], full, z);
+                fwd_load(k + RQ_PF < N ? k + RQ_PF : N - 1, buf[j]);
             }
         }
+        RQ_UNROLL
+        for (int j = 0; j < RQ_PF - 1; ++j)
+            if (k0 + j < N) fwd_stage(k0 + j, buf[j], full, z);
     }
 
     // =================================================================================================================

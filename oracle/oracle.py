@@ -16,9 +16,15 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
 
-def build(omp=False, quiet=True):
+def _target(omp=False, variant=None):
+    if variant:                                 # "asan" (sanitizers) or "ld" (80-bit arithmetic): tests/test_oracle_hygiene.py
+        return "liboracle_%s.so" % variant
+    return "liboracle_omp.so" if omp else "liboracle.so"
+
+
+def build(omp=False, quiet=True, variant=None):
     """(Re)build the oracle library with gcc; returns the .so path."""
-    target = "liboracle_omp.so" if omp else "liboracle.so"
+    target = _target(omp, variant)
     subprocess.run(["make", "-C", _HERE, target], check=True,
                    stdout=subprocess.DEVNULL if quiet else None)
     return os.path.join(_HERE, target)
@@ -29,10 +35,10 @@ def _ptr(a, ty=_dp):
 
 
 class Oracle:
-    def __init__(self, omp=False):
-        path = os.path.join(_HERE, "liboracle_omp.so" if omp else "liboracle.so")
+    def __init__(self, omp=False, variant=None):
+        path = os.path.join(_HERE, _target(omp, variant))
         try:
-            build(omp=omp)                      # no-op when up to date; a stale library must not outlive a change of the C file
+            build(omp=omp, variant=variant)                      # no-op when up to date; a stale library must not outlive a change of the C file
         except Exception:
             if not os.path.exists(path):
                 raise
