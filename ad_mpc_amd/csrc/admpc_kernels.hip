@@ -1777,7 +1777,7 @@ int admpc_reserve(AdmpcSolver* s, int B)
     } else {
         HIPCHK(hipMalloc((void**)&s->d_sched, (size_t)SCHED_HDR * sizeof(int)));       // [0]: ticket counter of the row kernel
     }
-    HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 36 * sizeof(double)));       // row kernel (every fp32 solve, fp64 for N != 20)
+    HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 38 * sizeof(double)));       // row kernel's workspace, RQ_RW = 38 values per record (every fp32 solve, fp64 for N != 20)
     s->cap = B;
     return ADMPC_OK;
 }

@@ -34,8 +34,10 @@
 //     Q1             Qt -> predictor ddx6              X     steering-barrier term of gx6 -> (corrector) xA -> ddx6
 //   workspace in global memory (L2-resident, streamed one stage ahead by the sweeps), RQ_RW values per record r = 0..N:
 //     XA[7] state of stage r (absolute)   D[7] Newton step of the state of stage r
-//     K0[7] K1[7] LI[3]  feedback gains / inverse of Huu of stage r-1
-//     UB[2] XB           sigma-mu coefficients of the corrector right-hand side of stage r-1
+//     KK[9][2]  of stage r-1, one pair per lane: (K0[c], K1[c]) for c < 7 (feedback gains, column c), then (i00, i01), (i01, i11)
+//               (inverse of Huu as lanes 7, 8 use it) -- ONE paired load / store per stage and sweep: a vector-memory
+//               instruction costs the CU 16 cycles whatever its lanes do, and the four waves of a CU share that pipe
+//     UB[2] XB  sigma-mu coefficients of the corrector right-hand side of stage r-1
 #pragma once
 
 #ifndef RQ_FN
@@ -55,8 +57,8 @@
 #define RQ_HDR 16
 #define RQ_RS 30
 enum { RQ_T = 0, RQ_LAM = 10, RQ_UA = 20, RQ_X6 = 22, RQ_X = 23, RQ_U = 24, RQ_A = 26, RQ_Q1 = 28 };
-#define RQ_RW 36
-enum { RW_XA = 0, RW_D = 8, RW_K0 = 16, RW_K1 = 23, RW_LI = 30, RW_UB = 33, RW_XB = 35 };
+#define RQ_RW 38
+enum { RW_XA = 0, RW_D = 8, RW_KK = 16, RW_UB = 34, RW_XB = 36 };
 #define RQ_GTS 42      // packed linearisation per stage: stored columns c' = 0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each
 
 template <class T>
@@ -107,7 +109,7 @@ struct RowQp {
     V lt2f;                    // 1 on lanes 0, 1
     V wq, wqe;                 // state weights of the lane (0 on lanes >= 7)
     V rjm;                     // Rd[j] on lanes 7, 8
-    I o_gc, o_gr, o_x, o_y, o_u, o_kr, o_ub;
+    I o_gc, o_gr, o_x, o_y, o_u, o_kk, o_ub;
     I l_u, l_a, l_ua, l_l0;
     // passes
     I sp, side, jin, o_tb, o_ts, o_vl, o_sa, o_sc, o_o1, o_o2, o_dxu;
@@ -141,7 +143,7 @@ struct RowQp {
         o_x = X::isel(is_x, lane, zi);
         o_y = X::isel(lane < 9, lane, zi);
         o_u = ju;
-        o_kr = ju * 7 + RW_K0;                                                      // forward sweeps, lanes 7, 8: row j of K
+        o_kk = X::isel(lane < 9, lane * 2, zi) + RW_KK;                              // the lane's pair of the gain record
         o_ub = X::isel(is_u, ju + RW_UB, X::isplat(RW_XB));                          // S3: lanes 7, 8 UB[j], lane 6 XB
         l_u = ju + RQ_U;                                                            // LDS: U[j] (lanes 7, 8)
         l_a = X::isel(is_u, ju + RQ_A, X::isplat(RQ_X));                            // LDS: A[j] (lanes 7, 8), X (lane 6)
@@ -183,6 +185,8 @@ struct RowQp {
     // reads it past the CU's L1, whose lines do not follow the wave's own stores)
     RQ_FN V wld(I off, int imm) { return X::wld(io.ws, iws + off + imm); }
     RQ_FN void wst(I off, int imm, V v, M m) { X::wst(io.ws, iws + off + imm, v, m & owns); }
+    RQ_FN void wld2(I off, int imm, V& a, V& b) { X::wld2(io.ws, iws + off + imm, a, b); }      // two consecutive values (even offset)
+    RQ_FN void wst2(I off, int imm, V a, V b, M m) { X::wst2(io.ws, iws + off + imm, a, b, m & owns); }
 
     // column layout of stage k: Gc[l] = G[l][c] for the lane's column c (rows 0..5)
     RQ_FN void load_gc(int k, V Gc[6]) { X::gld6(io.GT, igt + o_gc + k * RQ_GTS, Gc); }
@@ -290,11 +294,7 @@ struct RowQp {
             const V hu0 = X::template bc<7>(hv), hu1 = X::template bc<8>(hv);
             const V pn = fma(K1, hu1, fma(K0, hu0, hv));
             const V kff = X::sel(is7, -(i00 * hu0 + i01 * hu1), -(i01 * hu0 + i11 * hu1));
-            wst(o_x + RW_K0, (k + 1) * RQ_RW, K0, is_x);
-            wst(o_x + RW_K1, (k + 1) * RQ_RW, K1, is_x);
-            wst(X::isplat(RW_LI), (k + 1) * RQ_RW, i00, is7);
-            wst(X::isplat(RW_LI + 1), (k + 1) * RQ_RW, i01, is7);
-            wst(X::isplat(RW_LI + 2), (k + 1) * RQ_RW, i11, lane == 8);
+            wst2(o_kk, (k + 1) * RQ_RW, X::sel(is_x, K0, X::sel(is7, i00, i01)), X::sel(is_x, K1, X::sel(is7, i01, i11)), lane < 9);
             st(l_u, rec(k), kff, is_u);
             RQ_UNROLL
             for (int i = 0; i < 7; ++i) P[i] = H[i];
@@ -307,18 +307,17 @@ struct RowQp {
 
     // S3: backward sweep of the gradient alone (corrector right-hand side: gu = U - smu * UB, gx6 term = X - smu * XB).
     //     A light loop (about 60 instructions per stage) behind L2-latency loads: RQ_PF stages are kept in flight.
-    struct BwdIn { V Gc[6], xk, rk, vu, va, vb, k0, k1, i00, i01, i11; };
+    struct BwdIn { V Gc[6], xk, rk, vu, va, vb, ka, kb; };
     RQ_FN void bwd_load(int k, BwdIn& B) {
         load_gc(k, B.Gc);
         B.xk = wld(o_x + RW_XA, k * RQ_RW); B.rk = X::gld(io.yref, iyr + o_y + k * 9);
         B.vu = ld(l_u, rec(k)); B.va = ld(l_a, rec(k));
-        B.vb = wld(o_ub, (k + 1) * RQ_RW); B.k0 = wld(o_x + RW_K0, (k + 1) * RQ_RW); B.k1 = wld(o_x + RW_K1, (k + 1) * RQ_RW);
-        B.i00 = wld(X::isplat(RW_LI), (k + 1) * RQ_RW); B.i01 = wld(X::isplat(RW_LI + 1), (k + 1) * RQ_RW); B.i11 = wld(X::isplat(RW_LI + 2), (k + 1) * RQ_RW);
+        B.vb = wld(o_ub, (k + 1) * RQ_RW); wld2(o_kk, (k + 1) * RQ_RW, B.ka, B.kb);
     }
     RQ_FN void bwd_stage(int k, BwdIn& c, V smu, V& p) {
         const V zero = splat((T)0);
         fix_gc(c.Gc);
-        const V K0 = X::sel(is_x, c.k0, zero), K1 = X::sel(is_x, c.k1, zero);
+        const V K0 = X::sel(is_x, c.ka, zero), K1 = X::sel(is_x, c.kb, zero);
         const V g = X::sel(is_x, fma(wq, c.xk - c.rk, X::sel(is6, c.va - smu * c.vb, zero)), c.vu - smu * c.vb);
         V G7[7];
         RQ_UNROLL
@@ -328,7 +327,7 @@ struct RowQp {
         X::template dotbc<7, 0>(G7, p, hv);
         const V hu0 = X::template bc<7>(hv), hu1 = X::template bc<8>(hv);
         const V pn = fma(K1, hu1, fma(K0, hu0, hv));
-        const V kff = X::sel(is7, -(c.i00 * hu0 + c.i01 * hu1), -(c.i01 * hu0 + c.i11 * hu1));
+        const V kff = -(c.ka * hu0 + c.kb * hu1);                 // lanes 7, 8: their rows of the inverse of Huu
         st(l_u, rec(k), kff, is_u);
         p = X::sel(is_x, pn, zero);
     }
@@ -391,16 +390,15 @@ struct RowQp {
     // S2 / S4: forward roll-out of the Newton step: ddu_k = K_k ddx_k + kff_k (into U), ddx_{k+1} = A ddx_k + B ddu_k.
     //     full = false (predictor): only ddx6_{k+1} is kept (Q1 of stage k+1);  full = true: ddx_{k+1} into D, ddx6 also into X.
     //     A light loop (about 50 instructions per stage) behind L2-latency loads: RQ_PF stages are kept in flight.
-    struct FwdIn { V Gr[7], Kr[7], kff; };
+    struct FwdIn { V Gr[7], ka, kb, kff; };
     RQ_FN void fwd_load(int k, FwdIn& F) {
         load_gr(k, F.Gr);
-        RQ_UNROLL
-        for (int c = 0; c < 7; ++c) F.Kr[c] = wld(o_kr, (k + 1) * RQ_RW + c);
+        wld2(o_kk, (k + 1) * RQ_RW, F.ka, F.kb);
         F.kff = ld(l_u, rec(k));
     }
     RQ_FN void fwd_stage(int k, FwdIn& c, bool full, V& z) {
-        V ddu = c.kff;
-        X::template dotbc<7, 0>(c.Kr, z, ddu);
+        V ddu = c.kff;                                             // ddu_j = kff_j + sum_c K_j[c] z_c: the products are formed where
+        X::sumbc2(c.ka * z, c.kb * z, E[7], E[8], ddu);            // column c lives (lane c) and gathered on lanes 7, 8
         const V zz = X::sel(is_x, z, ddu);
         const V zn = apply_g(c.Gr, zz);
         st(l_u, rec(k), ddu, is_u);

@@ -59,22 +59,27 @@ struct DevCommon {
         const int o = (m && L.ok) ? off + imm : (int)(threadIdx.x & 14u);
         L.base[o] = a; L.base[o + 1] = b;
     }
-    // orders what one sweep / pass wrote (LDS records, workspace in global memory) before what the next one reads: one wave per
-    // workgroup, so a compiler-level fence plus the wave's own memory counters
+    // orders what one sweep / pass wrote (LDS records, workspace in global memory) before what the next one reads.  One wave per
+    // workgroup: the wave's own memory counters order the accesses; the workspace lines the CU's vector L1 still holds from an
+    // earlier sweep are dropped (acquire at agent scope = buffer_inv sc1) -- the L1 does not follow the wave's own stores
+    // (measured: stale states after the roll-out, run-to-run different results).  No sweep reads what it wrote itself.
     RQ_FN static void fence() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     // global arrays: uniform base + 32-bit byte offset of the lane (global_load ... v_off, s[base:base+1]); the host splits
     // batches whose arrays would exceed 4 GB
     RQ_FN static const T* gaddr(const T* p, I off) { return (const T*)((const char*)p + (unsigned)off * (unsigned)sizeof(T)); }
     RQ_FN static V gld(const T* p, I off) { return *gaddr(p, off); }
     RQ_FN static void gst(T* p, I off, V v, M m) { if (m) *(T*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; }
-    // workspace accesses.  A wave reads back what it stored itself, several sweeps later; the CU's vector L1 keeps the line it
-    // loaded before that store (measured: stale states after the roll-out, run-to-run different results), so these loads are
-    // agent-scope relaxed loads (global_load ... sc1: served by the L2, which the write-through stores have updated).
-    RQ_FN static V wld(const T* p, I off) { return __hip_atomic_load(gaddr(p, off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // workspace accesses: written by one sweep, read by a later one of the same wave (fence() in between)
+    RQ_FN static V wld(const T* p, I off) { return *gaddr(p, off); }
     RQ_FN static void wst(T* p, I off, V v, M m) { if (m) *(T*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; }
+    // pairs (even offsets): one 16-byte (fp64) / 8-byte (fp32) access
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    RQ_FN static void wld2(const T* p, I off, V& a, V& b) { const T2 v = *(const T2*)gaddr(p, off); a = v.x; b = v.y; }
+    RQ_FN static void wst2(T* p, I off, V a, V b, M m) { if (m) { T2 v; v.x = a; v.y = b; *(T2*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; } }
     // row-uniform logic through the wave ballot
     RQ_FN static unsigned rowbits(M m) {
         const unsigned long long b = __ballot(m);
@@ -145,6 +150,12 @@ struct DevX<double> : DevCommon<double, DevX<double>> {
         else
             asm volatile("s_nop 1\n\t" RQ_F64(a, s, c0, 2) RQ_F64(a, s, c1, 3) RQ_F64(a, s, c2, 4) RQ_F64(a, s, c3, 5) RQ_F64(a, s, c4, 6) RQ_F64(a, s, c5, 7) RQ_F64(a, s, c6, 8)
                          : [a] "+v"(acc) : [s] "v"(src), [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]));
+    }
+    // acc += sum_{c<7} lane_c(w0) * e0 + lane_c(w1) * e1
+    RQ_FN static void sumbc2(V w0, V w1, V e0, V e1, V& acc) {
+        asm volatile("s_nop 1\n\t" RQ_F64(a, u, p, 0) RQ_F64(a, v, q, 0) RQ_F64(a, u, p, 1) RQ_F64(a, v, q, 1) RQ_F64(a, u, p, 2) RQ_F64(a, v, q, 2) RQ_F64(a, u, p, 3) RQ_F64(a, v, q, 3)
+                     RQ_F64(a, u, p, 4) RQ_F64(a, v, q, 4) RQ_F64(a, u, p, 5) RQ_F64(a, v, q, 5) RQ_F64(a, u, p, 6) RQ_F64(a, v, q, 6)
+                     : [a] "+v"(acc) : [u] "v"(w0), [v] "v"(w1), [p] "v"(e0), [q] "v"(e1));
     }
 #define RQ_PG_ROW64(i) "v_mov_b64 %[m" #i "], 0\n\t" RQ_F64(m##i, p##i, g0, 0) RQ_F64(m##i, p##i, g1, 1) RQ_F64(m##i, p##i, g2, 2) RQ_F64(m##i, p##i, g3, 3) \
                        RQ_F64(m##i, p##i, g4, 4) RQ_F64(m##i, p##i, g5, 5) RQ_F64(m##i, p##i, g6, 6)
@@ -219,6 +230,11 @@ struct DevX<float> : DevCommon<float, DevX<float>> {
         else
             asm volatile("s_nop 1\n\t" RQ_F32(a, s, c0, 2) RQ_F32(a, s, c1, 3) RQ_F32(a, s, c2, 4) RQ_F32(a, s, c3, 5) RQ_F32(a, s, c4, 6) RQ_F32(a, s, c5, 7) RQ_F32(a, s, c6, 8)
                          : [a] "+v"(acc) : [s] "v"(src), [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]));
+    }
+    RQ_FN static void sumbc2(V w0, V w1, V e0, V e1, V& acc) {
+        asm volatile("s_nop 1\n\t" RQ_F32(a, u, p, 0) RQ_F32(a, v, q, 0) RQ_F32(a, u, p, 1) RQ_F32(a, v, q, 1) RQ_F32(a, u, p, 2) RQ_F32(a, v, q, 2) RQ_F32(a, u, p, 3) RQ_F32(a, v, q, 3)
+                     RQ_F32(a, u, p, 4) RQ_F32(a, v, q, 4) RQ_F32(a, u, p, 5) RQ_F32(a, v, q, 5) RQ_F32(a, u, p, 6) RQ_F32(a, v, q, 6)
+                     : [a] "+v"(acc) : [u] "v"(w0), [v] "v"(w1), [p] "v"(e0), [q] "v"(e1));
     }
 #define RQ_PG_ROW32(i) "v_mov_b32 %[m" #i "], 0\n\t" RQ_F32(m##i, p##i, g0, 0) RQ_F32(m##i, p##i, g1, 1) RQ_F32(m##i, p##i, g2, 2) RQ_F32(m##i, p##i, g3, 3) \
                        RQ_F32(m##i, p##i, g4, 4) RQ_F32(m##i, p##i, g5, 5) RQ_F32(m##i, p##i, g6, 6)

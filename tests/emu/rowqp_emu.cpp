@@ -72,11 +72,16 @@ struct EmuX {
     static void gst(T* p, const I& off, const V& v, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) p[off.v[l]] = v.v[l]; }
     static V wld(const T* p, const I& off) { return gld(p, off); }
     static void wst(T* p, const I& off, const V& v, const M& m) { gst(p, off, v, m); }
+    static void wld2(const T* p, const I& off, V& a, V& b) { for (int l = 0; l < NL; ++l) { if (off.v[l] & 1) __builtin_trap(); a.v[l] = p[off.v[l]]; b.v[l] = p[off.v[l] + 1]; } }
+    static void wst2(T* p, const I& off, const V& a, const V& b, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) { if (off.v[l] & 1) __builtin_trap(); p[off.v[l]] = a.v[l]; p[off.v[l] + 1] = b.v[l]; } }
     // cross-lane
     template <int L> static V bc(const V& a) { return splat(a.v[L]); }
     static V swap1(const V& a) { V r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l ^ 1]; return r; }
     template <int n, int L0> static void dotbc(const V* coef, const V& src, V& acc) {
         for (int i = 0; i < n; ++i) for (int l = 0; l < NL; ++l) acc.v[l] = std::fma(src.v[L0 + i], coef[i].v[l], acc.v[l]);
+    }
+    static void sumbc2(const V& w0, const V& w1, const V& e0, const V& e1, V& acc) {
+        for (int c = 0; c < 7; ++c) for (int l = 0; l < NL; ++l) { acc.v[l] = std::fma(w0.v[c], e0.v[l], acc.v[l]); acc.v[l] = std::fma(w1.v[c], e1.v[l], acc.v[l]); }
     }
     static void pg(const V P[7], const V G7[7], V Mm[7]) {           // M[i] = sum_l P[i]{lane l} * G[l]
         for (int i = 0; i < 7; ++i) { Mm[i] = splat((T)0); for (int l = 0; l < 7; ++l) for (int c = 0; c < NL; ++c) Mm[i].v[c] = std::fma(P[i].v[l], G7[l].v[c], Mm[i].v[c]); }
