@@ -184,9 +184,10 @@ struct RowQp {
     // workspace: written by one sweep / pass and read back by a later one of the same wave -> accessors of their own (the device
     // reads it past the CU's L1, whose lines do not follow the wave's own stores)
     RQ_FN V wld(I off, int imm) { return X::wld(io.ws, iws + off + imm); }
-    RQ_FN void wst(I off, int imm, V v, M m) { X::wst(io.ws, iws + off + imm, v, m & owns); }
+    // masked-off lanes store into the unused gain slots of record 0 (there is no stage -1): no EXEC branch around the store
+    RQ_FN void wst(I off, int imm, V v, M m) { X::wst(io.ws, iws + off + imm, iws + lane + RW_KK, v, m & owns); }
     RQ_FN void wld2(I off, int imm, V& a, V& b) { X::wld2(io.ws, iws + off + imm, a, b); }      // two consecutive values (even offset)
-    RQ_FN void wst2(I off, int imm, V a, V b, M m) { X::wst2(io.ws, iws + off + imm, a, b, m & owns); }
+    RQ_FN void wst2(I off, int imm, V a, V b, M m) { X::wst2(io.ws, iws + off + imm, iws + (lane & 7) * 2 + RW_KK, a, b, m & owns); }
 
     // column layout of stage k: Gc[l] = G[l][c] for the lane's column c (rows 0..5)
     RQ_FN void load_gc(int k, V Gc[6]) { X::gld6(io.GT, igt + o_gc + k * RQ_GTS, Gc); }
@@ -440,7 +441,13 @@ struct RowQp {
         I kc;                     // clamped stage index
     };
 
-    RQ_FN void side_load(int s, Side& S, bool with_state, bool with_steps) {
+    // reference of the side's input at step s (global memory): the pass loops fetch it two steps ahead of its use
+    RQ_FN V uref_load(int s) {
+        const int sc = 2 * s < N ? s : (N - 1) / 2;
+        const I k = sp + 2 * sc;
+        return X::gld(io.yref, iyr + X::isel(k < N, k, X::isplat(N - 1)) * 9 + 7 + jin);
+    }
+    RQ_FN void side_load(int s, Side& S, bool with_state, bool with_steps, V uref) {
         const I k = sp + 2 * s;
         const M in = k < N;
         S.kc = X::isel(in, k, X::isplat(N - 1));
@@ -448,7 +455,7 @@ struct RowQp {
         S.act = e_valid & in & ((!e_isd) | (k >= 1));
         S.stv = e_valid & in & e_even;
         S.inb = e_valid & in;
-        S.uref = X::gld(io.yref, iyr + S.kc * 9 + 7 + jin);
+        S.uref = uref;
         S.vabs = ld(S.kl + o_vl, 0);
         if (with_state) {
             S.tb = ld(S.kl + o_tb, RQ_T); S.lb = ld(S.kl + o_tb, RQ_LAM);
@@ -493,12 +500,14 @@ struct RowQp {
     RQ_FN void pass_e1(Red& R) {
         R.mu = splat((T)0); R.cmax = splat((T)0); R.rmax = splat((T)0);
         Side S, Sn;
-        side_load(0, S, true, false);
+        V u1 = uref_load(1);
+        side_load(0, S, true, false, uref_load(0));
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, false);
+            const V u2 = uref_load(s + 2);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, false, u1);
             e1_core(S, R);
-            S = Sn;
+            S = Sn; u1 = u2;
         }
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);
     }
@@ -517,10 +526,13 @@ struct RowQp {
         const V zero = splat((T)0), one = splat((T)1);
         rr = zero; s2 = zero;
         Side S, Sn;
-        side_load(0, S, true, true);
+        V u1 = uref_load(1);
+        side_load(0, S, true, true, uref_load(0));
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);
+            const V u2 = uref_load(s + 2);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, u1);
+            u1 = u2;
             Bar B; side_barrier(S, B);
             const V stp = X::sel(e_isd, S.sa, S.sc);               // ddx6_a (Q1) | ddu_a (U)
             const V uua = sgn * stp;
@@ -562,10 +574,10 @@ struct RowQp {
         const V zero = splat((T)0);
         V rr = zero;
         Side S, Sn;
-        side_load(0, S, true, true);
+        side_load(0, S, true, true, zero);                          // the ratio test does not use the input references
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, zero);
             Bar B; side_barrier(S, B);
             Step C; side_step_corr(S, B, smu, C);
             V r = X::vmax(-(C.dtb * B.itb), -(C.dlb * X::rcp(S.lb)));
@@ -576,19 +588,28 @@ struct RowQp {
         return X::row_max(rr);
     }
 
-    // xa += alpha ddx for every stage (lanes (sp, i < 7) <-> record 2s + sp + 1); the steering angle is mirrored into the LDS record
+    // xa += alpha ddx for every stage (lanes (sp, i < 7) <-> record 2s + sp + 1); the steering angle is mirrored into the LDS record.
+    // Four steps per group: their eight loads are in flight together (a step-by-step loop waits a full memory latency per step).
     RQ_FN void pass_dx_update(V alpha, M rowact) {
         const M go = rowact & (alpha > splat((T)0));
         RQ_NOUNROLL
-        for (int s = 0; 2 * s < N; ++s) {
-            const I k = sp + 2 * s;
-            const M in = (k < N) & dxl & go;
-            const I kc = X::isel(k < N, k, X::isplat(N - 1));
-            const I wo = (kc + 1) * RQ_RW + o_dxu;
-            const V xa = wld(wo, RW_XA), dd = wld(wo, RW_D);
-            const V xn = fma(alpha, dd, xa);
-            wst(wo, RW_XA, xn, in);
-            st((kc + 1) * RQ_RS + RQ_HDR, RQ_X6, xn, in & (side == 6) & (k < N - 1));
+        for (int s0 = 0; 2 * s0 < N; s0 += 4) {
+            V xa[4], dd[4]; I kc[4];
+            RQ_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const I k = sp + 2 * (s0 + j);
+                kc[j] = X::isel(k < N, k, X::isplat(N - 1));
+                const I wo = (kc[j] + 1) * RQ_RW + o_dxu;
+                xa[j] = wld(wo, RW_XA); dd[j] = wld(wo, RW_D);
+            }
+            RQ_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const I k = sp + 2 * (s0 + j);
+                const M in = (k < N) & dxl & go;
+                const V xn = fma(alpha, dd[j], xa[j]);
+                wst((kc[j] + 1) * RQ_RW + o_dxu, RW_XA, xn, in);
+                st((kc[j] + 1) * RQ_RS + RQ_HDR, RQ_X6, xn, in & (side == 6) & (k < N - 1));
+            }
         }
     }
 
@@ -599,10 +620,13 @@ struct RowQp {
         V stp = zero;
         R.mu = zero; R.cmax = zero; R.rmax = zero;
         Side S, Sn;
-        side_load(0, S, true, true);
+        V u1 = uref_load(1);
+        side_load(0, S, true, true, uref_load(0));
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);   // old state of the next step (its records are not written here)
+            const V u2 = uref_load(s + 2);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, u1);   // old state of the next step (its records are not written here)
+            u1 = u2;
             Bar B; side_barrier(S, B);
             Step C; side_step_corr(S, B, smu, C);
             const V fl = splat(q.floor_);
@@ -646,7 +670,7 @@ struct RowQp {
         M ok = X::mtrue();
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, false, true);
+            Side S; side_load(s, S, false, true, splat((T)0));
             const V qv = sgn * (S.vabs + S.sc - bound);
             ok = ok & ((!S.act) | (qv >= splat((T)0)));
         }
@@ -665,7 +689,7 @@ struct RowQp {
         V rs0 = zero;
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, false, true);
+            Side S; side_load(s, S, false, true, uref_load(s));
             const V vabs = S.vabs + X::sel(step, S.sc, zero);      // steering: X6 still holds the start point, X the trial's ddx6
             st(S.kl + jin + RQ_UA, 0, vabs, S.stv & e_in);
             const V qv = sgn * (vabs - bound);

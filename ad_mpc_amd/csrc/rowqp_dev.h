@@ -75,11 +75,13 @@ struct DevCommon {
     RQ_FN static void gst(T* p, I off, V v, M m) { if (m) *(T*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; }
     // workspace accesses: written by one sweep, read by a later one of the same wave (fence() in between)
     RQ_FN static V wld(const T* p, I off) { return *gaddr(p, off); }
-    RQ_FN static void wst(T* p, I off, V v, M m) { if (m) *(T*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; }
+    // masked stores are unconditional stores whose address is redirected to a dump slot (see lds_st): an EXEC branch around a store
+    // makes hipcc wait for every outstanding load at the join
+    RQ_FN static void wst(T* p, I off, I dump, V v, M m) { *(T*)((char*)p + (unsigned)(m ? off : dump) * (unsigned)sizeof(T)) = v; }
     // pairs (even offsets): one 16-byte (fp64) / 8-byte (fp32) access
     typedef T T2 __attribute__((ext_vector_type(2)));
     RQ_FN static void wld2(const T* p, I off, V& a, V& b) { const T2 v = *(const T2*)gaddr(p, off); a = v.x; b = v.y; }
-    RQ_FN static void wst2(T* p, I off, V a, V b, M m) { if (m) { T2 v; v.x = a; v.y = b; *(T2*)((char*)p + (unsigned)off * (unsigned)sizeof(T)) = v; } }
+    RQ_FN static void wst2(T* p, I off, I dump, V a, V b, M m) { T2 v; v.x = a; v.y = b; *(T2*)((char*)p + (unsigned)(m ? off : dump) * (unsigned)sizeof(T)) = v; }
     // row-uniform logic through the wave ballot
     RQ_FN static unsigned rowbits(M m) {
         const unsigned long long b = __ballot(m);

@@ -71,9 +71,11 @@ struct EmuX {
     static void gld6(const T* p, const I& off, V out[6]) { for (int i = 0; i < 6; ++i) for (int l = 0; l < NL; ++l) out[i].v[l] = p[off.v[l] + i]; }
     static void gst(T* p, const I& off, const V& v, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) p[off.v[l]] = v.v[l]; }
     static V wld(const T* p, const I& off) { return gld(p, off); }
-    static void wst(T* p, const I& off, const V& v, const M& m) { gst(p, off, v, m); }
+    static void wst(T* p, const I& off, const I& dump, const V& v, const M& m) { for (int l = 0; l < NL; ++l) p[m.v[l] ? off.v[l] : dump.v[l]] = v.v[l]; }
     static void wld2(const T* p, const I& off, V& a, V& b) { for (int l = 0; l < NL; ++l) { if (off.v[l] & 1) __builtin_trap(); a.v[l] = p[off.v[l]]; b.v[l] = p[off.v[l] + 1]; } }
-    static void wst2(T* p, const I& off, const V& a, const V& b, const M& m) { for (int l = 0; l < NL; ++l) if (m.v[l]) { if (off.v[l] & 1) __builtin_trap(); p[off.v[l]] = a.v[l]; p[off.v[l] + 1] = b.v[l]; } }
+    static void wst2(T* p, const I& off, const I& dump, const V& a, const V& b, const M& m) {
+        for (int l = 0; l < NL; ++l) { const int o = m.v[l] ? off.v[l] : dump.v[l]; if (o & 1) __builtin_trap(); p[o] = a.v[l]; p[o + 1] = b.v[l]; }
+    }
     // cross-lane
     template <int L> static V bc(const V& a) { return splat(a.v[L]); }
     static V swap1(const V& a) { V r; for (int l = 0; l < NL; ++l) r.v[l] = a.v[l ^ 1]; return r; }
