@@ -506,6 +506,7 @@ struct RowQp {
         for (int s = 0; 2 * s < N; ++s) {
             const V u2 = uref_load(s + 2);
             side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, false, u1);
+            X::sched_fence(S.tb, S.lb, S.ts, S.ls);                 // the loads of the next step stay ahead of this step's work
             e1_core(S, R);
             S = Sn; u1 = u2;
         }
@@ -532,7 +533,7 @@ struct RowQp {
         for (int s = 0; 2 * s < N; ++s) {
             const V u2 = uref_load(s + 2);
             side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, u1);
-            u1 = u2;
+            X::sched_fence(S.tb, S.lb, S.ts, S.ls);
             Bar B; side_barrier(S, B);
             const V stp = X::sel(e_isd, S.sa, S.sc);               // ddx6_a (Q1) | ddu_a (U)
             const V uua = sgn * stp;
@@ -551,7 +552,7 @@ struct RowQp {
             st(S.kl + jin + RQ_A, 0, stp, S.stv & e_in);                                              // predictor ddu
             st(S.kl + o_o1, 0, X::sel(e_isd, sa, fma(rjin, S.vabs - S.uref, sa)), S.stv);
             wst((S.kc + 1) * RQ_RW + X::isel(e_isd, X::isplat(RW_XB), jin + RW_UB), 0, sb, S.stv);
-            S = Sn;
+            S = Sn; u1 = u2;
         }
         rr = X::row_max(rr); s2 = X::row_sum(s2);
     }
@@ -578,6 +579,7 @@ struct RowQp {
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, zero);
+            X::sched_fence(S.tb, S.lb, S.ts, S.ls);
             Bar B; side_barrier(S, B);
             Step C; side_step_corr(S, B, smu, C);
             V r = X::vmax(-(C.dtb * B.itb), -(C.dlb * X::rcp(S.lb)));
@@ -626,7 +628,7 @@ struct RowQp {
         for (int s = 0; 2 * s < N; ++s) {
             const V u2 = uref_load(s + 2);
             side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, u1);   // old state of the next step (its records are not written here)
-            u1 = u2;
+            X::sched_fence(S.tb, S.lb, S.ts, S.ls);
             Bar B; side_barrier(S, B);
             Step C; side_step_corr(S, B, smu, C);
             const V fl = splat(q.floor_);
@@ -640,7 +642,7 @@ struct RowQp {
             st(S.kl + o_tb, RQ_T, S.tb, S.act); st(S.kl + o_tb, RQ_LAM, S.lb, S.act);
             st(S.kl + o_ts, RQ_T, S.ts, S.act & e_in); st(S.kl + o_ts, RQ_LAM, S.ls, S.act & e_in);
             e1_core(S, R);
-            S = Sn;
+            S = Sn; u1 = u2;
         }
         pass_dx_update(alpha, rowact);
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);

@@ -68,6 +68,9 @@ struct DevCommon {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // scheduling fence: memory operations are not moved across it, and what is computed from a, b, c, d starts after it (hipcc otherwise
+    // sinks the loads of the next step below the arithmetic of the current one and waits for them at once)
+    RQ_FN static void sched_fence(V& a, V& b, V& c, V& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); }
     // global arrays: uniform base + 32-bit byte offset of the lane (global_load ... v_off, s[base:base+1]); the host splits
     // batches whose arrays would exceed 4 GB
     RQ_FN static const T* gaddr(const T* p, I off) { return (const T*)((const char*)p + (unsigned)off * (unsigned)sizeof(T)); }

@@ -66,6 +66,7 @@ struct EmuX {
     static void lds_ld2(const Lds& L, const I& off, int imm, V& a, V& b) { a = lds_ld(L, off, imm); b = lds_ld(L, off, imm + 1); }
     static void lds_st2(const Lds& L, const I& off, int imm, const V& a, const V& b, const M& m) { lds_st(L, off, imm, a, m); lds_st(L, off, imm + 1, b, m); }
     static void fence() {}
+    static void sched_fence(V&, V&, V&, V&) {}
     static void stamp(int) {}
     static V gld(const T* p, const I& off) { V r; for (int l = 0; l < NL; ++l) r.v[l] = p[off.v[l]]; return r; }
     static void gld6(const T* p, const I& off, V out[6]) { for (int i = 0; i < 6; ++i) for (int l = 0; l < NL; ++l) out[i].v[l] = p[off.v[l] + i]; }
