@@ -198,3 +198,52 @@ class BatchSolver:
         ld = vel_ref.stride(0) if B > 1 else H
         _lib.check(self.lib.admpc_resample_vel_batch(self.device_index, B, H, int(ld), _ptr(vx), _ptr(vy), float(acc_max), float(dt),
                                                      C.c_void_p(vel_ref.data_ptr()), self._stream()))
+
+
+class EnsembleBatchSolver:
+    """Clustered GP ensembles (reference: one AcadosOcpSolver per cluster, quad_3d_optimizer.py:207, chosen per
+    solve by GPEnsemble.select_gp, :452 / :491).  One engine handle per cluster; a batch is routed by cluster: the instances of
+    cluster c are gathered, solved by handle c and scattered back (torch index ops are the plumbing, every number comes from
+    the HIP kernels).  ``ensemble``: gp_loader.GPEnsemble."""
+
+    def __init__(self, cfg, ensemble, device=0):
+        from .config import set_gp
+        self.ensemble = ensemble
+        self.solvers = []
+        for c in range(ensemble.n_models):
+            cc = cfg.copy()
+            set_gp(cc, ensemble.clusters[c])
+            self.solvers.append(BatchSolver(cc, device=device))
+        self.device = self.solvers[0].device
+        self.N = self.solvers[0].N
+        self._cent = torch.as_tensor(ensemble.centroids[:, 0].copy(), dtype=torch.float64, device=self.device)
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+
+    def select(self, x_sel, u_sel):
+        """Cluster of every instance from the state / input the caller selects on (the reference passes the reference state and
+        the input target): nearest centroid of the ensemble's feature, ties to the lowest index.  Device tensors in and out."""
+        f = self.ensemble.feat
+        z = (x_sel[:, f] if f < NX else u_sel[:, f - NX]).to(torch.float64)
+        return torch.argmin(torch.sqrt((z[None, :] - self._cent[:, None]) ** 2), dim=0)
+
+    def solve(self, gp_ind, x0, yref, yref_e, p, xbar, ubar, cost=None, status=None, iters=None):
+        """BatchSolver.solve with a cluster index per instance (int64 device tensor).  In place on xbar / ubar."""
+        B = x0.shape[0]
+        for c, sv in enumerate(self.solvers):
+            idx = torch.nonzero(gp_ind == c, as_tuple=False).reshape(-1)
+            n = int(idx.numel())
+            if n == 0:
+                continue
+            g = lambda t: t.index_select(0, idx).contiguous()
+            xb, ub = g(xbar), g(ubar)
+            co = torch.empty(n, dtype=x0.dtype, device=self.device)
+            st = torch.empty(n, dtype=torch.int32, device=self.device)
+            it = torch.empty(n, dtype=torch.int32, device=self.device)
+            sv.solve(g(x0), g(yref), g(yref_e), g(p), xb, ub, co, st, it)
+            xbar.index_copy_(0, idx, xb); ubar.index_copy_(0, idx, ub)
+            if cost is not None: cost.index_copy_(0, idx, co)
+            if status is not None: status.index_copy_(0, idx, st)
+            if iters is not None: iters.index_copy_(0, idx, it)

@@ -8,8 +8,13 @@ Directory scheme (``src/utils/utils.py:175-236``): ``<save_dir>/<git>/<model_nam
 
 The engine evaluates the GP mean  mu(z) = sum_i k(z, x_train_i) k_inv_y_i + y_mean  with  k = sigma_f exp(-|z - x|^2 / (2 l^2))
 (sigma_f is NOT squared in the reference, ``gp.py:81-138``) inside the dynamics (``ad_mpc_amd.config.set_gp``).  Device limits:
-1-D feature per regressor, at most 4 regressors and 32 training points each; anything else raises ``ValueError`` (the reference's
-ensembles / clusters, ``gp.py:738-770``, are not on the device path).
+1-D feature per regressor, at most 4 regressors and 32 training points each; anything else raises ``ValueError``.
+
+Clustered ensembles (``GPEnsemble``, ``gp.py:536-607``; selection ``select_gp``, ``gp.py:738-770``): the reference keeps one
+acados solver per cluster (``quad_3d_optimizer.py:207``) and picks one per solve from the reference state (``:452``, ``:491``).
+``GPEnsemble`` below is the host-side restatement (grouping by output dimension, clusters sorted by the first centroid
+coordinate, nearest-centroid selection); ``ad_mpc_amd.engine.EnsembleBatchSolver`` holds one engine handle per cluster and
+routes every instance of a batch to the handle of its cluster.
 """
 import os
 
@@ -84,6 +89,65 @@ def gp_entry_from_saved(d):
     return dict(feat=feat, out=out, Z=Z[:, 0], alpha=alpha, length_scale=ell, sigma_f=float(kp.get("sigma_f", 1.0)), ymean=ymean)
 
 
+class GPEnsemble:
+    """Homogeneous clustered ensemble: for every output dimension the same K centroids (what the reference's MPC path can use:
+    ``gp_ind`` is ONE key into its dictionary of solvers).  ``clusters[c]`` is the ``set_gp`` list of cluster c (one regressor
+    per output dimension), ``centroids`` is K x d (d = 1 for the device's one-feature regressors)."""
+
+    def __init__(self, clusters, centroids, feat):
+        self.clusters = clusters
+        self.centroids = np.asarray(centroids, dtype=np.float64).reshape(len(clusters), -1)
+        self.feat = int(feat)                                 # index into [x(7); u(2)] of the feature the centroids live in
+
+    @property
+    def n_models(self):
+        return len(self.clusters)
+
+    @classmethod
+    def from_pickled(cls, pre_trained_models):
+        """gp.py:575-607 (add_model per output dimension): group the saved regressors by ``reg_dim``, sort the clusters of a
+        dimension by the first coordinate of their centroid (the regressor's ``mean``), require the same centroids in every
+        dimension (``homogeneous_feature_space``, gp.py:772-788)."""
+        models = pre_trained_models["models"] if isinstance(pre_trained_models, dict) else list(pre_trained_models)
+        by_dim = {}
+        for m in models:
+            e = gp_entry_from_saved(m)
+            c = np.atleast_1d(np.asarray(m.get("mean", 0.0), dtype=np.float64)).reshape(-1)
+            by_dim.setdefault(e["out"], []).append((c, e))
+        if not by_dim:
+            raise ValueError("no regressors")
+        if len(by_dim) > GP_MAX:
+            raise ValueError("%d output dimensions; the device holds at most %d regressors" % (len(by_dim), GP_MAX))
+        dims = sorted(by_dim)
+        ref_c = None
+        feat = None
+        for d in dims:
+            grp = sorted(by_dim[d], key=lambda ce: ce[0][0])          # argsort of centroids[:, 0] (gp.py:594)
+            by_dim[d] = grp
+            cen = np.array([c for c, _ in grp])
+            if ref_c is None:
+                ref_c, feat = cen, grp[0][1]["feat"]
+            elif cen.shape != ref_c.shape or np.any(cen != ref_c):
+                raise ValueError("non-homogeneous ensemble (different centroids per output dimension): the reference's MPC path "
+                                 "cannot use it either (one solver key per solve, quad_3d_optimizer.py:452-462)")
+            if any(e["feat"] != grp[0][1]["feat"] for _, e in grp):
+                raise ValueError("the clusters of one output dimension must share their feature")
+        K = ref_c.shape[0]
+        clusters = [[by_dim[d][c][1] for d in dims] for c in range(K)]
+        return cls(clusters, ref_c, feat)
+
+    def get_z(self, x, u):
+        """gp.py:609-630 for numpy inputs: the feature the selection is made on.  x: (..., 7), u: (..., 2)."""
+        x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+        return x[..., self.feat] if self.feat < NX else u[..., self.feat - NX]
+
+    def select_gp(self, z):
+        """gp.py:738-770: index of the nearest centroid (Euclidean) for every sample; z: (n,) or (d, n).  Ties go to the lowest
+        index (numpy.argmin), i.e. to the cluster with the smaller first centroid coordinate."""
+        z = np.atleast_2d(np.asarray(z, dtype=np.float64))
+        return np.argmin(np.sqrt(np.sum((z[np.newaxis, :, :] - self.centroids[:, :, np.newaxis]) ** 2, 1)), 0)
+
+
 def gps_from_pickled(pre_trained_models):
     """``{"models": [...]}`` (or a plain list of saved dicts) -> list for ``set_gp``.  Several regressors for the same output
     dimension are the reference's per-cluster ensembles: rejected."""
@@ -93,7 +157,8 @@ def gps_from_pickled(pre_trained_models):
     gps = [gp_entry_from_saved(m) for m in models]
     outs = [g["out"] for g in gps]
     if len(set(outs)) != len(outs):
-        raise ValueError("several regressors for one output dimension (a clustered ensemble) are not supported on the device")
+        raise ValueError("several regressors for one output dimension: a clustered ensemble -- use GPEnsemble.from_pickled "
+                         "and engine.EnsembleBatchSolver (one handle per cluster)")
     return sorted(gps, key=lambda g: g["out"])
 
 
@@ -124,7 +189,7 @@ def save_regressor(path, entry, sigma_n=1e-3):
         "reg_dim": int(entry["out"]),
         "x_features": [feat] if feat < NX else [],
         "u_features": [feat - NX] if feat >= NX else [],
-        "mean": np.zeros(1),
+        "mean": np.atleast_1d(np.asarray(entry.get("centroid", 0.0), dtype=np.float64)),      # the cluster centroid (gp.py:593)
         "y_mean": np.array(float(entry.get("ymean", 0.0))),
     }
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)

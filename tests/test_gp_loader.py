@@ -59,3 +59,42 @@ def test_rejections(tmp_path):
         gp_loader.gps_from_pickled([d, d])
     with pytest.raises(ValueError):
         gp_loader.gp_entry_from_saved({"x_train": 1})
+
+
+def _ensemble_models(tmp_path, centroids=(6.0, 2.0, 10.0), dims=(3, 4)):
+    """Three clusters per output dimension, saved in a shuffled order, each cluster with its own training data."""
+    rng = np.random.default_rng(5)
+    saved = []
+    for d in dims:
+        for j, c in enumerate(centroids):
+            Z = c + np.linspace(-2.0, 2.0, 9)
+            e = dict(feat=3, out=d, Z=Z, alpha=0.05 * rng.standard_normal(9), length_scale=1.5, sigma_f=0.8, ymean=0.01 * j, centroid=[c])
+            saved.append(gp_loader.save_regressor(str(tmp_path / ("m_%d_%d.pkl" % (d, j))), e))
+    return saved
+
+
+def test_ensemble_grouping_and_nearest_centroid_selection(tmp_path):
+    """gp.py:575-607 (clusters sorted by their centroid, same centroids in every dimension) and gp.py:738-770 (select_gp) on a
+    hand-derived fixture: centroids 2, 6, 10 -> boundaries at 4 and 8, a tie goes to the lower index (numpy.argmin)."""
+    saved = _ensemble_models(tmp_path)
+    ens = gp_loader.GPEnsemble.from_pickled({"models": saved})
+    assert ens.n_models == 3 and ens.feat == 3
+    np.testing.assert_array_equal(ens.centroids[:, 0], [2.0, 6.0, 10.0])
+    for c, cen in enumerate((2.0, 6.0, 10.0)):                 # cluster c carries the regressors trained around centroid c, one per dimension
+        assert [g["out"] for g in ens.clusters[c]] == [3, 4]
+        for g in ens.clusters[c]:
+            assert abs(np.mean(g["Z"]) - cen) < 1e-12
+    z = np.array([-50.0, 0.0, 3.9, 4.0, 4.1, 7.999, 8.0, 8.001, 100.0])
+    np.testing.assert_array_equal(ens.select_gp(z), [0, 0, 0, 0, 1, 1, 1, 2, 2])
+    rng = np.random.default_rng(0)
+    zr = rng.uniform(-5, 15, 500)
+    loop = [min(range(3), key=lambda k: (abs(v - ens.centroids[k, 0]), k)) for v in zr]       # scalar restatement
+    np.testing.assert_array_equal(ens.select_gp(zr), loop)
+    x = rng.standard_normal((4, 7)); u = rng.standard_normal((4, 2))
+    np.testing.assert_array_equal(ens.get_z(x, u), x[:, 3])
+    # different centroids in the two dimensions: not usable by the reference's MPC path, rejected here
+    other = _ensemble_models(tmp_path, centroids=(6.0, 2.0, 11.0), dims=(4,))
+    with pytest.raises(ValueError):
+        gp_loader.GPEnsemble.from_pickled([m for m in saved if m["reg_dim"] == 3] + other)
+    with pytest.raises(ValueError):                              # the plain (one model per dimension) path still refuses ensembles
+        gp_loader.gps_from_pickled(saved[:4])

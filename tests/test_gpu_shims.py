@@ -168,3 +168,43 @@ def test_store_iterate_carries_the_acados_multipliers(golden_kat, tmp_path):
     sol2 = AdmpcOcpSolver(cfg)
     sol2.load_iterate(f)
     assert np.abs(sol2.get(3, "x") - sol.get(3, "x")).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_clustered_gp_ensemble_routes_every_instance_to_its_cluster(tmp_path, oracle):
+    """SURVEY 8f-4, gp.py:738-770 + quad_3d_optimizer.py:207,452: one engine handle per cluster, instances routed by the nearest
+    centroid of the reference speed.  Every instance must equal the oracle solve with the GP of ITS cluster (<= 1e-8, same
+    iteration counts), and must differ from the solve with another cluster's GP (the routing matters)."""
+    import torch
+    from test_gp_loader import _ensemble_models
+    from ad_mpc_amd import gp_loader
+    from ad_mpc_amd.config import set_gp
+    from ad_mpc_amd.engine import EnsembleBatchSolver
+    from ad_mpc_amd.scenarios import random_scenarios
+    ens = gp_loader.GPEnsemble.from_pickled({"models": _ensemble_models(tmp_path)})
+    cfg = default_config(N=20)
+    s = random_scenarios(96, N=20, seed=17, blend=(3.0, 5.0))
+    eng = EnsembleBatchSolver(cfg, ens, device=0)
+    d = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    x0, yref, yref_e, p = d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"])
+    xb, ub = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+    cost = torch.empty(96, dtype=torch.float64, device="cuda"); st = torch.empty(96, dtype=torch.int32, device="cuda"); it = torch.empty(96, dtype=torch.int32, device="cuda")
+    gp_ind = eng.select(x0, ub[:, 0, :])                                   # selection on the measured state (speed feature)
+    ind = gp_ind.cpu().numpy()
+    np.testing.assert_array_equal(ind, ens.select_gp(ens.get_z(s["x0"], s["ubar"][:, 0, :])))
+    assert len(np.unique(ind)) == 3                                          # the batch really spans the three clusters
+    eng.solve(gp_ind, x0, yref, yref_e, p, xb, ub, cost, st, it)
+    torch.cuda.synchronize()
+    U, X = ub.cpu().numpy(), xb.cpu().numpy()
+    differs = 0
+    for c in range(3):
+        m = ind == c
+        cc = cfg.copy(); set_gp(cc, ens.clusters[c])
+        o = oracle.solve_batch(cc, s["x0"][m], s["yref"][m], s["yref_e"][m], s["p"][m], s["xbar"][m], s["ubar"][m])
+        np.testing.assert_array_equal(st.cpu().numpy()[m], o[3]); np.testing.assert_array_equal(it.cpu().numpy()[m], o[4])
+        assert np.abs(U[m] - o[1]).max() <= 1e-8 and np.abs(X[m] - o[0]).max() <= 1e-8
+        co = cfg.copy(); set_gp(co, ens.clusters[(c + 1) % 3])
+        oo = oracle.solve_batch(co, s["x0"][m], s["yref"][m], s["yref_e"][m], s["p"][m], s["xbar"][m], s["ubar"][m])
+        differs += int(np.abs(U[m] - oo[1]).max() > 1e-6)
+    assert differs == 3
+    eng.close()
