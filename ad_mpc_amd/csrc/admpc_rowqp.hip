@@ -8,9 +8,9 @@
 //     defects b [B][N][7] from the linearisation kernel, the references yref / yref_e; xbar / ubar at the start and the end.
 //   workspace [B][N+1][36] in global memory (L2 / Infinity Cache resident): what only the sweeps touch -- the absolute state,
 //     its Newton step, the feedback gains, the corrector's sigma-mu coefficients -- written by one sweep, streamed by the next.
-//   LDS: what the passes over the inequalities touch, 30 values per stage and instance (slacks, multipliers, inputs, right-hand
-//     sides and steps of the inputs / the steering angle): 240 B (fp64) / 120 B (fp32) per stage -> N = 40 fp64 / N = 80 fp32:
-//     9.7 KB per instance, four waves (16 instances) per CU, one wave per SIMD.
+//   LDS: what the passes over the inequalities touch, 31 values per stage and instance (slacks, multipliers, inputs and their
+//     references, right-hand sides and steps of the inputs / the steering angle): 248 B (fp64) / 124 B (fp32) per stage ->
+//     N = 40 fp64 / N = 80 fp32: 9.9 KB per instance, four waves (16 instances) per CU, one wave per SIMD.
 //   Registers: the Riccati matrix P (7 values per lane), the stage data of the current and the next stage, lane constants.
 // Waves draw quadruples of instances from a ticket counter (zeroed by the linearisation kernel).  The four instances of a wave
 // iterate until the last of them has converged; finished rows are frozen by masks (their state is not rewritten).
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
 template <class T>
 static int rowqp_inst_stride(int N)
 {
-    int s = RQ_HDR + N * RQ_RS;                                             // values of T, even
+    int s = RQ_HDR + N * RQ_RS;                                             // values of T
+    s += s & 1;
     const int half = sizeof(T) == 8 ? 16 : 16;                              // fp64: 16 doubles = 128 B; fp32: 16 floats = 64 B
     while (s % (2 * half) != half) s += 2;
     return s;

@@ -26,12 +26,14 @@
 //   passes   l = 8*sp + side: stage parity sp, side 0..3 = (u0 lower, u0 upper, u1 lower, u1 upper), 4, 5 = steering lower, upper
 //
 // Data placement per instance
-//   LDS, pass-private, RQ_RS values per stage k = 0..N-1 behind a 16-value dump header:
+//   LDS, pass-private, RQ_RS = 31 values per stage k = 0..N-1 behind a 16-value dump header (N = 40 fp64 / N = 80 fp32: 16 instances
+//   fill the 160 KB of a CU to 98.8 %):
 //     T[10] LAM[10]  slack / multiplier of the bound pairs (side 0..5) and slack pairs (6 + side, side 0..3)
 //     UA[2]          input of stage k (absolute)        X6   steering angle of stage k (copy of XA_k[6])
 //     U[2]           gu -> kff -> ddu -> (corrector) gA -> kff -> ddu
 //     A[2]           Rt (barrier-augmented R) -> predictor ddu
 //     Q1             Qt -> predictor ddx6              X     steering-barrier term of gx6 -> (corrector) xA -> ddx6
+//     UR[2]          input references of the stage (copied once: the passes of an iteration touch no global memory but E2's store)
 //   workspace in global memory (L2-resident, streamed one stage ahead by the sweeps), RQ_RW values per record r = 0..N:
 //     XA[7] state of stage r (absolute)   D[7] Newton step of the state of stage r
 //     KK[9][2]  of stage r-1, one pair per lane: (K0[c], K1[c]) for c < 7 (feedback gains, column c), then (i00, i01), (i01, i11)
@@ -55,8 +57,8 @@
 #define RQ_PF 3        // stages in flight in the light sweeps (fp64: 4 would spill to scratch; 2 -> 3 gains 1 % at N = 40)
 #endif
 #define RQ_HDR 16
-#define RQ_RS 30
-enum { RQ_T = 0, RQ_LAM = 10, RQ_UA = 20, RQ_X6 = 22, RQ_X = 23, RQ_U = 24, RQ_A = 26, RQ_Q1 = 28 };
+#define RQ_RS 31
+enum { RQ_T = 0, RQ_LAM = 10, RQ_UA = 20, RQ_X6 = 22, RQ_X = 23, RQ_U = 24, RQ_A = 26, RQ_Q1 = 28, RQ_UR = 29 };
 #define RQ_RW 38
 enum { RW_XA = 0, RW_D = 8, RW_KK = 16, RW_UB = 34, RW_XB = 36 };
 #define RQ_GTS 42      // packed linearisation per stage: stored columns c' = 0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each
@@ -441,13 +443,7 @@ struct RowQp {
         I kc;                     // clamped stage index
     };
 
-    // reference of the side's input at step s (global memory): the pass loops fetch it two steps ahead of its use
-    RQ_FN V uref_load(int s) {
-        const int sc = 2 * s < N ? s : (N - 1) / 2;
-        const I k = sp + 2 * sc;
-        return X::gld(io.yref, iyr + X::isel(k < N, k, X::isplat(N - 1)) * 9 + 7 + jin);
-    }
-    RQ_FN void side_load(int s, Side& S, bool with_state, bool with_steps, V uref) {
+    RQ_FN void side_load(int s, Side& S, bool with_state, bool with_steps) {
         const I k = sp + 2 * s;
         const M in = k < N;
         S.kc = X::isel(in, k, X::isplat(N - 1));
@@ -455,7 +451,7 @@ struct RowQp {
         S.act = e_valid & in & ((!e_isd) | (k >= 1));
         S.stv = e_valid & in & e_even;
         S.inb = e_valid & in;
-        S.uref = uref;
+        S.uref = ld(S.kl + jin, RQ_UR);
         S.vabs = ld(S.kl + o_vl, 0);
         if (with_state) {
             S.tb = ld(S.kl + o_tb, RQ_T); S.lb = ld(S.kl + o_tb, RQ_LAM);
@@ -500,15 +496,13 @@ struct RowQp {
     RQ_FN void pass_e1(Red& R) {
         R.mu = splat((T)0); R.cmax = splat((T)0); R.rmax = splat((T)0);
         Side S, Sn;
-        V u1 = uref_load(1);
-        side_load(0, S, true, false, uref_load(0));
+        side_load(0, S, true, false);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            const V u2 = uref_load(s + 2);
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, false, u1);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, false);
             X::sched_fence(S.tb, S.lb, S.ts, S.ls);                 // the loads of the next step stay ahead of this step's work
             e1_core(S, R);
-            S = Sn; u1 = u2;
+            S = Sn;
         }
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);
     }
@@ -527,12 +521,10 @@ struct RowQp {
         const V zero = splat((T)0), one = splat((T)1);
         rr = zero; s2 = zero;
         Side S, Sn;
-        V u1 = uref_load(1);
-        side_load(0, S, true, true, uref_load(0));
+        side_load(0, S, true, true);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            const V u2 = uref_load(s + 2);
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, u1);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);
             X::sched_fence(S.tb, S.lb, S.ts, S.ls);
             Bar B; side_barrier(S, B);
             const V stp = X::sel(e_isd, S.sa, S.sc);               // ddx6_a (Q1) | ddu_a (U)
@@ -552,7 +544,7 @@ struct RowQp {
             st(S.kl + jin + RQ_A, 0, stp, S.stv & e_in);                                              // predictor ddu
             st(S.kl + o_o1, 0, X::sel(e_isd, sa, fma(rjin, S.vabs - S.uref, sa)), S.stv);
             wst((S.kc + 1) * RQ_RW + X::isel(e_isd, X::isplat(RW_XB), jin + RW_UB), 0, sb, S.stv);
-            S = Sn; u1 = u2;
+            S = Sn;
         }
         rr = X::row_max(rr); s2 = X::row_sum(s2);
     }
@@ -575,10 +567,10 @@ struct RowQp {
         const V zero = splat((T)0);
         V rr = zero;
         Side S, Sn;
-        side_load(0, S, true, true, zero);                          // the ratio test does not use the input references
+        side_load(0, S, true, true);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, zero);
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);
             X::sched_fence(S.tb, S.lb, S.ts, S.ls);
             Bar B; side_barrier(S, B);
             Step C; side_step_corr(S, B, smu, C);
@@ -622,12 +614,10 @@ struct RowQp {
         V stp = zero;
         R.mu = zero; R.cmax = zero; R.rmax = zero;
         Side S, Sn;
-        V u1 = uref_load(1);
-        side_load(0, S, true, true, uref_load(0));
+        side_load(0, S, true, true);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            const V u2 = uref_load(s + 2);
-            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true, u1);   // old state of the next step (its records are not written here)
+            side_load(2 * (s + 1) < N ? s + 1 : s, Sn, true, true);   // old state of the next step (its records are not written here)
             X::sched_fence(S.tb, S.lb, S.ts, S.ls);
             Bar B; side_barrier(S, B);
             Step C; side_step_corr(S, B, smu, C);
@@ -642,7 +632,7 @@ struct RowQp {
             st(S.kl + o_tb, RQ_T, S.tb, S.act); st(S.kl + o_tb, RQ_LAM, S.lb, S.act);
             st(S.kl + o_ts, RQ_T, S.ts, S.act & e_in); st(S.kl + o_ts, RQ_LAM, S.ls, S.act & e_in);
             e1_core(S, R);
-            S = Sn; u1 = u2;
+            S = Sn;
         }
         pass_dx_update(alpha, rowact);
         R.mu = X::row_sum(R.mu); R.cmax = X::row_max(R.cmax); R.rmax = X::row_maxnan(R.rmax);
@@ -664,6 +654,7 @@ struct RowQp {
             st(kl + o_o1, 0, X::sel(e_isd, zero, rjin * (ub - ur)), stv);
             st(kl + o_o2, 0, q6orr, stv);
             st(kl + jin + RQ_UA, 0, ub, stv & e_in);
+            st(kl + jin + RQ_UR, 0, ur, stv & e_in);
         }
     }
 
@@ -672,7 +663,7 @@ struct RowQp {
         M ok = X::mtrue();
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, false, true, splat((T)0));
+            Side S; side_load(s, S, false, true);
             const V qv = sgn * (S.vabs + S.sc - bound);
             ok = ok & ((!S.act) | (qv >= splat((T)0)));
         }
@@ -691,7 +682,7 @@ struct RowQp {
         V rs0 = zero;
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
-            Side S; side_load(s, S, false, true, uref_load(s));
+            Side S; side_load(s, S, false, true);
             const V vabs = S.vabs + X::sel(step, S.sc, zero);      // steering: X6 still holds the start point, X the trial's ddx6
             st(S.kl + jin + RQ_UA, 0, vabs, S.stv & e_in);
             const V qv = sgn * (vabs - bound);
