@@ -149,6 +149,34 @@ def test_all_state_weights_nonzero(gpu_engine_factory, oracle):
         _assert_parity(g, o)
 
 
+def _random_problem(rng, N):
+    """Problem data away from the shipped values: every weight, asymmetric bounds and L1 penalties, sampling time, terminal scale,
+    vehicle parameters (SURVEY Appendix A lists the fields the reference sets; all of them reach the kernels through AdmpcConfig)."""
+    q = tuple(float(v) for v in np.r_[rng.uniform(5, 20, 2), rng.uniform(50, 150), rng.uniform(0.0, 3.0, 4)])
+    r = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(50, 150)))
+    cfg = default_config(N=N, Ts=float(rng.uniform(0.03, 0.08)), q=q, r=r, terminal_scale=float(10 ** rng.uniform(-6, -2)))
+    cfg.lbu[0], cfg.ubu[0] = float(-rng.uniform(4, 10)), float(rng.uniform(2, 5))
+    cfg.lbu[1], cfg.ubu[1] = float(-rng.uniform(0.3, 0.6)), float(rng.uniform(0.3, 0.6))
+    cfg.lbx_delta, cfg.ubx_delta = float(-rng.uniform(0.35, 0.5)), float(rng.uniform(0.35, 0.5))
+    cfg.zl, cfg.zu = float(rng.uniform(5, 20)), float(rng.uniform(5, 20))
+    cfg.mass *= float(rng.uniform(0.8, 1.2)); cfg.Iz *= float(rng.uniform(0.8, 1.2)); cfg.L_F *= float(rng.uniform(0.9, 1.1))
+    return cfg
+
+
+@pytest.mark.parametrize("N", [13, 20, 40])
+def test_randomised_problem_data(gpu_engine_factory, oracle_omp, N):
+    """Five random problem descriptions per horizon (weights, asymmetric bounds and slack penalties, sampling time, terminal scale,
+    vehicle parameters), 96 scenarios each, against the oracle: condensed pipeline (general-weight instantiation) at N = 20,
+    kernel R otherwise.  Same statuses and iteration counts, 1e-8 / 1e-7."""
+    rng = np.random.default_rng(100 + N)
+    for trial in range(5):
+        cfg = _random_problem(rng, N)
+        s = random_scenarios(96, N=N, seed=int(rng.integers(1 << 30)), blend=(3.0, 5.0))
+        g, o = _solve_both(gpu_engine_factory(cfg), oracle_omp, cfg, s, nthreads=8)
+        assert (o[3] == 0).mean() >= 0.9
+        _assert_parity(g, o, tol_for(N))
+
+
 def test_bitwise_repeatability(gpu_engine_factory):
     """Instances are independent and every wave's arithmetic is fixed, so repeated solves must agree bit for bit -- for any
     batch size and whatever the scheduler's draw order.  Small batches matter: a wave that is alone on its SIMD gets no

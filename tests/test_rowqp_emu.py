@@ -50,6 +50,18 @@ def test_emulated_kernel_option_paths(emu, oracle):
     _strict(*_both(emu, oracle, c, random_scenarios(48, N=24, seed=99, blend=(3.0, 5.0))), 1e-8)
 
 
+def test_emulated_kernel_randomised_problem_data(emu, oracle):
+    """Weights, asymmetric bounds and L1 penalties, sampling time, terminal scale and vehicle parameters away from the shipped values
+    (CPU twin of tests/test_gpu_parity.py::test_randomised_problem_data)."""
+    from test_gpu_parity import _random_problem
+    for N in (13, 40):
+        rng = np.random.default_rng(100 + N)
+        for trial in range(3):
+            cfg = _random_problem(rng, N)
+            s = random_scenarios(24, N=N, seed=int(rng.integers(1 << 30)), blend=(3.0, 5.0))
+            _strict(*_both(emu, oracle, cfg, s), 1e-8 if N <= 32 else 1e-7)
+
+
 def test_emulated_kernel_active_slacks_steering_bound_and_failure(emu, oracle):
     cfg = default_config()
     x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
