@@ -11,18 +11,19 @@ NX, NU, NY = 7, 2, 9
 MAX_N = 128
 GP_MAX = 4
 GP_MAX_POINTS = 32
+GP_MAX_FEAT = 3
 
 
 class AdmpcGp(C.Structure):
     _fields_ = [
-        ("feat", C.c_int32),
+        ("n_feat", C.c_int32),
+        ("feat", C.c_int32 * GP_MAX_FEAT),
         ("out", C.c_int32),
         ("n_points", C.c_int32),
-        ("_pad", C.c_int32),
         ("sigma_f", C.c_double),
-        ("inv_l2", C.c_double),
+        ("inv_l2", C.c_double * GP_MAX_FEAT),
         ("ymean", C.c_double),
-        ("Z", C.c_double * GP_MAX_POINTS),
+        ("Z", (C.c_double * GP_MAX_POINTS) * GP_MAX_FEAT),
         ("alpha", C.c_double * GP_MAX_POINTS),
     ]
 
@@ -130,23 +131,30 @@ def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TER
 
 
 def set_gp(cfg, gps):
-    """Install residual GPs.  ``gps``: iterable of dicts with keys feat, out, Z, alpha, length_scale,
-    sigma_f, ymean (1-D squared-exponential GPs, src/model_fitting/gp.py:81-138,446-471)."""
+    """Install residual GPs.  ``gps``: iterable of dicts with keys feat (an index into [x;u] or a list of up to 3), out, Z (n or
+    n x d training inputs), alpha, length_scale (scalar or one per feature), sigma_f, ymean -- squared-exponential GPs with a diagonal
+    length-scale matrix, src/model_fitting/gp.py:81-138,446-471."""
     gps = list(gps)
     if len(gps) > GP_MAX:
         raise ValueError("at most %d GPs" % GP_MAX)
     cfg.n_gp = len(gps)
     for g, d in enumerate(gps):
-        Z = np.asarray(d["Z"], dtype=np.float64).reshape(-1)
+        feats = [int(f) for f in np.atleast_1d(d["feat"]).reshape(-1)]
+        nf = len(feats)
         al = np.asarray(d["alpha"], dtype=np.float64).reshape(-1)
-        if Z.size != al.size or Z.size > GP_MAX_POINTS:
+        Z = np.asarray(d["Z"], dtype=np.float64).reshape(al.size, -1)
+        ell = np.broadcast_to(np.asarray(d["length_scale"], dtype=np.float64).reshape(-1), (nf,)) if np.size(d["length_scale"]) in (1, nf) else None
+        if not (1 <= nf <= GP_MAX_FEAT) or Z.shape[1] != nf or ell is None or al.size > GP_MAX_POINTS:
             raise ValueError("bad GP size")
         s = cfg.gp[g]
-        s.feat, s.out, s.n_points = int(d["feat"]), int(d["out"]), int(Z.size)
+        s.n_feat, s.out, s.n_points = nf, int(d["out"]), int(al.size)
         s.sigma_f = float(d.get("sigma_f", 1.0))
-        s.inv_l2 = 1.0 / float(d["length_scale"]) ** 2
         s.ymean = float(d.get("ymean", 0.0))
+        for k in range(GP_MAX_FEAT):
+            s.feat[k] = feats[k] if k < nf else 0
+            s.inv_l2[k] = 1.0 / float(ell[k]) ** 2 if k < nf else 0.0
+            for i in range(GP_MAX_POINTS):
+                s.Z[k][i] = float(Z[i, k]) if (k < nf and i < al.size) else 0.0
         for i in range(GP_MAX_POINTS):
-            s.Z[i] = float(Z[i]) if i < Z.size else 0.0
-            s.alpha[i] = float(al[i]) if i < Z.size else 0.0
+            s.alpha[i] = float(al[i]) if i < al.size else 0.0
     return cfg

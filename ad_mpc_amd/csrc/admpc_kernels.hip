@@ -81,24 +81,35 @@ __device__ __forceinline__ double exp_nonpos(const double x) {
 }
 __device__ __forceinline__ float exp_nonpos(const float x) { return expf(x); }
 
-// Mean and derivative of one 1-D squared-exponential GP.  The three threads of a stage (adjacent lanes 3m, 3m+1, 3m+2: the
-// kernel maps 63 tasks to a wave) integrate the same state, so they evaluate the same GP: each takes every third training
+// Mean and gradient of one squared-exponential GP over 1..3 features (anisotropic length scale, gp.py:81-138).  The three
+// threads of a stage (adjacent lanes 3m, 3m+1, 3m+2: the kernel maps 63 tasks to a wave) integrate the same state, so they evaluate the same GP: each takes every third training
 // point and the partial sums are combined by lane shuffles, in the same order on all three lanes (identical results).
 template <class T>
-__device__ __forceinline__ void gp_eval(const AdmpcGp& g, T z, T& mu, T& dmu) {
-    T m = 0, d = 0;
-    const int n = g.n_points;
+__device__ __forceinline__ void gp_eval(const AdmpcGp& g, const T (&z)[ADMPC_GP_MAX_FEAT], T& mu, T (&dmu)[ADMPC_GP_MAX_FEAT]) {
+    T m = 0, d0 = 0, d1 = 0, d2 = 0;
+    const int n = g.n_points, nf = g.n_feat;
     const int lane = threadIdx.x & 63, sub = lane - 3 * (int)(((unsigned)lane * 21846u) >> 16), base = lane - sub;   // lane % 3 without a narrow urem (see div7)
-    const T sf = (T)g.sigma_f, il2 = (T)g.inv_l2;
-    for (int i = sub; i < n; i += 3) {
-        const T dz = z - (T)g.Z[i];
-        const T k = sf * exp_nonpos((T)-0.5 * dz * dz * il2);
-        m += k * (T)g.alpha[i];
-        d -= k * dz * il2 * (T)g.alpha[i];
+    const T sf = (T)g.sigma_f;
+    const T il0 = (T)g.inv_l2[0];
+    if (nf == 1) {                          // wave-uniform: the one-feature regressors of config 3 keep their short loop
+        for (int i = sub; i < n; i += 3) {
+            const T e0 = z[0] - (T)g.Z[0][i];
+            const T ka = sf * exp_nonpos((T)-0.5 * e0 * e0 * il0) * (T)g.alpha[i];
+            m += ka;
+            d0 -= ka * e0 * il0;
+        }
+    } else {
+        const T il1 = (T)g.inv_l2[1], il2 = nf > 2 ? (T)g.inv_l2[2] : (T)0;   // unused feature: weight 0
+        for (int i = sub; i < n; i += 3) {
+            const T e0 = z[0] - (T)g.Z[0][i], e1 = z[1] - (T)g.Z[1][i], e2 = z[2] - (T)g.Z[2][i];
+            const T ka = sf * exp_nonpos((T)-0.5 * (e0 * e0 * il0 + e1 * e1 * il1 + e2 * e2 * il2)) * (T)g.alpha[i];
+            m += ka;
+            d0 -= ka * e0 * il0; d1 -= ka * e1 * il1; d2 -= ka * e2 * il2;
+        }
     }
-    const T m0 = __shfl(m, base), m1 = __shfl(m, base + 1), m2 = __shfl(m, base + 2);
-    const T d0 = __shfl(d, base), d1 = __shfl(d, base + 1), d2 = __shfl(d, base + 2);
-    mu = (m0 + m1) + m2 + (T)g.ymean; dmu = (d0 + d1) + d2;
+    auto tri = [&](T v) { const T a = __shfl(v, base), b = __shfl(v, base + 1), c = __shfl(v, base + 2); return (a + b) + c; };
+    mu = tri(m) + (T)g.ymean; dmu[0] = tri(d0); dmu[1] = (T)0; dmu[2] = (T)0;
+    if (nf > 1) { dmu[1] = tri(d1); dmu[2] = tri(d2); }
 }
 
 // T = float: the reference's "+ 1e-99" in the slip-angle denominators (ad_3d_optimizer.py:290,296-297) is 0 in fp32, and with
@@ -160,19 +171,37 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     const int ngp = c->n_gp;
     for (int g = 0; g < ngp; ++g) {          // residual GPs: out in {3,4,5}, feat in {3..8} (validated on the host)
         const AdmpcGp& gp = c->gp[g];
-        const int feat = gp.feat - 3, out = gp.out - 3;          // feat: 0..3 -> (vx,vy,r,delta), 4..5 -> (u0,u1)
+        const int out = gp.out - 3, nf = gp.n_feat;
         // static indexing only: runtime-indexed private arrays would live in scratch memory
-        const T z = feat == 0 ? vx : feat == 1 ? vy : feat == 2 ? r : feat == 3 ? dl : feat == 4 ? u[0] : u[1];
-        T mu, dmu;
+        int fd[ADMPC_GP_MAX_FEAT];
+        T z[ADMPC_GP_MAX_FEAT], dmu[ADMPC_GP_MAX_FEAT], mu;
+#pragma unroll
+        for (int d = 0; d < ADMPC_GP_MAX_FEAT; ++d) {
+            fd[d] = d < nf ? gp.feat[d] - 3 : -1;                // 0..3 -> (vx,vy,r,delta), 4..5 -> (u0,u1); -1: unused
+            z[d] = fd[d] == 0 ? vx : fd[d] == 1 ? vy : fd[d] == 2 ? r : fd[d] == 3 ? dl : fd[d] == 4 ? u[0] : fd[d] == 5 ? u[1] : (T)0;
+        }
         gp_eval<T>(gp, z, mu, dmu);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const bool so = out == o;
             e.f[3 + o] += so ? mu : (T)0;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && feat == cc) ? dmu : (T)0;
-            e.bu[o][0] += (so && feat == 4) ? dmu : (T)0;
-            e.bu[o][1] += (so && feat == 5) ? dmu : (T)0;
+            for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && fd[0] == cc) ? dmu[0] : (T)0;
+            e.bu[o][0] += (so && fd[0] == 4) ? dmu[0] : (T)0;
+            e.bu[o][1] += (so && fd[0] == 5) ? dmu[0] : (T)0;
+        }
+        if (nf > 1) {                        // wave-uniform: one-feature regressors skip the selects of the other two features
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const bool so = out == o;
+#pragma unroll
+                for (int d = 1; d < ADMPC_GP_MAX_FEAT; ++d) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && fd[d] == cc) ? dmu[d] : (T)0;
+                    e.bu[o][0] += (so && fd[d] == 4) ? dmu[d] : (T)0;
+                    e.bu[o][1] += (so && fd[d] == 5) ? dmu[d] : (T)0;
+                }
+            }
         }
     }
 }
@@ -1673,8 +1702,10 @@ static int validate(const AdmpcConfig* c)
     if (c->n_gp < 0 || c->n_gp > ADMPC_GP_MAX) return fail(ADMPC_EINVAL, "n_gp out of range");
     for (int g = 0; g < c->n_gp; ++g) {
         const AdmpcGp& gp = c->gp[g];
-        if (gp.out < 3 || gp.out > 5 || gp.feat < 3 || gp.feat > 8 || gp.n_points < 0 || gp.n_points > ADMPC_GP_MAX_POINTS)
-            return fail(ADMPC_EINVAL, "GP: out must be in {3,4,5}, feat in {3..8}, n_points <= 32");
+        bool okf = gp.n_feat >= 1 && gp.n_feat <= ADMPC_GP_MAX_FEAT;
+        for (int d = 0; okf && d < gp.n_feat; ++d) okf = gp.feat[d] >= 3 && gp.feat[d] <= 8;
+        if (gp.out < 3 || gp.out > 5 || !okf || gp.n_points < 0 || gp.n_points > ADMPC_GP_MAX_POINTS)
+            return fail(ADMPC_EINVAL, "GP: out must be in {3,4,5}, 1..3 features in {3..8}, n_points <= 32");
     }
     if (!(c->W[NX] > 0 && c->W[NX + 1] > 0)) return fail(ADMPC_EINVAL, "input weights must be positive (strict convexity)");
     if (c->ipm_iter_max < 1) return fail(ADMPC_EINVAL, "ipm_iter_max < 1");

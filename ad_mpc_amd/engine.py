@@ -216,7 +216,7 @@ class EnsembleBatchSolver:
             self.solvers.append(BatchSolver(cc, device=device))
         self.device = self.solvers[0].device
         self.N = self.solvers[0].N
-        self._cent = torch.as_tensor(ensemble.centroids[:, 0].copy(), dtype=torch.float64, device=self.device)
+        self._cent = torch.as_tensor(ensemble.centroids.copy(), dtype=torch.float64, device=self.device)       # K x d
 
     def close(self):
         for s in self.solvers:
@@ -225,9 +225,9 @@ class EnsembleBatchSolver:
     def select(self, x_sel, u_sel):
         """Cluster of every instance from the state / input the caller selects on (the reference passes the reference state and
         the input target): nearest centroid of the ensemble's feature, ties to the lowest index.  Device tensors in and out."""
-        f = self.ensemble.feat
-        z = (x_sel[:, f] if f < NX else u_sel[:, f - NX]).to(torch.float64)
-        return torch.argmin(torch.sqrt((z[None, :] - self._cent[:, None]) ** 2), dim=0)
+        xu = torch.cat([x_sel, u_sel], dim=1).to(torch.float64)
+        z = xu[:, self.ensemble.feats]                                                   # B x d
+        return torch.argmin(torch.sqrt(((z[None, :, :] - self._cent[:, None, :]) ** 2).sum(dim=2)), dim=0)
 
     def solve(self, gp_ind, x0, yref, yref_e, p, xbar, ubar, cost=None, status=None, iters=None):
         """BatchSolver.solve with a cluster index per instance (int64 device tensor).  In place on xbar / ubar."""

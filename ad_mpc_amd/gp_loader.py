@@ -7,8 +7,9 @@ Directory scheme (``src/utils/utils.py:175-236``): ``<save_dir>/<git>/<model_nam
 ``file_name = '__'.join(('' if v else 'no_') + k for k, v in sorted(params.items()))``.
 
 The engine evaluates the GP mean  mu(z) = sum_i k(z, x_train_i) k_inv_y_i + y_mean  with  k = sigma_f exp(-|z - x|^2 / (2 l^2))
-(sigma_f is NOT squared in the reference, ``gp.py:81-138``) inside the dynamics (``ad_mpc_amd.config.set_gp``).  Device limits:
-1-D feature per regressor, at most 4 regressors and 32 training points each; anything else raises ``ValueError``.
+(sigma_f is NOT squared in the reference, ``gp.py:81-138``; ``l`` is a scalar or one length scale per feature) inside the dynamics
+(``ad_mpc_amd.config.set_gp``).  Device limits: 1 to 3 features per regressor out of (v_x, v_y, psi_dot, delta, a, delta_dot), at
+most 4 regressors and 32 training points each; anything else raises ``ValueError``.
 
 Clustered ensembles (``GPEnsemble``, ``gp.py:536-607``; selection ``select_gp``, ``gp.py:738-770``): the reference keeps one
 acados solver per cluster (``quad_3d_optimizer.py:207``) and picks one per solve from the reference state (``:452``, ``:491``).
@@ -20,7 +21,7 @@ import os
 
 import numpy as np
 
-from .config import GP_MAX, GP_MAX_POINTS, NX, NU, set_gp
+from .config import GP_MAX, GP_MAX_FEAT, GP_MAX_POINTS, NX, NU, set_gp
 
 SAVED_KEYS = ("kernel_params", "kernel_type", "x_train", "y_train", "k_inv_y", "k_inv", "sigma_n", "reg_dim", "x_features",
               "u_features", "mean", "y_mean")
@@ -66,27 +67,32 @@ def gp_entry_from_saved(d):
         raise ValueError("only the squared_exponential kernel is supported (gp.py:60)")
     xf = [int(i) for i in np.atleast_1d(d["x_features"]).reshape(-1)] if d["x_features"] is not None else []
     uf = [int(i) for i in np.atleast_1d(d["u_features"]).reshape(-1)] if d["u_features"] is not None else []
-    if len(xf) + len(uf) != 1:
-        raise ValueError("device GPs take ONE feature; this regressor has x_features=%s u_features=%s" % (xf, uf))
-    feat = xf[0] if xf else NX + uf[0]
-    if not (0 <= feat < NX + NU):
-        raise ValueError("feature index %d outside [x(7); u(2)]" % feat)
+    feats = xf + [NX + i for i in uf]                       # z = [x[x_features]; u[u_features]] (gp.py:609-630)
+    if not (1 <= len(feats) <= GP_MAX_FEAT):
+        raise ValueError("device GPs take 1..%d features; this regressor has x_features=%s u_features=%s" % (GP_MAX_FEAT, xf, uf))
+    if any(not (3 <= f < NX + NU) for f in feats):
+        raise ValueError("features must be among v_x, v_y, psi_dot, delta, a, delta_dot (indices 3..8 of [x(7); u(2)]), got %s" % feats)
     Z = np.asarray(d["x_train"], dtype=np.float64)
     Z = Z.reshape(Z.shape[0], -1)
-    if Z.shape[1] != 1:
-        raise ValueError("x_train must be n x 1 for a one-feature regressor, got %s" % (Z.shape,))
+    if Z.shape[1] != len(feats):
+        raise ValueError("x_train must be n x %d for this regressor, got %s" % (len(feats), Z.shape,))
     alpha = np.asarray(d["k_inv_y"], dtype=np.float64).reshape(-1)
     if alpha.size != Z.shape[0]:
         raise ValueError("k_inv_y has %d entries for %d training points" % (alpha.size, Z.shape[0]))
     if Z.shape[0] > GP_MAX_POINTS:
         raise ValueError("%d training points; the device holds at most %d" % (Z.shape[0], GP_MAX_POINTS))
     kp = d["kernel_params"]
-    ell = float(np.squeeze(kp["l"])) if "l" in kp else 1.0
+    ell = np.atleast_1d(np.squeeze(np.asarray(kp["l"], dtype=np.float64))).reshape(-1) if "l" in kp else np.ones(1)
+    if ell.size not in (1, len(feats)):
+        raise ValueError("anisotropic kernel must have one length scale per feature (gp.py:73-80)")
+    ell = float(ell[0]) if ell.size == 1 else ell
     out = int(np.squeeze(d["reg_dim"]))
     if not (0 <= out < NX):
         raise ValueError("reg_dim %d outside the state" % out)
     ymean = float(np.squeeze(d["y_mean"])) if d.get("y_mean") is not None else 0.0
-    return dict(feat=feat, out=out, Z=Z[:, 0], alpha=alpha, length_scale=ell, sigma_f=float(kp.get("sigma_f", 1.0)), ymean=ymean)
+    one = len(feats) == 1
+    return dict(feat=feats[0] if one else feats, out=out, Z=Z[:, 0] if one else Z, alpha=alpha, length_scale=ell,
+                sigma_f=float(kp.get("sigma_f", 1.0)), ymean=ymean)
 
 
 class GPEnsemble:
@@ -97,7 +103,8 @@ class GPEnsemble:
     def __init__(self, clusters, centroids, feat):
         self.clusters = clusters
         self.centroids = np.asarray(centroids, dtype=np.float64).reshape(len(clusters), -1)
-        self.feat = int(feat)                                 # index into [x(7); u(2)] of the feature the centroids live in
+        self.feats = [int(f) for f in np.atleast_1d(feat).reshape(-1)]      # indices into [x(7); u(2)] of the features the centroids live in
+        self.feat = self.feats[0]
 
     @property
     def n_models(self):
@@ -139,7 +146,9 @@ class GPEnsemble:
     def get_z(self, x, u):
         """gp.py:609-630 for numpy inputs: the feature the selection is made on.  x: (..., 7), u: (..., 2)."""
         x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
-        return x[..., self.feat] if self.feat < NX else u[..., self.feat - NX]
+        xu = np.concatenate([x, u], axis=-1)
+        z = xu[..., self.feats]
+        return z[..., 0] if len(self.feats) == 1 else np.moveaxis(z, -1, 0)          # (n,) or (d, n) as select_gp takes it
 
     def select_gp(self, z):
         """gp.py:738-770: index of the nearest centroid (Euclidean) for every sample; z: (n,) or (d, n).  Ties go to the lowest
@@ -176,10 +185,10 @@ def save_regressor(path, entry, sigma_n=1e-3):
     """Write one regressor in the reference's format (used by tests and for hand-made models): ``entry`` as for ``set_gp``
     plus optional ``y_train``.  The key set and value shapes follow ``GPRegressor.save`` (gp.py:495-508)."""
     import joblib
-    Z = np.asarray(entry["Z"], dtype=np.float64).reshape(-1, 1)
-    feat = int(entry["feat"])
+    feats = [int(f) for f in np.atleast_1d(entry["feat"]).reshape(-1)]
+    Z = np.asarray(entry["Z"], dtype=np.float64).reshape(-1, len(feats))
     d = {
-        "kernel_params": {"l": np.array([float(entry["length_scale"])]), "sigma_f": float(entry.get("sigma_f", 1.0))},
+        "kernel_params": {"l": np.atleast_1d(np.asarray(entry["length_scale"], dtype=np.float64)).reshape(-1), "sigma_f": float(entry.get("sigma_f", 1.0))},
         "kernel_type": "squared_exponential",
         "x_train": Z,
         "y_train": np.asarray(entry.get("y_train", np.zeros(Z.shape[0])), dtype=np.float64).reshape(-1, 1),
@@ -187,8 +196,8 @@ def save_regressor(path, entry, sigma_n=1e-3):
         "k_inv": np.eye(Z.shape[0]),
         "sigma_n": float(sigma_n),
         "reg_dim": int(entry["out"]),
-        "x_features": [feat] if feat < NX else [],
-        "u_features": [feat - NX] if feat >= NX else [],
+        "x_features": [f for f in feats if f < NX],
+        "u_features": [f - NX for f in feats if f >= NX],
         "mean": np.atleast_1d(np.asarray(entry.get("centroid", 0.0), dtype=np.float64)),      # the cluster centroid (gp.py:593)
         "y_mean": np.array(float(entry.get("ymean", 0.0))),
     }

@@ -43,6 +43,7 @@ extern "C" {
 #define ADMPC_MAX_N 128     /* largest supported horizon                                       */
 #define ADMPC_GP_MAX 4      /* residual GPs per model                                          */
 #define ADMPC_GP_MAX_POINTS 32
+#define ADMPC_GP_MAX_FEAT 3   /* features per residual GP                                         */
 
 #define ADMPC_OK            0
 #define ADMPC_EINVAL      (-1)   /* bad argument / unsupported configuration  */
@@ -60,19 +61,20 @@ extern "C" {
 #define ADMPC_STATUS_MAXITER     2   /* SQP mode with sqp_tol > 0: not converged within sqp_iters steps (iterate and cost are valid) */
 #define ADMPC_STATUS_QP_FAILURE  4
 
-/* One 1-D squared-exponential residual GP: f[out] += mu(z),  z = [x;u][feat]
- *   mu(z) = ymean + sum_i sigma_f * exp(-0.5*(z-Z_i)^2*inv_l2) * alpha_i
+/* One squared-exponential residual GP with an anisotropic (diagonal) length scale over 1..3 features:
+ * f[out] += mu(z),  z_d = [x;u][feat[d]]
+ *   mu(z) = ymean + sum_i sigma_f * exp(-0.5 * sum_d (z_d - Z[d][i])^2 * inv_l2[d]) * alpha_i
  * (model_fitting/gp.py:81-138,446-471 -- note sigma_f is NOT squared, gp.py:138;
  *  B_z/B_x selection matrices utils/utils.py:773-808; wiring quad_3d_optimizer.py:289-327) */
 typedef struct AdmpcGp {
-    int32_t feat;                       /* index into [x(7);u(2)] */
+    int32_t n_feat;                     /* 1 .. ADMPC_GP_MAX_FEAT (x_features + u_features of the saved regressor, gp.py:495-508) */
+    int32_t feat[ADMPC_GP_MAX_FEAT];    /* indices into [x(7);u(2)], each in {3..8}: v_x v_y psi_dot delta a delta_dot */
     int32_t out;                        /* state derivative row that receives mu */
     int32_t n_points;                   /* <= ADMPC_GP_MAX_POINTS */
-    int32_t _pad;
     double  sigma_f;
-    double  inv_l2;                     /* 1 / l^2 */
+    double  inv_l2[ADMPC_GP_MAX_FEAT];  /* 1 / l_d^2 (a scalar length scale is repeated) */
     double  ymean;
-    double  Z[ADMPC_GP_MAX_POINTS];
+    double  Z[ADMPC_GP_MAX_FEAT][ADMPC_GP_MAX_POINTS];   /* training inputs, feature-major */
     double  alpha[ADMPC_GP_MAX_POINTS]; /* K^-1 y */
 } AdmpcGp;
 

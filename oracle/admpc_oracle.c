@@ -57,18 +57,22 @@ typedef double real;
 /* model                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
 
-/* mean and derivative of one 1-D SE GP (gp.py:81-138 kernel, :446-471 mean, :140-165 derivative) */
-static void gp_eval(const AdmpcGp* g, real z, real* mu, real* dmu)
+/* mean and gradient of one SE GP with an anisotropic length scale over n_feat features (gp.py:81-138 kernel: sigma_f exp(-0.5
+ * sum_d (z_d - x_d)^2 / l_d^2), :446-471 mean, :140-165 derivative); z_d = [x;u][feat[d]] */
+static void gp_eval(const AdmpcGp* g, const real* x, const real* u, real* mu, real* dmu)
 {
-    real m = 0, d = 0;
+    real m = 0, d[ADMPC_GP_MAX_FEAT] = {0};
+    real z[ADMPC_GP_MAX_FEAT];
+    for (int k = 0; k < g->n_feat; ++k) z[k] = g->feat[k] < NX ? x[g->feat[k]] : u[g->feat[k] - NX];
     for (int i = 0; i < g->n_points; ++i) {
-        real dz = z - (real)g->Z[i];
-        real k = (real)g->sigma_f * R_EXP(-(real)0.5 * dz * dz * (real)g->inv_l2);
-        m += k * (real)g->alpha[i];
-        d -= k * dz * (real)g->inv_l2 * (real)g->alpha[i];
+        real e = 0;
+        for (int k = 0; k < g->n_feat; ++k) { real dz = z[k] - (real)g->Z[k][i]; e += dz * dz * (real)g->inv_l2[k]; }
+        real ka = (real)g->sigma_f * R_EXP(-(real)0.5 * e) * (real)g->alpha[i];
+        m += ka;
+        for (int k = 0; k < g->n_feat; ++k) d[k] -= ka * (z[k] - (real)g->Z[k][i]) * (real)g->inv_l2[k];
     }
     *mu = m + (real)g->ymean;
-    *dmu = d;
+    for (int k = 0; k < g->n_feat; ++k) dmu[k] = d[k];
 }
 
 static void model_f(const AdmpcConfig* c, const real* x, const real* u, real p, real* f)
@@ -94,9 +98,8 @@ static void model_f(const AdmpcConfig* c, const real* x, const real* u, real p, 
     f[6] = u[1];                                                /* :310 */
     for (int g = 0; g < c->n_gp; ++g) {                         /* quad_3d_optimizer.py:315 */
         const AdmpcGp* gp = &c->gp[g];
-        real z = gp->feat < NX ? x[gp->feat] : u[gp->feat - NX];
-        real mu, dmu;
-        gp_eval(gp, z, &mu, &dmu);
+        real mu, dmu[ADMPC_GP_MAX_FEAT];
+        gp_eval(gp, x, u, &mu, dmu);
         f[gp->out] += mu;
     }
 }
@@ -141,10 +144,11 @@ static void model_jac(const AdmpcConfig* c, const real* x, const real* u, real p
     Ju[6][1] = 1;
     for (int g = 0; g < c->n_gp; ++g) {
         const AdmpcGp* gp = &c->gp[g];
-        real z = gp->feat < NX ? x[gp->feat] : u[gp->feat - NX];
-        real mu, dmu;
-        gp_eval(gp, z, &mu, &dmu);
-        if (gp->feat < NX) Jx[gp->out][gp->feat] += dmu; else Ju[gp->out][gp->feat - NX] += dmu;
+        real mu, dmu[ADMPC_GP_MAX_FEAT];
+        gp_eval(gp, x, u, &mu, dmu);
+        for (int k = 0; k < gp->n_feat; ++k) {
+            if (gp->feat[k] < NX) Jx[gp->out][gp->feat[k]] += dmu[k]; else Ju[gp->out][gp->feat[k] - NX] += dmu[k];
+        }
     }
 }
 

@@ -46,9 +46,15 @@ def test_round_trip_and_directory_scheme(tmp_path, oracle):
 def test_rejections(tmp_path):
     e = grid_gp()[0]
     d = gp_loader.save_regressor(str(tmp_path / "a.pkl"), e)
-    two = dict(d); two["x_features"] = [3, 4]
+    two = dict(d); two["x_features"] = [3, 4]                  # two features but one-column training inputs
     with pytest.raises(ValueError):
         gp_loader.gp_entry_from_saved(two)
+    four = dict(d); four["x_features"] = [3, 4, 5, 6]; four["x_train"] = np.zeros((5, 4)); four["k_inv_y"] = np.zeros((5, 1))
+    with pytest.raises(ValueError):                             # more features than the device holds
+        gp_loader.gp_entry_from_saved(four)
+    pos = dict(d); pos["x_features"] = [0]                      # position is not a feature of the device model
+    with pytest.raises(ValueError):
+        gp_loader.gp_entry_from_saved(pos)
     wrong = dict(d); wrong["kernel_type"] = "matern"
     with pytest.raises(ValueError):
         gp_loader.gp_entry_from_saved(wrong)
@@ -98,3 +104,34 @@ def test_ensemble_grouping_and_nearest_centroid_selection(tmp_path):
         gp_loader.GPEnsemble.from_pickled([m for m in saved if m["reg_dim"] == 3] + other)
     with pytest.raises(ValueError):                              # the plain (one model per dimension) path still refuses ensembles
         gp_loader.gps_from_pickled(saved[:4])
+
+
+def test_multi_feature_regressor_round_trip_and_oracle_jacobian(tmp_path, oracle):
+    """A regressor over (v_x, delta, a) with one length scale per feature (the reference's anisotropic kernel, gp.py:81-138): file
+    round trip, predictive mean inside the oracle's dynamics against a direct numpy evaluation, and the oracle's analytic Jacobian
+    (all three features, state and input columns) against central differences."""
+    rng = np.random.default_rng(3)
+    Z = np.c_[rng.uniform(2, 12, 24), rng.uniform(-0.3, 0.3, 24), rng.uniform(-3, 3, 24)]
+    e = dict(feat=[3, 6, 7], out=4, Z=Z, alpha=0.2 * rng.standard_normal(24), length_scale=[2.0, 0.2, 1.5], sigma_f=0.7, ymean=0.05)
+    d = gp_loader.save_regressor(str(tmp_path / "mf.pkl"), e)
+    assert d["x_features"] == [3, 6] and d["u_features"] == [0] and d["x_train"].shape == (24, 3)
+    g = gp_loader.gp_entry_from_saved(d)
+    assert g["feat"] == [3, 6, 7]
+    cfg = default_config(N=20)
+    from ad_mpc_amd.config import set_gp
+    set_gp(cfg, [g])
+    base = default_config(N=20)
+    x = np.array([1.0, -2.0, 0.3, 6.0, 0.2, -0.1, 0.05]); u = np.array([0.5, -0.2])
+    z = np.array([x[3], x[6], u[0]])
+    k = 0.7 * np.exp(-0.5 * (((z - Z) / np.array([2.0, 0.2, 1.5])) ** 2).sum(1))
+    mu = float(k @ e["alpha"] + 0.05)
+    f0 = oracle.f(base, x, u, 0.4); f1 = oracle.f(cfg, x, u, 0.4)
+    assert abs((f1[4] - f0[4]) - mu) <= 1e-13 and np.abs(np.delete(f1 - f0, 4)).max() == 0.0
+    Jx, Ju = oracle.jac(cfg, x, u, 0.4)
+    h = 1e-6
+    for i in range(7):
+        dx = np.zeros(7); dx[i] = h
+        np.testing.assert_allclose(Jx[:, i], (oracle.f(cfg, x + dx, u, 0.4) - oracle.f(cfg, x - dx, u, 0.4)) / (2 * h), atol=2e-7)
+    for j in range(2):
+        du = np.zeros(2); du[j] = h
+        np.testing.assert_allclose(Ju[:, j], (oracle.f(cfg, x, u + du, 0.4) - oracle.f(cfg, x, u - du, 0.4)) / (2 * h), atol=2e-7)

@@ -363,6 +363,38 @@ def test_gp_residual_config3(gpu_engine_factory, oracle):
     assert np.abs(base[1] - o[1]).max() > 1e-3       # the GP really changes the answer
 
 
+def _multi_feature_gps(seed=8):
+    """Three regressors with 3, 2 and 1 features (states and inputs mixed, one length scale per feature)."""
+    rng = np.random.default_rng(seed)
+    Z3 = np.c_[rng.uniform(2, 14, 28), rng.uniform(-0.3, 0.3, 28), rng.uniform(-4, 4, 28)]
+    Z2 = np.c_[rng.uniform(-0.5, 0.5, 20), rng.uniform(-0.5, 0.5, 20)]
+    return [dict(feat=[3, 6, 7], out=3, Z=Z3, alpha=0.15 * rng.standard_normal(28), length_scale=[2.5, 0.25, 2.0], sigma_f=0.9, ymean=0.02),
+            dict(feat=[4, 8], out=4, Z=Z2, alpha=0.1 * rng.standard_normal(20), length_scale=[0.3, 0.4], sigma_f=1.1, ymean=-0.01),
+            dict(feat=5, out=5, Z=np.linspace(-0.4, 0.4, 16), alpha=0.1 * rng.standard_normal(16), length_scale=0.2, sigma_f=1.0, ymean=0.0)]
+
+
+@pytest.mark.parametrize("N", [20, 40])
+def test_multi_feature_gp_residual(gpu_engine_factory, oracle_omp, N):
+    """Residual GPs over up to three features with an anisotropic length scale (gp.py:81-138): shooting (state, A, B) against the
+    oracle's RK4 with analytic GP gradients at 1e-11 relative, then the solve on the condensed pipeline (N = 20) and kernel R (N = 40)."""
+    import torch
+    cfg = default_config(N=N); set_gp(cfg, _multi_feature_gps())
+    s = random_scenarios(128, N=N, seed=77, blend=(3.0, 5.0))
+    eng = gpu_engine_factory(cfg)
+    phi, A, Bm = eng.shoot(eng.to_device(s["xbar"]), eng.to_device(s["ubar"]), eng.to_device(s["p"]))
+    torch.cuda.synchronize()
+    phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
+    for b in range(0, 128, 17):
+        for k in (0, N // 2, N - 1):
+            po, Ao, Bo = oracle_omp.rk4_sens(cfg, s["xbar"][b, k], s["ubar"][b, k], s["p"][b], cfg.Ts)
+            for got, ref in ((phi[b, k], po), (A[b, k], Ao), (Bm[b, k], Bo)):
+                assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    g, o = _solve_both(eng, oracle_omp, cfg, s, nthreads=8)
+    _assert_parity(g, o, tol_for(N))
+    base = oracle_omp.solve_batch(default_config(N=N), s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=8)
+    assert np.abs(base[1] - o[1]).max() > 1e-3       # the GPs really change the answer
+
+
 def test_active_slack_and_steering_bound(gpu_engine_factory, oracle):
     cfg = default_config()
     x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
@@ -469,7 +501,7 @@ def test_empty_batch_and_argument_errors(gpu_engine_factory):
     bad = cfg.copy(); bad.N = 1
     h = C.c_void_p(0)
     assert L.admpc_create(C.byref(bad), 0, C.byref(h)) == -1
-    bad = cfg.copy(); bad.n_gp = 1; bad.gp[0].out = 0; bad.gp[0].feat = 3
+    bad = cfg.copy(); bad.n_gp = 1; bad.gp[0].out = 0; bad.gp[0].n_feat = 1; bad.gp[0].feat[0] = 3
     assert L.admpc_create(C.byref(bad), 0, C.byref(h)) == -1
     assert L.admpc_create(C.byref(cfg), 99, C.byref(h)) == -2                           # no such device
     with pytest.raises(ValueError):
