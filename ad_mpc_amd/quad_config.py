@@ -1,0 +1,44 @@
+"""ctypes mirror of include/admpc_quad.h (AdmpcQuadConfig) and the shipped quadrotor problem
+(acados_models/my_quad_acados_ocp.json, src/quad_mpc/quad_3d.py:40-74)."""
+import ctypes as C
+import math
+
+QNX, QNU, QNY, QUAD_MAX_N = 13, 4, 17, 16
+
+
+class AdmpcQuadConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("ipm_iter_max", C.c_int32), ("Ts", C.c_double),
+        ("W", C.c_double * QNY), ("We", C.c_double * QNX),
+        ("lbu", C.c_double * QNU), ("ubu", C.c_double * QNU),
+        ("mass", C.c_double), ("J", C.c_double * 3), ("max_thrust", C.c_double),
+        ("x_f", C.c_double * 4), ("y_f", C.c_double * 4), ("z_l_tau", C.c_double * 4), ("g", C.c_double),
+        ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double), ("ipm_tol_comp", C.c_double), ("ipm_tol_res", C.c_double),
+    ]
+
+    def copy(self):
+        c = AdmpcQuadConfig()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(self))
+        return c
+
+
+def default_quad_config(N=10, t_horizon=1.0):
+    """my_quad_acados_ocp.json: N = 10, tf = 1 s, W = diag(10,10,10, 0,.1,.1,.1, .05 x 6, .1 x 4), W_e = 0, 0 <= u <= 1;
+    vehicle of quad_3d.py ('x' configuration)."""
+    if not (2 <= N <= QUAD_MAX_N):
+        raise ValueError("N must be in [2, %d]" % QUAD_MAX_N)
+    c = AdmpcQuadConfig()
+    c.N, c.ipm_iter_max, c.Ts = int(N), 50, float(t_horizon) / N
+    for i, v in enumerate([10.0] * 3 + [0.0] + [0.1] * 3 + [0.05] * 6 + [0.1] * 4):
+        c.W[i] = v
+    for i in range(QNX):
+        c.We[i] = 0.0
+    for i in range(QNU):
+        c.lbu[i], c.ubu[i] = 0.0, 1.0
+    c.mass, c.max_thrust, c.g = 1.0, 20.0, 9.81
+    c.J[0], c.J[1], c.J[2] = 0.03, 0.03, 0.06
+    h = math.cos(math.pi / 4) * (0.47 / 2)
+    for i, (xf, yf, zt) in enumerate(zip((h, -h, -h, h), (-h, -h, h, h), (-0.013, 0.013, -0.013, 0.013))):
+        c.x_f[i], c.y_f[i], c.z_l_tau[i] = xf, yf, zt
+    c.ipm_mu0, c.ipm_thr0, c.ipm_tol_comp, c.ipm_tol_res = 1.0, 0.1, 1e-10, 1e-9
+    return c

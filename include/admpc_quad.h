@@ -1,0 +1,69 @@
+/*
+ * admpc_quad.h -- C ABI of the second vehicle model behind the engine: the quadrotor of
+ * data_driven_mpc/ros_gp_mpc/src/quad_mpc (nx = 13, nu = 4), one acados SQP-RTI step per call for a batch of instances.
+ *
+ *   reference call site (data_driven_mpc/ros_gp_mpc/src/quad_mpc/...)              replaced by
+ *   ------------------------------------------------------------------------------  --------------------------
+ *   quad_3d_optimizer.py:341-393   quad_dynamics (p, q, v, w dynamics)              the model inside admpc_quad_solve_batch
+ *   quad_3d_optimizer.py:150-207   AcadosOcp: LINEAR_LS cost, input box, ERK, GN,    AdmpcQuadConfig
+ *                                  FULL_CONDENSING_HPIPM, SQP_RTI
+ *   acados_models/my_quad_acados_ocp.json  dims / W / bounds / tf                   admpc_quad_default_config
+ *   quad_3d_optimizer.py:530-566   set x0 / solve() / get x, u                      admpc_quad_solve_batch
+ *
+ * State  x = [p(3), q_wxyz(4), v(3), w(3)],  input u = activations of the four rotors in [0, 1].
+ * Conventions as in admpc.h: device pointers owned by the caller, instance-major and dense, fp64; `stream` is a hipStream_t passed
+ * as void*; 0 or a negative ADMPC_E* code is returned (admpc_last_error() of admpc.h gives the message); one solve in flight per
+ * handle.  Per-instance status: 0 success (also at ipm_iter_max, acados RTI semantics), 4 non-finite step (iterate untouched).
+ */
+#ifndef ADMPC_QUAD_H
+#define ADMPC_QUAD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADMPC_QUAD_NX 13
+#define ADMPC_QUAD_NU 4
+#define ADMPC_QUAD_NY 17
+#define ADMPC_QUAD_MAX_N 16      /* N * nu <= 64: one lane per input of the condensed QP */
+
+typedef struct AdmpcQuadConfig {
+    int32_t N;                    /* shooting intervals (reference: 10)                                            */
+    int32_t ipm_iter_max;         /* qp_solver_iter_max (50)                                                       */
+    double  Ts;                   /* tf / N (0.1 s)                                                                */
+    double  W[ADMPC_QUAD_NY];     /* diag of the stage weight on y = [x; u] (acados scales it by Ts)               */
+    double  We[ADMPC_QUAD_NX];    /* diag of the terminal weight (0 in the shipped configuration)                  */
+    double  lbu[ADMPC_QUAD_NU], ubu[ADMPC_QUAD_NU];       /* hard input box (0, 1)                                 */
+    double  mass;                 /* quad_3d.py:57  1.0 kg                                                         */
+    double  J[3];                 /* quad_3d.py:56  diag inertia (.03, .03, .06)                                   */
+    double  max_thrust;           /* quad_3d.py:40  20 N per rotor                                                 */
+    double  x_f[4], y_f[4], z_l_tau[4];                   /* rotor arms and yaw-torque coefficients (:62-74)       */
+    double  g;                    /* 9.81                                                                          */
+    double  ipm_mu0, ipm_thr0, ipm_tol_comp, ipm_tol_res; /* interior point: start and stop levels                 */
+} AdmpcQuadConfig;
+
+typedef struct AdmpcQuadSolver AdmpcQuadSolver;
+
+/* The shipped problem: my_quad_acados_ocp.json (N = 10, tf = 1 s, W = diag(10,10,10, 0,.1,.1,.1, .05 x 6, .1 x 4), W_e = 0,
+ * 0 <= u <= 1) and the vehicle of quad_3d.py ('x' configuration). */
+void admpc_quad_default_config(AdmpcQuadConfig* cfg);
+
+int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** out);
+void admpc_quad_destroy(AdmpcQuadSolver* s);
+
+/* One SQP-RTI step for B instances.
+ *   x0 [B][13]   yref [B][N][17] (state and input references)   yref_e [B][13]
+ *   xbar [B][N+1][13], ubar [B][N][4]  in: linearisation point, out: the iterate after the full step
+ *   cost [B], status [B], iters [B]  (each may be NULL) */
+int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e,
+                           double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream);
+
+/* Test hook: the shooting step alone -- phi [B][N][13], A [B][N][13][13], Bm [B][N][13][4] of every interval. */
+int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, double* phi, double* A, double* Bm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

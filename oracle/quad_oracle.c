@@ -1,0 +1,303 @@
+/*
+ * quad_oracle.c -- CPU restatement (plain C, fp64) of one acados SQP-RTI step of the reference's quadrotor MPC.
+ * TEST INFRASTRUCTURE ONLY: loaded by tests/ (and nothing else); the product path is ad_mpc_amd/csrc/admpc_quad.hip.
+ *
+ * What it follows (data_driven_mpc/ros_gp_mpc):
+ *   model        src/quad_mpc/quad_3d_optimizer.py:341-393 (p, q, v, w dynamics; no drag in the shipped generated code),
+ *                src/utils/utils.py:323-338 (q_to_rot_mat), :392-410 (skew_symmetric), src/quad_mpc/quad_3d.py:40-74 (vehicle)
+ *   formulation  src/quad_mpc/quad_3d_optimizer.py:150-207 + acados_models/my_quad_acados_ocp.json (LINEAR_LS, W scaled by Ts,
+ *                hard input box, x0 fixed, ERK4 with one step per interval, Gauss-Newton, full condensing, RTI)
+ *   QP           the condensed QP is strictly convex in du (R > 0): any method reaching its minimiser is equivalent; here a Mehrotra
+ *                predictor-corrector on the box-constrained dense QP (HPIPM's own algorithm is not in the reference tree).
+ * Pins: the model against the reference's compiled CasADi code (oracle/_ref/libquad_ref.so, tests/golden/quad_shooting.json);
+ * the QP solution against an independent bounded solve of the condensed QP built from the reference's VDE (tests/test_quad_oracle.py).
+ */
+#include "../include/admpc_quad.h"
+#include <math.h>
+#include <string.h>
+
+#define NX ADMPC_QUAD_NX
+#define NU ADMPC_QUAD_NU
+#define NMAX (ADMPC_QUAD_MAX_N * ADMPC_QUAD_NU)
+typedef double real;
+typedef AdmpcQuadConfig Cfg;
+
+/* f(x, u) and its directional derivative df = Jx sx + Ju su (forward mode, by hand) */
+static void quad_f_tan(const Cfg* c, const real* x, const real* u, const real* sx, const real* su, real* f, real* df)
+{
+    const real qw = x[3], qx = x[4], qy = x[5], qz = x[6], r0 = x[10], r1 = x[11], r2 = x[12];
+    const real sw = sx[3], sxx = sx[4], sy = sx[5], sz = sx[6], t0 = sx[10], t1 = sx[11], t2 = sx[12];
+    for (int i = 0; i < 3; ++i) { f[i] = x[7 + i]; df[i] = sx[7 + i]; }                       /* :361 p' = v */
+    f[3] = 0.5 * (-r0 * qx - r1 * qy - r2 * qz);                                               /* :364 q' = 1/2 S(r) q, utils.py:401-404 */
+    f[4] = 0.5 * ( r0 * qw + r2 * qy - r1 * qz);
+    f[5] = 0.5 * ( r1 * qw - r2 * qx + r0 * qz);
+    f[6] = 0.5 * ( r2 * qw + r1 * qx - r0 * qy);
+    df[3] = 0.5 * (-t0 * qx - r0 * sxx - t1 * qy - r1 * sy - t2 * qz - r2 * sz);
+    df[4] = 0.5 * ( t0 * qw + r0 * sw + t2 * qy + r2 * sy - t1 * qz - r1 * sz);
+    df[5] = 0.5 * ( t1 * qw + r1 * sw - t2 * qx - r2 * sxx + t0 * qz + r0 * sz);
+    df[6] = 0.5 * ( t2 * qw + r2 * sw + t1 * qx + r1 * sxx - t0 * qy - r0 * sy);
+    const real a = c->max_thrust * (u[0] + u[1] + u[2] + u[3]) / c->mass;                     /* :372-374 */
+    const real da = c->max_thrust * (su[0] + su[1] + su[2] + su[3]) / c->mass;
+    const real c0 = 2 * (qx * qz + qw * qy), c1 = 2 * (qy * qz - qw * qx), c2 = 1 - 2 * (qx * qx + qy * qy);   /* third column of R(q) */
+    const real d0 = 2 * (sxx * qz + qx * sz + sw * qy + qw * sy), d1 = 2 * (sy * qz + qy * sz - sw * qx - qw * sxx),
+               d2 = -4 * (qx * sxx + qy * sy);
+    f[7] = c0 * a; f[8] = c1 * a; f[9] = c2 * a - c->g;                                        /* :376 v' = R(q) a_thrust - g */
+    df[7] = d0 * a + c0 * da; df[8] = d1 * a + c1 * da; df[9] = d2 * a + c2 * da;
+    real tx = 0, ty = 0, tz = 0, dtx = 0, dty = 0, dtz = 0;                                     /* :386-393 */
+    for (int i = 0; i < 4; ++i) {
+        tx += c->max_thrust * u[i] * c->y_f[i]; ty -= c->max_thrust * u[i] * c->x_f[i]; tz += c->max_thrust * u[i] * c->z_l_tau[i];
+        dtx += c->max_thrust * su[i] * c->y_f[i]; dty -= c->max_thrust * su[i] * c->x_f[i]; dtz += c->max_thrust * su[i] * c->z_l_tau[i];
+    }
+    f[10] = (tx + (c->J[1] - c->J[2]) * r1 * r2) / c->J[0];
+    f[11] = (ty + (c->J[2] - c->J[0]) * r2 * r0) / c->J[1];
+    f[12] = (tz + (c->J[0] - c->J[1]) * r0 * r1) / c->J[2];
+    df[10] = (dtx + (c->J[1] - c->J[2]) * (t1 * r2 + r1 * t2)) / c->J[0];
+    df[11] = (dty + (c->J[2] - c->J[0]) * (t2 * r0 + r2 * t0)) / c->J[1];
+    df[12] = (dtz + (c->J[0] - c->J[1]) * (t0 * r1 + r0 * t1)) / c->J[2];
+}
+
+/* classic RK4 (one step of length h) of the state and ONE sensitivity column: col < 13 -> d/dx_col, col >= 13 -> d/du_(col-13) */
+static void rk4_col(const Cfg* c, const real* x, const real* u, real h, int col, real* phi, real* scol)
+{
+    static const real cs[4] = { 0, 0.5, 0.5, 1.0 }, ws[4] = { 1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6 };
+    real kx[NX] = {0}, ks[NX] = {0}, ax[NX] = {0}, as[NX] = {0}, su[NU] = {0};
+    if (col >= NX) su[col - NX] = 1;
+    for (int s = 0; s < 4; ++s) {
+        real X[NX], S[NX], f[NX], df[NX];
+        for (int i = 0; i < NX; ++i) { X[i] = x[i] + cs[s] * h * kx[i]; S[i] = (col == i ? 1.0 : 0.0) + cs[s] * h * ks[i]; }
+        quad_f_tan(c, X, u, S, su, f, df);
+        for (int i = 0; i < NX; ++i) { kx[i] = f[i]; ks[i] = df[i]; ax[i] += ws[s] * f[i]; as[i] += ws[s] * df[i]; }
+    }
+    for (int i = 0; i < NX; ++i) { phi[i] = x[i] + h * ax[i]; scol[i] = (col == i ? 1.0 : 0.0) + h * as[i]; }
+}
+
+void quad_oracle_f(const Cfg* c, const double* x, const double* u, double* f)
+{
+    real z13[NX] = {0}, z4[NU] = {0}, df[NX];
+    quad_f_tan(c, x, u, z13, z4, f, df);
+}
+
+/* phi [13], A [13][13], B [13][4] (row-major) */
+void quad_oracle_rk4_sens(const Cfg* c, const double* x, const double* u, double h, double* phi, double* A, double* B)
+{
+    real col[NX];
+    for (int cc = 0; cc < NX + NU; ++cc) {
+        rk4_col(c, x, u, h, cc, phi, col);
+        for (int i = 0; i < NX; ++i) { if (cc < NX) A[i * NX + cc] = col[i]; else B[i * NU + (cc - NX)] = col[i]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* one RTI step of one instance                                                                                        */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { real A[ADMPC_QUAD_MAX_N][NX][NX], B[ADMPC_QUAD_MAX_N][NX][NU], b[ADMPC_QUAD_MAX_N][NX]; real H[NMAX][NMAX], g[NMAX]; } Work;
+
+static void condense(const Cfg* c, const real* x0, const real* yref, const real* yref_e, const real* xbar, const real* ubar, Work* w)
+{
+    const int N = c->N, n = N * NU;
+    real G[NX][NMAX], xh[NX];                     /* Gamma_k (13 x n), free response */
+    memset(G, 0, sizeof G); memset(w->H, 0, sizeof w->H);
+    for (int i = 0; i < NX; ++i) xh[i] = x0[i] - xbar[i];
+    for (int i = 0; i < n; ++i) w->g[i] = c->Ts * c->W[NX + i % NU] * (ubar[i] - yref[(i / NU) * ADMPC_QUAD_NY + NX + i % NU]);
+    for (int k = 0; k < N; ++k) {
+        real Gn[NX][NMAX], xn[NX];
+        for (int r = 0; r < NX; ++r) {
+            real a = w->b[k][r];
+            for (int cc = 0; cc < NX; ++cc) a += w->A[k][r][cc] * xh[cc];
+            xn[r] = a;
+            for (int i = 0; i < n; ++i) {
+                real s = 0;
+                if (i / NU == k) s = w->B[k][r][i % NU];
+                else if (i / NU < k) for (int cc = 0; cc < NX; ++cc) s += w->A[k][r][cc] * G[cc][i];
+                Gn[r][i] = s;
+            }
+        }
+        memcpy(G, Gn, sizeof G); memcpy(xh, xn, sizeof xh);
+        /* cost of stage k + 1: weight Ts W (stages < N) or W_e (terminal) on  xbar + xhat + Gamma du - ref */
+        const real* ref = k + 1 < N ? yref + (k + 1) * ADMPC_QUAD_NY : yref_e;
+        for (int cc = 0; cc < NX; ++cc) {
+            const real wq = k + 1 < N ? c->Ts * c->W[cc] : c->We[cc];
+            if (wq == 0) continue;
+            const real e = xbar[(k + 1) * NX + cc] + xh[cc] - ref[cc];
+            for (int i = 0; i < (k + 1) * NU; ++i) {
+                w->g[i] += G[cc][i] * wq * e;
+                for (int j = 0; j <= i; ++j) w->H[i][j] += G[cc][i] * wq * G[cc][j];
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) { w->H[i][i] += c->Ts * c->W[NX + i % NU]; for (int j = 0; j < i; ++j) w->H[j][i] = w->H[i][j]; }
+}
+
+/* in-place Cholesky M = L L' (lower) and solve M x = rhs; returns 0 on a non-positive pivot */
+static int chol(int n, real M[NMAX][NMAX])
+{
+    for (int j = 0; j < n; ++j) {
+        real d = M[j][j];
+        for (int k = 0; k < j; ++k) d -= M[j][k] * M[j][k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d); M[j][j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            real s = M[i][j];
+            for (int k = 0; k < j; ++k) s -= M[i][k] * M[j][k];
+            M[i][j] = s / d;
+        }
+    }
+    return 1;
+}
+static void chol_solve(int n, real L[NMAX][NMAX], real* x)
+{
+    for (int i = 0; i < n; ++i) { real s = x[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * x[k]; x[i] = s / L[i][i]; }
+    for (int i = n - 1; i >= 0; --i) { real s = x[i]; for (int k = i + 1; k < n; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+}
+
+/* Mehrotra predictor-corrector on  min 1/2 du'H du + g'du,  lo <= du <= hi.  Returns 0 ok, 4 failure. */
+static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const real* lo, const real* hi, real* du, int* iters)
+{
+    real tl[NMAX], tu[NMAX], ll[NMAX], lu[NMAX];
+    for (int i = 0; i < n; ++i) {
+        du[i] = 0;
+        tl[i] = fmax(du[i] - lo[i], c->ipm_thr0); tu[i] = fmax(hi[i] - du[i], c->ipm_thr0);
+        ll[i] = c->ipm_mu0 / tl[i]; lu[i] = c->ipm_mu0 / tu[i];
+    }
+    real alpha_prev = 1;
+    int it = 0;
+    for (;; ++it) {
+        real rs[NMAX], rl[NMAX], ru[NMAX], mu = 0, cmax = 0, rmax = 0;
+        for (int i = 0; i < n; ++i) {
+            real s = g[i] - ll[i] + lu[i];
+            for (int j = 0; j < n; ++j) s += H[i][j] * du[j];
+            rs[i] = s; rl[i] = du[i] - lo[i] - tl[i]; ru[i] = hi[i] - du[i] - tu[i];
+            mu += tl[i] * ll[i] + tu[i] * lu[i];
+            cmax = fmax(cmax, fmax(tl[i] * ll[i], tu[i] * lu[i]));
+            rmax = fmax(rmax, fmax(fabs(rs[i]), fmax(fabs(rl[i]), fabs(ru[i]))));
+        }
+        mu /= 2 * n;
+        if (!(mu == mu) || !(rmax == rmax)) { *iters = it; return 4; }
+        if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
+        real M[NMAX][NMAX];
+        real Dl[NMAX], Du[NMAX], da[NMAX], dtl[NMAX], dtu[NMAX], dll[NMAX], dlu[NMAX];
+        for (int i = 0; i < n; ++i) {
+            Dl[i] = ll[i] / tl[i]; Du[i] = lu[i] / tu[i];
+            for (int j = 0; j <= i; ++j) M[i][j] = H[i][j];
+            M[i][i] += Dl[i] + Du[i];
+        }
+        if (!chol(n, M)) { *iters = it; return 4; }
+        /* predictor (sigma = 0) */
+        for (int i = 0; i < n; ++i) da[i] = -rs[i] + (-ll[i] - Dl[i] * rl[i]) - (-lu[i] - Du[i] * ru[i]);
+        chol_solve(n, M, da);
+        real amax = 1, muaff = 0;
+        for (int i = 0; i < n; ++i) {
+            dtl[i] = da[i] + rl[i]; dtu[i] = -da[i] + ru[i];
+            dll[i] = -ll[i] - Dl[i] * dtl[i]; dlu[i] = -lu[i] - Du[i] * dtu[i];
+            if (dtl[i] < 0) amax = fmin(amax, -tl[i] / dtl[i]);
+            if (dtu[i] < 0) amax = fmin(amax, -tu[i] / dtu[i]);
+            if (dll[i] < 0) amax = fmin(amax, -ll[i] / dll[i]);
+            if (dlu[i] < 0) amax = fmin(amax, -lu[i] / dlu[i]);
+        }
+        for (int i = 0; i < n; ++i) muaff += (tl[i] + amax * dtl[i]) * (ll[i] + amax * dll[i]) + (tu[i] + amax * dtu[i]) * (lu[i] + amax * dlu[i]);
+        muaff /= 2 * n;
+        real sigma = muaff / mu; sigma = sigma * sigma * sigma;
+        if (alpha_prev < 0.05) sigma = 1;                                     /* blocked step: centre (ADMPC_IPM_BLOCKED_STEP of admpc.h) */
+        const real smu = sigma * mu;
+        /* corrector: complementarity target  sigma mu - dt_aff dlam_aff */
+        real d[NMAX], cl[NMAX], cu[NMAX];
+        for (int i = 0; i < n; ++i) {
+            cl[i] = (smu - dtl[i] * dll[i]) / tl[i]; cu[i] = (smu - dtu[i] * dlu[i]) / tu[i];
+            d[i] = -rs[i] + (cl[i] - ll[i] - Dl[i] * rl[i]) - (cu[i] - lu[i] - Du[i] * ru[i]);
+        }
+        chol_solve(n, M, d);
+        amax = 1;
+        for (int i = 0; i < n; ++i) {
+            dtl[i] = d[i] + rl[i]; dtu[i] = -d[i] + ru[i];
+            dll[i] = cl[i] - ll[i] - Dl[i] * dtl[i]; dlu[i] = cu[i] - lu[i] - Du[i] * dtu[i];
+            if (dtl[i] < 0) amax = fmin(amax, -tl[i] / dtl[i]);
+            if (dtu[i] < 0) amax = fmin(amax, -tu[i] / dtu[i]);
+            if (dll[i] < 0) amax = fmin(amax, -ll[i] / dll[i]);
+            if (dlu[i] < 0) amax = fmin(amax, -lu[i] / dlu[i]);
+        }
+        real tau = 1 - muaff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+        const real alpha = fmin(tau * amax, 1.0);
+        for (int i = 0; i < n; ++i) {
+            du[i] += alpha * d[i];
+            tl[i] = fmax(tl[i] + alpha * dtl[i], 1e-40); tu[i] = fmax(tu[i] + alpha * dtu[i], 1e-40);
+            ll[i] = fmax(ll[i] + alpha * dll[i], 1e-40); lu[i] = fmax(lu[i] + alpha * dlu[i], 1e-40);
+        }
+        alpha_prev = alpha;
+    }
+    *iters = it;
+    return 0;
+}
+
+static int rti_step(const Cfg* c, const real* x0, const real* yref, const real* yref_e, real* xbar, real* ubar, real* cost, int* iters,
+                    real* H_out, real* g_out)
+{
+    Work w;
+    const int N = c->N, n = N * NU;
+    for (int k = 0; k < N; ++k) {
+        real phi[NX];
+        quad_oracle_rk4_sens(c, xbar + k * NX, ubar + k * NU, c->Ts, phi, &w.A[k][0][0], &w.B[k][0][0]);
+        for (int i = 0; i < NX; ++i) w.b[k][i] = phi[i] - xbar[(k + 1) * NX + i];
+    }
+    condense(c, x0, yref, yref_e, xbar, ubar, &w);
+    if (H_out) for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) H_out[i * n + j] = w.H[i][j]; g_out[i] = w.g[i]; }
+    real lo[NMAX], hi[NMAX], du[NMAX];
+    for (int i = 0; i < n; ++i) { lo[i] = c->lbu[i % NU] - ubar[i]; hi[i] = c->ubu[i % NU] - ubar[i]; }
+    int st = box_qp(c, n, w.H, w.g, lo, hi, du, iters);
+    /* expand + full step */
+    real xn[(ADMPC_QUAD_MAX_N + 1) * NX], un[NMAX], dx[NX];
+    for (int i = 0; i < NX; ++i) { dx[i] = x0[i] - xbar[i]; xn[i] = xbar[i] + dx[i]; }
+    int bad = st != 0;
+    real J = 0;
+    for (int k = 0; k < N && !bad; ++k) {
+        real dn[NX];
+        for (int r = 0; r < NX; ++r) {
+            real a = w.b[k][r];
+            for (int cc = 0; cc < NX; ++cc) a += w.A[k][r][cc] * dx[cc];
+            for (int m = 0; m < NU; ++m) a += w.B[k][r][m] * du[k * NU + m];
+            dn[r] = a;
+        }
+        for (int m = 0; m < NU; ++m) { un[k * NU + m] = ubar[k * NU + m] + du[k * NU + m]; if (!(fabs(un[k * NU + m]) <= 1e300)) bad = 1; }
+        for (int r = 0; r < NX; ++r) { dx[r] = dn[r]; xn[(k + 1) * NX + r] = xbar[(k + 1) * NX + r] + dn[r]; if (!(fabs(xn[(k + 1) * NX + r]) <= 1e300)) bad = 1; }
+    }
+    if (bad) { *cost = INFINITY; return 4; }
+    for (int k = 0; k < N; ++k) {
+        for (int cc = 0; cc < NX; ++cc) { const real e = xn[k * NX + cc] - yref[k * ADMPC_QUAD_NY + cc]; J += 0.5 * c->Ts * c->W[cc] * e * e; }
+        for (int m = 0; m < NU; ++m) { const real e = un[k * NU + m] - yref[k * ADMPC_QUAD_NY + NX + m]; J += 0.5 * c->Ts * c->W[NX + m] * e * e; }
+    }
+    for (int cc = 0; cc < NX; ++cc) { const real e = xn[N * NX + cc] - yref_e[cc]; J += 0.5 * c->We[cc] * e * e; }
+    memcpy(xbar, xn, sizeof(real) * (N + 1) * NX); memcpy(ubar, un, sizeof(real) * n);
+    *cost = J;
+    return 0;
+}
+
+/* x, u in place; returns the number of instances with a non-zero status */
+int quad_oracle_solve_batch(const Cfg* c, int B, const double* x0, const double* yref, const double* yref_e,
+                            double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, int nthreads)
+{
+    const int N = c->N;
+    int nbad = 0;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : nbad) schedule(dynamic, 8)
+#endif
+    for (int b = 0; b < B; ++b) {
+        int it = 0; real J;
+        const int st = rti_step(c, x0 + (size_t)b * NX, yref + (size_t)b * N * ADMPC_QUAD_NY, yref_e + (size_t)b * NX,
+                                xbar + (size_t)b * (N + 1) * NX, ubar + (size_t)b * N * NU, &J, &it, 0, 0);
+        if (cost) cost[b] = J;
+        if (status) status[b] = st;
+        if (iters) iters[b] = it;
+        nbad += st != 0;
+    }
+    return nbad;
+}
+
+/* the condensed QP of one instance (tests): H [n][n], g [n]; xbar / ubar receive the step as in quad_oracle_solve_batch */
+int quad_oracle_qp_debug(const Cfg* c, const double* x0, const double* yref, const double* yref_e, double* xbar, double* ubar,
+                         double* H, double* g, int32_t* iters)
+{
+    int it = 0; real J;
+    const int st = rti_step(c, x0, yref, yref_e, xbar, ubar, &J, &it, H, g);
+    *iters = it;
+    return st;
+}

@@ -1,0 +1,95 @@
+"""Quadrotor model and RTI step of the CPU oracle, CPU only.
+Pins: (1) the model and its ERK4 sensitivities against golden vectors produced by the reference's own compiled CasADi code
+(oracle/make_golden_quad.py); (2) the condensed QP against an independent numpy condensing of the same linearisation and its
+solution against an exact active-set solver (scipy BVLS on the Cholesky-transformed QP) plus a KKT check."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ad_mpc_amd.quad_config import default_quad_config, QNX, QNU
+from ad_mpc_amd.quad_scenarios import random_quad_scenarios, hover_input
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quad_shooting.json")
+
+
+@pytest.fixture(scope="module")
+def qoracle():
+    from oracle.quad_oracle import QuadOracle
+    return QuadOracle()
+
+
+def test_model_and_rk4_against_the_reference_golden_vectors(qoracle):
+    cfg = default_quad_config()
+    cases = json.load(open(GOLDEN))["cases"]
+    assert len(cases) == 60
+    for c in cases:
+        x, u = np.array(c["x"]), np.array(c["u"])
+        assert np.abs(qoracle.f(cfg, x, u) - np.array(c["xdot"])).max() <= 1e-12 * max(1.0, np.abs(c["xdot"]).max())
+        phi, A, B = qoracle.rk4_sens(cfg, x, u, c["h"])
+        for got, ref in ((phi, c["phi"]), (A, c["A"]), (B, c["B"])):
+            ref = np.array(ref)
+            assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_hover_is_an_equilibrium(qoracle):
+    cfg = default_quad_config()
+    x = np.zeros(QNX); x[3] = 1.0
+    assert np.abs(qoracle.f(cfg, x, np.full(4, hover_input(cfg)))).max() <= 1e-14
+
+
+def _numpy_condense(cfg, qoracle, x0, yref, yref_e, xbar, ubar):
+    N, n = cfg.N, cfg.N * QNU
+    Qd = cfg.Ts * np.array(cfg.W[:QNX]); Rd = cfg.Ts * np.array(cfg.W[QNX:]); Qe = np.array(cfg.We[:])
+    G = np.zeros((QNX, n)); xh = x0 - xbar[0]
+    H = np.kron(np.eye(N), np.diag(Rd)); g = (np.tile(Rd, N) * (ubar - yref[:, QNX:]).reshape(-1)).copy()
+    for k in range(N):
+        phi, A, B = qoracle.rk4_sens(cfg, xbar[k], ubar[k], cfg.Ts)
+        G = A @ G; G[:, k * QNU:(k + 1) * QNU] = B
+        xh = A @ xh + (phi - xbar[k + 1])
+        Q = Qd if k + 1 < N else Qe
+        ref = yref[k + 1, :QNX] if k + 1 < N else yref_e
+        H += G.T @ (Q[:, None] * G); g += G.T @ (Q * (xbar[k + 1] + xh - ref))
+    return H, g
+
+
+def test_condensed_qp_and_its_minimiser(qoracle):
+    """H, g against an independent numpy condensing (matrix form); du against scipy's BVLS on the equivalent bounded least-squares
+    problem; KKT: stationarity with multipliers of the right sign, feasibility."""
+    from scipy.optimize import lsq_linear
+    cfg = default_quad_config()
+    s = random_quad_scenarios(24, cfg, seed=3)
+    nact = 0
+    for b in range(24):
+        d = qoracle.qp_debug(cfg, s["x0"][b], s["yref"][b], s["yref_e"][b], s["xbar"][b], s["ubar"][b])
+        assert d["status"] == 0 and d["iters"] < cfg.ipm_iter_max
+        H, g = _numpy_condense(cfg, qoracle, s["x0"][b], s["yref"][b], s["yref_e"][b], s["xbar"][b], s["ubar"][b])
+        assert np.abs(d["H"] - H).max() <= 1e-11 * np.abs(H).max() and np.abs(d["g"] - g).max() <= 1e-11 * max(1.0, np.abs(g).max())
+        du = (d["u"] - s["ubar"][b]).reshape(-1)
+        lo = np.tile(np.array(cfg.lbu[:]), cfg.N) - s["ubar"][b].reshape(-1); hi = np.tile(np.array(cfg.ubu[:]), cfg.N) - s["ubar"][b].reshape(-1)
+        Lc = np.linalg.cholesky(H)
+        r = lsq_linear(Lc.T, -np.linalg.solve(Lc, g), bounds=(lo, hi), method="bvls", tol=1e-14, max_iter=500)
+        f = lambda v: 0.5 * v @ H @ v + g @ v
+        assert np.abs(du - r.x).max() <= 1e-5 and f(du) - f(r.x) <= 1e-11 * abs(f(r.x)), (np.abs(du - r.x).max(), f(du) - f(r.x))   # (flat directions: cond(H) ~ 2e5)
+        grad = H @ du + g                                        # KKT of the box QP
+        atl, atu = du - lo <= 1e-7, hi - du <= 1e-7
+        nact += int(atl.sum() + atu.sum())
+        assert (du >= lo - 1e-9).all() and (du <= hi + 1e-9).all()
+        assert np.abs(grad[~atl & ~atu]).max(initial=0) <= 1e-5 and (grad[atl] >= -1e-5).all() and (grad[atu] <= 1e-5).all()
+    assert nact > 20                                             # the batch really has active input bounds
+
+
+def test_batch_solve_statuses_and_failure(qoracle):
+    cfg = default_quad_config()
+    s = random_quad_scenarios(32, cfg, seed=11)
+    s["x0"][5, 2] = np.nan
+    x, u, cost, st, it = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=4)
+    assert st[5] == 4 and np.isinf(cost[5]) and (x[5] == s["xbar"][5]).all() and (u[5] == s["ubar"][5]).all()
+    ok = np.arange(32) != 5
+    assert (st[ok] == 0).all() and np.isfinite(cost[ok]).all() and it[ok].max() < cfg.ipm_iter_max
+    assert (u[ok] >= -1e-9).all() and (u[ok] <= 1 + 1e-9).all()
+    np.testing.assert_allclose(x[ok][:, 0], s["x0"][ok], atol=1e-15)        # x_0 pinned to the measured state
+    # a second step from the new iterate lowers the cost (SQP-RTI converging on the tracking problem)
+    x2, u2, cost2, st2, _ = qoracle.solve_batch(cfg, s["x0"][ok], s["yref"][ok], s["yref_e"][ok], x[ok], u[ok], nthreads=4)
+    assert (st2 == 0).all() and (cost2 <= cost[ok] * (1 + 1e-9) + 1e-12).mean() >= 0.9
