@@ -7,6 +7,7 @@ import ctypes as C
 import os
 
 from .config import AdmpcConfig
+from .quad_config import AdmpcQuadConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmpc.so")
@@ -15,6 +16,7 @@ EXPORTS = (
     "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_ex", "admpc_solve_batch_f32", "admpc_shoot_batch",
     "admpc_argmin", "admpc_argmin_pairs", "admpc_argmin_global", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_actuation_batch", "admpc_resample_vel_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
 )
+QUAD_EXPORTS = ("admpc_quad_default_config", "admpc_quad_create", "admpc_quad_destroy", "admpc_quad_solve_batch", "admpc_quad_shoot_batch")   # include/admpc_quad.h
 
 _lib = None
 
@@ -54,6 +56,12 @@ def load():
     L.admpc_resample_vel_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp, vp]; L.admpc_resample_vel_batch.restype = C.c_int
     L.admpc_waypoints_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [dp] * 13 + [vp]
     L.admpc_waypoints_batch.restype = C.c_int
+    qp = C.POINTER(AdmpcQuadConfig)
+    L.admpc_quad_default_config.argtypes = [qp]; L.admpc_quad_default_config.restype = None
+    L.admpc_quad_create.argtypes = [qp, C.c_int, C.POINTER(C.c_void_p)]; L.admpc_quad_create.restype = C.c_int
+    L.admpc_quad_destroy.argtypes = [C.c_void_p]; L.admpc_quad_destroy.restype = None
+    L.admpc_quad_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, vp]; L.admpc_quad_solve_batch.restype = C.c_int
+    L.admpc_quad_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, vp]; L.admpc_quad_shoot_batch.restype = C.c_int
     L.admpc_last_error.restype = C.c_char_p
     L.admpc_version.restype = C.c_char_p
     _lib = L

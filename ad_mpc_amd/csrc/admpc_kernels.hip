@@ -1673,6 +1673,8 @@ extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, 
 extern "C" {
 
 const char* admpc_last_error(void) { return g_err.c_str(); }
+// for the other translation units of the library (admpc_quad.hip)
+__attribute__((visibility("hidden"))) int admpc_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 const char* admpc_version(void) { return "admpc-mi355x 0.1 (gfx950)"; }
 
 int admpc_default_config(AdmpcConfig* c, int N, double Ts)

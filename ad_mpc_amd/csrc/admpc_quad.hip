@@ -1,0 +1,443 @@
+// admpc_quad.hip -- the second vehicle model behind the engine: one SQP-RTI step of the reference's quadrotor MPC
+// (src/quad_mpc/quad_3d_optimizer.py:150-207 formulation, :341-393 dynamics; nx = 13, nu = 4, N = 10) for a batch of instances.
+//
+// One workgroup of one wavefront per instance (grid-stride over instances); the whole step lives in LDS and registers:
+//   1. shooting: 17 N tasks (stage, sensitivity column) spread over the 64 lanes -- each integrates the state and ONE column of
+//      [S_x S_u] through classic RK4 with the model's forward-mode tangent (the model is polynomial: no Jacobian matrix is formed);
+//   2. condensing: lane i <-> input i = (stage, rotor) carries column i of Gamma_k = d x_k / d u through the stages; the tracking
+//      terms Gamma' Q Gamma accumulate into the dense Hessian in LDS (the reference solves the same condensed QP: FULL_CONDENSING_HPIPM);
+//   3. box-constrained dense QP (N nu <= 64 inputs, one per lane): Mehrotra predictor-corrector, Cholesky with row i on lane i;
+//   4. expansion of the states, full step, cost, status.
+// Arithmetic follows oracle/quad_oracle.c operation by operation where the order matters (Cholesky, forward substitution).
+// This path is built for coverage and parity, not tuned: the quadrotor problem is not a BASELINE config.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include "../../include/admpc.h"
+#include "../../include/admpc_quad.h"
+
+extern "C" int admpc_set_error(int code, const char* msg);          // admpc_kernels.hip: thread-local message behind admpc_last_error()
+
+namespace {
+
+constexpr int QX = ADMPC_QUAD_NX, QU = ADMPC_QUAD_NU, QY = ADMPC_QUAD_NY;
+typedef AdmpcQuadConfig Cfg;
+
+// f(x, u) and df = Jx sx + Ju su   (oracle/quad_oracle.c:quad_f_tan, same expressions)
+__device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const double* x, const double* u, const double* sx, const double* su,
+                                           double* f, double* df)
+{
+    const double qw = x[3], qx = x[4], qy = x[5], qz = x[6], r0 = x[10], r1 = x[11], r2 = x[12];
+    const double sw = sx[3], sxx = sx[4], sy = sx[5], sz = sx[6], t0 = sx[10], t1 = sx[11], t2 = sx[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { f[i] = x[7 + i]; df[i] = sx[7 + i]; }
+    f[3] = 0.5 * (-r0 * qx - r1 * qy - r2 * qz);
+    f[4] = 0.5 * ( r0 * qw + r2 * qy - r1 * qz);
+    f[5] = 0.5 * ( r1 * qw - r2 * qx + r0 * qz);
+    f[6] = 0.5 * ( r2 * qw + r1 * qx - r0 * qy);
+    df[3] = 0.5 * (-t0 * qx - r0 * sxx - t1 * qy - r1 * sy - t2 * qz - r2 * sz);
+    df[4] = 0.5 * ( t0 * qw + r0 * sw + t2 * qy + r2 * sy - t1 * qz - r1 * sz);
+    df[5] = 0.5 * ( t1 * qw + r1 * sw - t2 * qx - r2 * sxx + t0 * qz + r0 * sz);
+    df[6] = 0.5 * ( t2 * qw + r2 * sw + t1 * qx + r1 * sxx - t0 * qy - r0 * sy);
+    const double a = c->max_thrust * (u[0] + u[1] + u[2] + u[3]) / c->mass;
+    const double da = c->max_thrust * (su[0] + su[1] + su[2] + su[3]) / c->mass;
+    const double c0 = 2 * (qx * qz + qw * qy), c1 = 2 * (qy * qz - qw * qx), c2 = 1 - 2 * (qx * qx + qy * qy);
+    const double d0 = 2 * (sxx * qz + qx * sz + sw * qy + qw * sy), d1 = 2 * (sy * qz + qy * sz - sw * qx - qw * sxx),
+                 d2 = -4 * (qx * sxx + qy * sy);
+    f[7] = c0 * a; f[8] = c1 * a; f[9] = c2 * a - c->g;
+    df[7] = d0 * a + c0 * da; df[8] = d1 * a + c1 * da; df[9] = d2 * a + c2 * da;
+    double tx = 0, ty = 0, tz = 0, dtx = 0, dty = 0, dtz = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tx += c->max_thrust * u[i] * c->y_f[i]; ty -= c->max_thrust * u[i] * c->x_f[i]; tz += c->max_thrust * u[i] * c->z_l_tau[i];
+        dtx += c->max_thrust * su[i] * c->y_f[i]; dty -= c->max_thrust * su[i] * c->x_f[i]; dtz += c->max_thrust * su[i] * c->z_l_tau[i];
+    }
+    f[10] = (tx + (c->J[1] - c->J[2]) * r1 * r2) / c->J[0];
+    f[11] = (ty + (c->J[2] - c->J[0]) * r2 * r0) / c->J[1];
+    f[12] = (tz + (c->J[0] - c->J[1]) * r0 * r1) / c->J[2];
+    df[10] = (dtx + (c->J[1] - c->J[2]) * (t1 * r2 + r1 * t2)) / c->J[0];
+    df[11] = (dty + (c->J[2] - c->J[0]) * (t2 * r0 + r2 * t0)) / c->J[1];
+    df[12] = (dtz + (c->J[0] - c->J[1]) * (t0 * r1 + r0 * t1)) / c->J[2];
+}
+
+// classic RK4, one step of length h: the state and ONE sensitivity column (col < 13: d/dx_col, else d/du_(col-13))
+__device__ __forceinline__ void rk4_col(const Cfg* __restrict__ c, const double* x, const double* u, double h, int col, double* phi, double* scol)
+{
+    const double cs[4] = { 0, 0.5, 0.5, 1.0 }, ws[4] = { 1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6 };
+    double kx[QX], ks[QX], ax[QX], as[QX], su[QU];
+#pragma unroll
+    for (int i = 0; i < QX; ++i) { kx[i] = 0; ks[i] = 0; ax[i] = 0; as[i] = 0; }
+#pragma unroll
+    for (int m = 0; m < QU; ++m) su[m] = col == QX + m ? 1.0 : 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        double X[QX], S[QX], f[QX], df[QX];
+#pragma unroll
+        for (int i = 0; i < QX; ++i) { X[i] = x[i] + cs[s] * h * kx[i]; S[i] = (col == i ? 1.0 : 0.0) + cs[s] * h * ks[i]; }
+        quad_f_tan(c, X, u, S, su, f, df);
+#pragma unroll
+        for (int i = 0; i < QX; ++i) { kx[i] = f[i]; ks[i] = df[i]; ax[i] += ws[s] * f[i]; as[i] += ws[s] * df[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < QX; ++i) { phi[i] = x[i] + h * ax[i]; scol[i] = (col == i ? 1.0 : 0.0) + h * as[i]; }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {         // NaN-propagating
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = (w > v || w != w) ? w : v; }
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+// LDS layout (doubles): A [N][13][13] | B [N][13][4] | b [N][13] | H [n][n+1] | M [n][n+1] | gam [13][64] | vec [64] | xnew [(N+1)*13]
+struct Lds {
+    double *A, *B, *b, *H, *M, *gam, *vec, *xnew;
+    int ld;
+    __device__ Lds(double* p, int N) {
+        const int n = N * QU; ld = n + 1;
+        A = p; B = A + N * QX * QX; b = B + N * QX * QU; H = b + N * QX; M = H + n * ld; gam = M + n * ld; vec = gam + QX * 64; xnew = vec + 64;
+    }
+};
+__host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + 2 * n * (n + 1) + QX * 64 + 64 + (N + 1) * QX; }
+
+__device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const Lds& L, int lane, double* phi_out)
+{
+    const int N = c->N;
+    for (int t = lane; t < N * (QX + QU); t += 64) {
+        const int k = t / (QX + QU), col = t - k * (QX + QU);
+        double x[QX], u[QU], phi[QX], sc[QX];
+#pragma unroll
+        for (int i = 0; i < QX; ++i) x[i] = xb[k * QX + i];
+#pragma unroll
+        for (int m = 0; m < QU; ++m) u[m] = ub[k * QU + m];
+        rk4_col(c, x, u, c->Ts, col, phi, sc);
+#pragma unroll
+        for (int i = 0; i < QX; ++i) {
+            if (col < QX) L.A[(k * QX + i) * QX + col] = sc[i]; else L.B[(k * QX + i) * QU + (col - QX)] = sc[i];
+            if (col == 0) { L.b[k * QX + i] = phi[i] - xb[(k + 1) * QX + i]; if (phi_out) phi_out[k * QX + i] = phi[i]; }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void admpc_quad_shoot_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ xbarg, const double* __restrict__ ubarg,
+                                                             double* __restrict__ phig, double* __restrict__ Ag, double* __restrict__ Bg)
+{
+    extern __shared__ double lds_raw[];
+    const int N = c->N, lane = threadIdx.x;
+    Lds L(lds_raw, N);
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        shoot_instance(c, xbarg + (size_t)inst * (N + 1) * QX, ubarg + (size_t)inst * N * QU, L, lane, phig + (size_t)inst * N * QX);
+        for (int i = lane; i < N * QX * QX; i += 64) Ag[(size_t)inst * N * QX * QX + i] = L.A[i];
+        for (int i = lane; i < N * QX * QU; i += 64) Bg[(size_t)inst * N * QX * QU + i] = L.B[i];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                             const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                             double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg)
+{
+    extern __shared__ double lds_raw[];
+    const int N = c->N, n = N * QU, lane = threadIdx.x;
+    Lds L(lds_raw, N);
+    const int ld = L.ld;
+    const bool act = lane < n;
+    const int li = act ? lane : 0, ji = li / QU, mi = li - ji * QU;
+    const double Ts = c->Ts;
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        double* xb = xbarg + (size_t)inst * (N + 1) * QX;
+        double* ub = ubarg + (size_t)inst * N * QU;
+        const double* yr = yrefg + (size_t)inst * N * QY;
+        const double* ye = yrefeg + (size_t)inst * QX;
+        const double* x0 = x0g + (size_t)inst * QX;
+        // ---- 1. shooting
+        shoot_instance(c, xb, ub, L, lane, nullptr);
+        // ---- 2. condensing (oracle: condense)
+        for (int j = 0; j <= li; ++j) if (act) L.H[li * ld + j] = 0.0;
+        double g[QX], xh[QX];
+#pragma unroll
+        for (int i = 0; i < QX; ++i) { g[i] = 0.0; xh[i] = x0[i] - xb[i]; }
+        const double ubar_i = ub[li];
+        double grad = Ts * c->W[QX + mi] * (ubar_i - yr[ji * QY + QX + mi]);
+        __syncthreads();
+        for (int k = 0; k < N; ++k) {
+            double gn[QX], xn[QX];
+#pragma unroll
+            for (int r = 0; r < QX; ++r) {
+                double a = L.b[k * QX + r], s = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < QX; ++cc) { const double ark = L.A[(k * QX + r) * QX + cc]; a += ark * xh[cc]; s += ark * g[cc]; }
+                xn[r] = a;
+                gn[r] = ji == k ? L.B[(k * QX + r) * QU + mi] : (ji < k ? s : 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; L.gam[r * 64 + lane] = act ? gn[r] : 0.0; }
+            __syncthreads();
+            const double* ref = k + 1 < N ? yr + (k + 1) * QY : ye;
+            const int lim = (k + 1) * QU;                                   // inputs of stages <= k
+            double wg[QX];
+#pragma unroll
+            for (int cc = 0; cc < QX; ++cc) {
+                const double wq = k + 1 < N ? Ts * c->W[cc] : c->We[cc];
+                wg[cc] = g[cc] * wq;
+                if (wq != 0.0) grad += wg[cc] * (xb[(k + 1) * QX + cc] + xh[cc] - ref[cc]);
+            }
+            if (act && li < lim) {
+                for (int j = 0; j <= li; ++j) {
+                    double s = L.H[li * ld + j];
+#pragma unroll
+                    for (int cc = 0; cc < QX; ++cc) s += wg[cc] * L.gam[cc * 64 + j];
+                    L.H[li * ld + j] = s;
+                }
+            }
+            __syncthreads();
+        }
+        if (act) L.H[li * ld + li] += Ts * c->W[QX + mi];
+        __syncthreads();
+        if (act) for (int j = 0; j < li; ++j) L.H[j * ld + li] = L.H[li * ld + j];
+        __syncthreads();
+        // ---- 3. box QP (oracle: box_qp)
+        const double lo = c->lbu[mi] - ubar_i, hi = c->ubu[mi] - ubar_i;
+        double du = 0.0;
+        double tl = act ? fmax(du - lo, c->ipm_thr0) : 1.0, tu = act ? fmax(hi - du, c->ipm_thr0) : 1.0;
+        double ll = act ? c->ipm_mu0 / tl : 0.0, lu = act ? c->ipm_mu0 / tu : 0.0;
+        double alpha_prev = 1.0;
+        int it = 0, st = 0;
+        for (;; ++it) {
+            L.vec[lane] = du;
+            __syncthreads();
+            double rs = grad - ll + lu;
+            if (act) for (int j = 0; j < n; ++j) rs += L.H[li * ld + j] * L.vec[j];
+            const double rl = du - lo - tl, ru = hi - du - tu;
+            const double mu = wave_sum(act ? tl * ll + tu * lu : 0.0) / (2.0 * n);
+            const double cmax = wave_max(act ? fmax(tl * ll, tu * lu) : 0.0);
+            const double rmax = wave_max(act ? fmax(fabs(rs), fmax(fabs(rl), fabs(ru))) : 0.0);
+            __syncthreads();
+            if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
+            if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
+            const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
+            if (act) { for (int j = 0; j <= li; ++j) L.M[li * ld + j] = L.H[li * ld + j]; L.M[li * ld + li] += Dl + Du; }
+            __syncthreads();
+            // Cholesky M = L L' (lower), row i on lane i, columns left to right (oracle: chol)
+            bool posdef = true;
+            for (int j = 0; j < n; ++j) {
+                double s = 0.0;
+                if (act && li >= j) { s = L.M[li * ld + j]; for (int k2 = 0; k2 < j; ++k2) s -= L.M[li * ld + k2] * L.M[j * ld + k2]; }
+                const double dj = __shfl(s, j);
+                if (!(dj > 0.0)) { posdef = false; break; }
+                const double dsq = sqrt(dj);
+                __syncthreads();
+                if (act && li == j) L.M[j * ld + j] = dsq;
+                if (act && li > j) L.M[li * ld + j] = s / dsq;
+                __syncthreads();
+            }
+            if (!posdef) { st = 4; break; }
+            // two solves with the factor: forward by columns (same subtraction order as the oracle's rows), backward by columns
+            auto solve = [&](double rhs) -> double {
+                double r = rhs;
+                for (int k2 = 0; k2 < n; ++k2) {
+                    const double xk = __shfl(r, k2) / L.M[k2 * ld + k2];
+                    if (lane == k2) r = xk;
+                    if (act && li > k2) r -= L.M[li * ld + k2] * xk;
+                }
+                for (int k2 = n - 1; k2 >= 0; --k2) {
+                    const double xk = __shfl(r, k2) / L.M[k2 * ld + k2];
+                    if (lane == k2) r = xk;
+                    if (act && li < k2) r -= L.M[k2 * ld + li] * xk;
+                }
+                return r;
+            };
+            const double da = solve(act ? -rs + (-ll - Dl * rl) - (-lu - Du * ru) : 0.0);
+            double dtl = da + rl, dtu = -da + ru;
+            double dll = -ll - Dl * dtl, dlu = -lu - Du * dtu;
+            auto ratio = [&]() -> double {
+                double a = 1.0;
+                if (act) {
+                    if (dtl < 0) a = fmin(a, -tl / dtl);
+                    if (dtu < 0) a = fmin(a, -tu / dtu);
+                    if (dll < 0) a = fmin(a, -ll / dll);
+                    if (dlu < 0) a = fmin(a, -lu / dlu);
+                }
+                return wave_min(a);
+            };
+            double amax = ratio();
+            const double muaff = wave_sum(act ? (tl + amax * dtl) * (ll + amax * dll) + (tu + amax * dtu) * (lu + amax * dlu) : 0.0) / (2.0 * n);
+            double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+            if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;
+            const double smu = sigma * mu;
+            const double cl = act ? (smu - dtl * dll) / tl : 0.0, cu = act ? (smu - dtu * dlu) / tu : 0.0;
+            const double d = solve(act ? -rs + (cl - ll - Dl * rl) - (cu - lu - Du * ru) : 0.0);
+            dtl = d + rl; dtu = -d + ru;
+            dll = cl - ll - Dl * dtl; dlu = cu - lu - Du * dtu;
+            amax = ratio();
+            double tau = 1.0 - muaff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+            const double alpha = fmin(tau * amax, 1.0);
+            if (act) {
+                du += alpha * d;
+                tl = fmax(tl + alpha * dtl, 1e-40); tu = fmax(tu + alpha * dtu, 1e-40);
+                ll = fmax(ll + alpha * dll, 1e-40); lu = fmax(lu + alpha * dlu, 1e-40);
+            }
+            alpha_prev = alpha;
+            __syncthreads();
+        }
+        // ---- 4. expansion, full step, cost (oracle: rti_step)
+        __syncthreads();
+        L.vec[lane] = act ? du : 0.0;
+        if (lane < QX) L.xnew[lane] = xb[lane] + (x0[lane] - xb[lane]);
+        __syncthreads();
+        bool bad = st != 0;
+        const double un = ubar_i + du;
+        if (act && !(fabs(un) <= 1e300)) bad = true;
+        double dx = lane < QX ? x0[lane] - xb[lane] : 0.0;
+        double J = 0.0;
+        if (act) { const double e = un - yr[ji * QY + QX + mi]; J += 0.5 * Ts * c->W[QX + mi] * e * e; }
+        for (int k = 0; k < N; ++k) {
+            L.gam[lane] = dx;                                        // dx_k of all components (lanes < 13)
+            __syncthreads();
+            double dn = 0.0;
+            if (lane < QX) {
+                dn = L.b[k * QX + lane];
+                for (int cc = 0; cc < QX; ++cc) dn += L.A[(k * QX + lane) * QX + cc] * L.gam[cc];
+                for (int m = 0; m < QU; ++m) dn += L.B[(k * QX + lane) * QU + m] * L.vec[k * QU + m];
+                const double xv = xb[(k + 1) * QX + lane] + dn;
+                L.xnew[(k + 1) * QX + lane] = xv;
+                if (!(fabs(xv) <= 1e300)) bad = true;
+            }
+            __syncthreads();
+            dx = dn;
+        }
+        for (int i = lane; i < (N + 1) * QX; i += 64) {
+            const int k = i / QX, cc = i - k * QX;
+            const double e = L.xnew[i] - (k < N ? yr[k * QY + cc] : ye[cc]);
+            J += 0.5 * (k < N ? Ts * c->W[cc] : c->We[cc]) * e * e;
+        }
+        bad = __any(bad) != 0;
+        J = wave_sum(J);
+        if (!bad) {
+            for (int i = lane; i < (N + 1) * QX; i += 64) xb[i] = L.xnew[i];
+            if (act) ub[li] = un;
+        }
+        if (lane == 0) {
+            if (costg) costg[inst] = bad ? INFINITY : J;
+            if (statusg) statusg[inst] = bad ? 4 : 0;
+            if (itersg) itersg[inst] = it;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+struct AdmpcQuadSolver {
+    AdmpcQuadConfig cfg;
+    AdmpcQuadConfig* d_cfg;
+    int device, num_cu, lds_bytes;
+};
+
+namespace {
+struct QGuard {
+    int prev; bool switched, good;
+    explicit QGuard(int dev) : prev(-1), switched(false), good(true) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { good = hipSetDevice(dev) == hipSuccess; switched = good; }
+    }
+    ~QGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
+}
+
+extern "C" {
+
+void admpc_quad_default_config(AdmpcQuadConfig* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->N = 10; c->ipm_iter_max = 50; c->Ts = 0.1;
+    const double w[QY] = { 10, 10, 10, 0, 0.1, 0.1, 0.1, 0.05, 0.05, 0.05, 0.05, 0.05, 0.05, 0.1, 0.1, 0.1, 0.1 };
+    for (int i = 0; i < QY; ++i) c->W[i] = w[i];
+    for (int m = 0; m < QU; ++m) { c->lbu[m] = 0.0; c->ubu[m] = 1.0; }
+    c->mass = 1.0; c->J[0] = 0.03; c->J[1] = 0.03; c->J[2] = 0.06; c->max_thrust = 20.0; c->g = 9.81;
+    const double h = cos(M_PI / 4) * (0.47 / 2);
+    const double xf[4] = { h, -h, -h, h }, yf[4] = { -h, -h, h, h }, zt[4] = { -0.013, 0.013, -0.013, 0.013 };
+    for (int i = 0; i < 4; ++i) { c->x_f[i] = xf[i]; c->y_f[i] = yf[i]; c->z_l_tau[i] = zt[i]; }
+    c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9;
+}
+
+int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** out)
+{
+    if (!cfg || !out) return admpc_set_error(ADMPC_EINVAL, "admpc_quad_create: null argument");
+    if (cfg->N < 2 || cfg->N > ADMPC_QUAD_MAX_N) return admpc_set_error(ADMPC_EINVAL, "quad: N must be in [2, 16]");
+    if (!(cfg->Ts > 0) || !(cfg->mass > 0) || !(cfg->J[0] > 0 && cfg->J[1] > 0 && cfg->J[2] > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: Ts, mass, J must be positive");
+    for (int m = 0; m < QU; ++m) {
+        if (!(cfg->W[QX + m] > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: input weights must be positive (strict convexity)");
+        if (!(cfg->lbu[m] < cfg->ubu[m])) return admpc_set_error(ADMPC_EINVAL, "quad: lbu < ubu required");
+    }
+    if (cfg->ipm_iter_max < 1 || !(cfg->ipm_mu0 > 0) || !(cfg->ipm_thr0 > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: bad interior-point parameters");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return admpc_set_error(ADMPC_ENODEV, "no HIP device");
+    if (device < 0 || device >= ndev) return admpc_set_error(ADMPC_ENODEV, "no such device");
+    QGuard guard(device);
+    if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
+    AdmpcQuadSolver* s = new (std::nothrow) AdmpcQuadSolver();
+    if (!s) return admpc_set_error(ADMPC_ENOMEM, "out of host memory");
+    s->cfg = *cfg; s->device = device; s->d_cfg = nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return admpc_set_error(ADMPC_EHIP, "hipGetDeviceProperties failed"); }
+    s->num_cu = prop.multiProcessorCount;
+    s->lds_bytes = quad_lds_doubles(cfg->N) * (int)sizeof(double);
+    if (hipMalloc((void**)&s->d_cfg, sizeof(AdmpcQuadConfig)) != hipSuccess ||
+        hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcQuadConfig), hipMemcpyHostToDevice) != hipSuccess) { if (s->d_cfg) (void)hipFree(s->d_cfg); delete s; return admpc_set_error(ADMPC_EHIP, "device allocation failed"); }
+    (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_quad_shoot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = s;
+    return ADMPC_OK;
+}
+
+void admpc_quad_destroy(AdmpcQuadSolver* s)
+{
+    if (!s) return;
+    QGuard guard(s->device);
+    if (s->d_cfg) (void)hipFree(s->d_cfg);
+    delete s;
+}
+
+int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e,
+                           double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
+{
+    if (!s) return admpc_set_error(ADMPC_EINVAL, "null solver");
+    if (B < 0) return admpc_set_error(ADMPC_EINVAL, "negative batch");
+    if (B == 0) return ADMPC_OK;
+    if (!x0 || !yref || !yref_e || !xbar || !ubar) return admpc_set_error(ADMPC_EINVAL, "null array argument");
+    QGuard guard(s->device);
+    if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
+    int per_cu = (160 * 1024) / s->lds_bytes; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    int grid = s->num_cu * per_cu; if (grid > B) grid = B;
+    hipLaunchKernelGGL(admpc_quad_solve_kernel, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters);
+    if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad solve kernel launch failed");
+    return ADMPC_OK;
+}
+
+int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, double* phi, double* A, double* Bm, void* stream)
+{
+    if (!s) return admpc_set_error(ADMPC_EINVAL, "null solver");
+    if (B <= 0) return B == 0 ? ADMPC_OK : admpc_set_error(ADMPC_EINVAL, "negative batch");
+    if (!xbar || !ubar || !phi || !A || !Bm) return admpc_set_error(ADMPC_EINVAL, "null array argument");
+    QGuard guard(s->device);
+    if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
+    int grid = s->num_cu * 2; if (grid > B) grid = B;
+    hipLaunchKernelGGL(admpc_quad_shoot_kernel, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, xbar, ubar, phi, A, Bm);
+    if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad shoot kernel launch failed");
+    return ADMPC_OK;
+}
+
+}  // extern "C"

@@ -247,3 +247,68 @@ class EnsembleBatchSolver:
             if cost is not None: cost.index_copy_(0, idx, co)
             if status is not None: status.index_copy_(0, idx, st)
             if iters is not None: iters.index_copy_(0, idx, it)
+
+
+class QuadBatchSolver:
+    """The second vehicle model (include/admpc_quad.h): one SQP-RTI step of the reference's quadrotor MPC for a batch.
+    Replaces the AcadosOcpSolver of quad_3d_optimizer.py:207 for B independent instances."""
+
+    def __init__(self, cfg=None, device=0):
+        from .quad_config import default_quad_config
+        if not torch.cuda.is_available():
+            raise _lib.AdmpcError("no HIP device visible: the AD-MPC engine has no CPU fallback")
+        self.lib = _lib.load()
+        self.cfg = (cfg if cfg is not None else default_quad_config()).copy()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p(0)
+        _lib.check(self.lib.admpc_quad_create(C.byref(self.cfg), self.device_index, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.admpc_quad_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t, shape, dtype=torch.float64):
+        if t.dtype != dtype or not t.is_contiguous() or t.device != self.device or tuple(t.shape) != tuple(shape):
+            raise ValueError("expected contiguous %s tensor of shape %s on %s" % (dtype, tuple(shape), self.device))
+
+    def solve(self, x0, yref, yref_e, xbar, ubar, cost=None, status=None, iters=None):
+        """In place on xbar [B,N+1,13] / ubar [B,N,4] (float64 device tensors).  Asynchronous."""
+        from .quad_config import QNX, QNU, QNY
+        N, B = int(self.cfg.N), x0.shape[0]
+        self._chk(x0, (B, QNX)); self._chk(yref, (B, N, QNY)); self._chk(yref_e, (B, QNX)); self._chk(xbar, (B, N + 1, QNX)); self._chk(ubar, (B, N, QNU))
+        if cost is not None: self._chk(cost, (B,))
+        if status is not None: self._chk(status, (B,), torch.int32)
+        if iters is not None: self._chk(iters, (B,), torch.int32)
+        _lib.check(self.lib.admpc_quad_solve_batch(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(xbar), _ptr(ubar), _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
+
+    def shoot(self, xbar, ubar):
+        from .quad_config import QNX, QNU
+        N, B = int(self.cfg.N), xbar.shape[0]
+        self._chk(xbar, (B, N + 1, QNX)); self._chk(ubar, (B, N, QNU))
+        phi = torch.empty((B, N, QNX), dtype=torch.float64, device=self.device)
+        A = torch.empty((B, N, QNX, QNX), dtype=torch.float64, device=self.device)
+        Bm = torch.empty((B, N, QNX, QNU), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.admpc_quad_shoot_batch(self._h, B, _ptr(xbar), _ptr(ubar), _ptr(phi), _ptr(A), _ptr(Bm), self._stream()))
+        return phi, A, Bm
+
+    def solve_numpy(self, x0, yref, yref_e, xbar, ubar):
+        """Host arrays in, host arrays out: (x, u, cost, status, iters)."""
+        d = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+        B = np.asarray(x0).shape[0]
+        tx, tu = d(xbar).clone(), d(ubar).clone()
+        cost = torch.empty(B, dtype=torch.float64, device=self.device); st = torch.empty(B, dtype=torch.int32, device=self.device); it = torch.empty(B, dtype=torch.int32, device=self.device)
+        self.solve(d(x0), d(yref), d(yref_e), tx, tu, cost, st, it)
+        torch.cuda.synchronize(self.device)
+        return tx.cpu().numpy(), tu.cpu().numpy(), cost.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()

@@ -27,6 +27,18 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
+    qh = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "admpc_quad.h")).read(), flags=re.S)
+    qdecl = set(re.findall(r"\b(admpc_quad_[a-z0-9_]+)\s*\(", qh))
+    assert qdecl == set(_lib.QUAD_EXPORTS), qdecl ^ set(_lib.QUAD_EXPORTS)
+    for name in qdecl:
+        assert getattr(lib, name) is not None
+
+
+def test_quad_default_config_matches_python_mirror(lib):
+    from ad_mpc_amd.quad_config import AdmpcQuadConfig, default_quad_config
+    c = AdmpcQuadConfig()
+    lib.admpc_quad_default_config(C.byref(c))
+    assert bytes(c) == bytes(default_quad_config()), "struct layout or default values differ between include/admpc_quad.h and ad_mpc_amd/quad_config.py"
 
 
 def test_default_config_matches_python_mirror(lib):

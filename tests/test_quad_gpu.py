@@ -1,0 +1,90 @@
+"""Quadrotor path on the GPU (include/admpc_quad.h) against the CPU oracle, through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ad_mpc_amd.quad_config import default_quad_config, QNX, QNU
+from ad_mpc_amd.quad_scenarios import random_quad_scenarios
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quad_shooting.json")
+
+
+@pytest.fixture(scope="module")
+def qoracle():
+    from oracle.quad_oracle import QuadOracle
+    return QuadOracle()
+
+
+@pytest.fixture(scope="module")
+def qeng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ad_mpc_amd.engine import QuadBatchSolver
+    return QuadBatchSolver(default_quad_config(), device=0)
+
+
+def test_quad_shooting_against_the_reference_golden_vectors(qeng):
+    """phi, A, B of the device against vectors from the reference's compiled CasADi code (ERK4, h = 0.1): 1e-11 relative."""
+    import torch
+    cases = json.load(open(GOLDEN))["cases"]
+    N = qeng.cfg.N
+    B = (len(cases) + N - 1) // N
+    xbar = np.zeros((B, N + 1, QNX)); xbar[:, :, 3] = 1.0; ubar = np.full((B, N, QNU), 0.1)
+    for i, c in enumerate(cases):
+        xbar[i // N, i % N] = c["x"]; ubar[i // N, i % N] = c["u"]
+    d = lambda a: torch.as_tensor(a, device="cuda")
+    phi, A, Bm = qeng.shoot(d(xbar), d(ubar))
+    torch.cuda.synchronize()
+    phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
+    for i, c in enumerate(cases):
+        for got, ref in ((phi[i // N, i % N], c["phi"]), (A[i // N, i % N], c["A"]), (Bm[i // N, i % N], c["B"])):
+            ref = np.array(ref)
+            assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("N,B", [(10, 257), (5, 64), (16, 40)])
+def test_quad_solve_parity_with_oracle(qoracle, N, B):
+    """One RTI step per instance: identical status and interior-point iteration counts, inputs and states within 1e-8, cost 1e-9
+    relative; saturated inputs in the batch; x_0 pinned; inputs inside the box."""
+    from ad_mpc_amd.engine import QuadBatchSolver
+    cfg = default_quad_config(N=N, t_horizon=0.1 * N)
+    eng = QuadBatchSolver(cfg, device=0)
+    s = random_quad_scenarios(B, cfg, seed=100 + N)
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    np.testing.assert_array_equal(g[3], o[3]); assert (o[3] == 0).all()
+    np.testing.assert_array_equal(g[4], o[4])
+    assert np.abs(g[1] - o[1]).max() <= 1e-8 and np.abs(g[0] - o[0]).max() <= 1e-8, (np.abs(g[1] - o[1]).max(), np.abs(g[0] - o[0]).max())
+    np.testing.assert_allclose(g[2], o[2], rtol=1e-9)
+    assert (g[1] >= -1e-9).all() and (g[1] <= 1 + 1e-9).all() and ((g[1] <= 1e-6) | (g[1] >= 1 - 1e-6)).sum() > B // 4
+    np.testing.assert_array_equal(g[0][:, 0], s["x0"])
+    eng.close()
+
+
+def test_quad_failure_status_and_repeatability(qeng, qoracle):
+    cfg = qeng.cfg
+    s = random_quad_scenarios(48, cfg, seed=5)
+    s["x0"][7, 1] = np.nan
+    a = qeng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    b = qeng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)                       # bit-wise repeatable
+    assert a[3][7] == 4 and np.isinf(a[2][7]) and (a[0][7] == s["xbar"][7]).all() and (a[1][7] == s["ubar"][7]).all()
+    o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    np.testing.assert_array_equal(a[3], o[3])
+
+
+def test_quad_argument_errors():
+    import ctypes as C
+    from ad_mpc_amd import _lib
+    L = _lib.load()
+    bad = default_quad_config(); bad.N = 40
+    h = C.c_void_p(0)
+    assert L.admpc_quad_create(C.byref(bad), 0, C.byref(h)) == -1 and b"N must be" in L.admpc_last_error()
+    bad = default_quad_config(); bad.W[14] = 0.0
+    assert L.admpc_quad_create(C.byref(bad), 0, C.byref(h)) == -1
+    assert L.admpc_quad_create(C.byref(default_quad_config()), 99, C.byref(h)) == -2
