@@ -88,3 +88,31 @@ def test_quad_argument_errors():
     bad = default_quad_config(); bad.W[14] = 0.0
     assert L.admpc_quad_create(C.byref(bad), 0, C.byref(h)) == -1
     assert L.admpc_quad_create(C.byref(default_quad_config()), 99, C.byref(h)) == -2
+
+
+def test_quad_3d_optimizer_shim_against_oracle(qoracle):
+    """The reference-shaped host class: weight expansion with q_mask (my_quad_acados_ocp.json has W[3] = 0), body-frame velocity in the
+    point reference, padding of a short trajectory, persistent iterate over two calls -- each call equals an oracle step from the
+    same data."""
+    from ad_mpc_amd.quad_3d_optimizer import Quad3DOptimizer, v_dot_q, quaternion_inverse
+    opt = Quad3DOptimizer(None, t_horizon=1.0, n_nodes=10, q_mask=np.ones(12))
+    np.testing.assert_allclose(np.array(opt.cfg.W[:]), [10, 10, 10, 0, .1, .1, .1] + [.05] * 6 + [.1] * 4)
+    assert bytes(opt.cfg) == bytes(default_quad_config())                        # exactly the shipped OCP
+    q = np.array([0.9, 0.1, -0.2, 0.3]); q /= np.linalg.norm(q)
+    tgt = [[1.0, -2.0, 0.5], list(q), [0.5, 0.2, -0.1], [0, 0, 0]]
+    opt.set_reference_state(tgt, [0.12] * 4)
+    np.testing.assert_allclose(opt.yref[3, 7:10], v_dot_q(tgt[2], quaternion_inverse(q)))      # the reference's body-frame quirk
+    x0 = [0.2, 0.1, -0.3, 1, 0, 0, 0, 0.1, 0, 0, 0, 0, 0.1]
+    xi, ui = opt.x_iter.copy(), opt.u_iter.copy()
+    for _ in range(2):
+        w, x = opt.run_optimization(x0, return_x=True)
+        o = qoracle.solve_batch(opt.cfg, np.array(x0)[None], opt.yref[None], opt.yref_e[None], xi[None], ui[None])
+        assert o[3][0] == 0 and np.abs(w - o[1][0].reshape(-1)).max() <= 1e-8 and np.abs(x - o[0][0]).max() <= 1e-8
+        xi, ui = o[0][0], o[1][0]
+    # trajectory reference shorter than the horizon: padded with its last row; the terminal node takes the state only
+    T = 6
+    xt = [np.linspace(0, 1, T)[:, None] * np.ones((1, 3)), np.tile([1.0, 0, 0, 0], (T, 1)), np.zeros((T, 3)), np.zeros((T, 3))]
+    opt.set_reference_trajectory(xt, np.full((T - 1, 4), 0.12))
+    assert (opt.yref[T:, :3] == 1.0).all() and (opt.yref_e[:3] == 1.0).all() and opt.yref.shape == (10, 17)
+    w = opt.run_optimization(x0)
+    assert w.shape == (40,) and opt.status == 0
