@@ -16,8 +16,8 @@ def test_no_readlane_or_dpp_hazard_in_compiled_kernels(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import check_dpp_hazard
     import check_inflight
-    # the two translation units exactly as csrc/Makefile builds them
-    for name in ("admpc_kernels", "admpc_rowqp"):
+    # the three translation units exactly as csrc/Makefile builds them
+    for name in ("admpc_kernels", "admpc_rowqp", "admpc_quad"):
         out = str(tmp_path / (name + ".s"))
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-DADMPC_WSYNC_FENCE_ONLY", "-std=c++17", "-O3", "-S", "--cuda-device-only",
                         "-Wno-bitwise-instead-of-logical", "-o", out, os.path.join(csrc, name + ".hip")], check=True, capture_output=True, cwd=csrc)
