@@ -99,16 +99,17 @@ __device__ __forceinline__ double wave_min(double v) {
     return v;
 }
 
-// LDS layout (doubles): A [N][13][13] | B [N][13][4] | b [N][13] | H [n][n+1] | M [n][n+1] | gam [13][64] | vec [64] | xnew [(N+1)*13]
+// LDS layout (doubles): A [N][13][13] | B [N][13][4] | b [N][13] | H, M: packed lower triangles n(n+1)/2 | gam [13][n] | vec [64] | xnew [(N+1)*13]
 struct Lds {
     double *A, *B, *b, *H, *M, *gam, *vec, *xnew;
-    int ld;
     __device__ Lds(double* p, int N) {
-        const int n = N * QU; ld = n + 1;
-        A = p; B = A + N * QX * QX; b = B + N * QX * QU; H = b + N * QX; M = H + n * ld; gam = M + n * ld; vec = gam + QX * 64; xnew = vec + 64;
+        const int n = N * QU, tri = n * (n + 1) / 2;
+        A = p; B = A + N * QX * QX; b = B + N * QX * QU; H = b + N * QX; M = H + tri; gam = M + tri; vec = gam + QX * n; xnew = vec + 64;
     }
 };
-__host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + 2 * n * (n + 1) + QX * 64 + 64 + (N + 1) * QX; }
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }                    // j <= i
+__device__ __forceinline__ int sym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
+__host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + n * (n + 1) + QX * n + 64 + (N + 1) * QX; }
 
 __device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const Lds& L, int lane, double* phi_out)
 {
@@ -151,7 +152,6 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
     extern __shared__ double lds_raw[];
     const int N = c->N, n = N * QU, lane = threadIdx.x;
     Lds L(lds_raw, N);
-    const int ld = L.ld;
     const bool act = lane < n;
     const int li = act ? lane : 0, ji = li / QU, mi = li - ji * QU;
     const double Ts = c->Ts;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         // ---- 1. shooting
         shoot_instance(c, xb, ub, L, lane, nullptr);
         // ---- 2. condensing (oracle: condense)
-        for (int j = 0; j <= li; ++j) if (act) L.H[li * ld + j] = 0.0;
+        for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0;
         double g[QX], xh[QX];
 #pragma unroll
         for (int i = 0; i < QX; ++i) { g[i] = 0.0; xh[i] = x0[i] - xb[i]; }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
                 gn[r] = ji == k ? L.B[(k * QX + r) * QU + mi] : (ji < k ? s : 0.0);
             }
 #pragma unroll
-            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; L.gam[r * 64 + lane] = act ? gn[r] : 0.0; }
+            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; if (act) L.gam[r * n + lane] = gn[r]; }
             __syncthreads();
             const double* ref = k + 1 < N ? yr + (k + 1) * QY : ye;
             const int lim = (k + 1) * QU;                                   // inputs of stages <= k
@@ -195,17 +195,15 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             }
             if (act && li < lim) {
                 for (int j = 0; j <= li; ++j) {
-                    double s = L.H[li * ld + j];
+                    double s = L.H[tri(li, j)];
 #pragma unroll
-                    for (int cc = 0; cc < QX; ++cc) s += wg[cc] * L.gam[cc * 64 + j];
-                    L.H[li * ld + j] = s;
+                    for (int cc = 0; cc < QX; ++cc) s += wg[cc] * L.gam[cc * n + j];
+                    L.H[tri(li, j)] = s;
                 }
             }
             __syncthreads();
         }
-        if (act) L.H[li * ld + li] += Ts * c->W[QX + mi];
-        __syncthreads();
-        if (act) for (int j = 0; j < li; ++j) L.H[j * ld + li] = L.H[li * ld + j];
+        if (act) L.H[tri(li, li)] += Ts * c->W[QX + mi];
         __syncthreads();
         // ---- 3. box QP (oracle: box_qp)
         const double lo = c->lbu[mi] - ubar_i, hi = c->ubu[mi] - ubar_i;
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             L.vec[lane] = du;
             __syncthreads();
             double rs = grad - ll + lu;
-            if (act) for (int j = 0; j < n; ++j) rs += L.H[li * ld + j] * L.vec[j];
+            if (act) for (int j = 0; j < n; ++j) rs += L.H[sym(li, j)] * L.vec[j];
             const double rl = du - lo - tl, ru = hi - du - tu;
             const double mu = wave_sum(act ? tl * ll + tu * lu : 0.0) / (2.0 * n);
             const double cmax = wave_max(act ? fmax(tl * ll, tu * lu) : 0.0);
@@ -227,19 +225,19 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
             if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
             const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
-            if (act) { for (int j = 0; j <= li; ++j) L.M[li * ld + j] = L.H[li * ld + j]; L.M[li * ld + li] += Dl + Du; }
+            if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
             __syncthreads();
             // Cholesky M = L L' (lower), row i on lane i, columns left to right (oracle: chol)
             bool posdef = true;
             for (int j = 0; j < n; ++j) {
                 double s = 0.0;
-                if (act && li >= j) { s = L.M[li * ld + j]; for (int k2 = 0; k2 < j; ++k2) s -= L.M[li * ld + k2] * L.M[j * ld + k2]; }
+                if (act && li >= j) { s = L.M[tri(li, j)]; for (int k2 = 0; k2 < j; ++k2) s -= L.M[tri(li, k2)] * L.M[tri(j, k2)]; }
                 const double dj = __shfl(s, j);
                 if (!(dj > 0.0)) { posdef = false; break; }
                 const double dsq = sqrt(dj);
                 __syncthreads();
-                if (act && li == j) L.M[j * ld + j] = dsq;
-                if (act && li > j) L.M[li * ld + j] = s / dsq;
+                if (act && li == j) L.M[tri(j, j)] = dsq;
+                if (act && li > j) L.M[tri(li, j)] = s / dsq;
                 __syncthreads();
             }
             if (!posdef) { st = 4; break; }
@@ -247,14 +245,14 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             auto solve = [&](double rhs) -> double {
                 double r = rhs;
                 for (int k2 = 0; k2 < n; ++k2) {
-                    const double xk = __shfl(r, k2) / L.M[k2 * ld + k2];
+                    const double xk = __shfl(r, k2) / L.M[tri(k2, k2)];
                     if (lane == k2) r = xk;
-                    if (act && li > k2) r -= L.M[li * ld + k2] * xk;
+                    if (act && li > k2) r -= L.M[tri(li, k2)] * xk;
                 }
                 for (int k2 = n - 1; k2 >= 0; --k2) {
-                    const double xk = __shfl(r, k2) / L.M[k2 * ld + k2];
+                    const double xk = __shfl(r, k2) / L.M[tri(k2, k2)];
                     if (lane == k2) r = xk;
-                    if (act && li < k2) r -= L.M[k2 * ld + li] * xk;
+                    if (act && li < k2) r -= L.M[tri(k2, li)] * xk;
                 }
                 return r;
             };
@@ -303,7 +301,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         double J = 0.0;
         if (act) { const double e = un - yr[ji * QY + QX + mi]; J += 0.5 * Ts * c->W[QX + mi] * e * e; }
         for (int k = 0; k < N; ++k) {
-            L.gam[lane] = dx;                                        // dx_k of all components (lanes < 13)
+            if (lane < QX) L.gam[lane] = dx;                         // dx_k of all components
             __syncthreads();
             double dn = 0.0;
             if (lane < QX) {
