@@ -19,6 +19,15 @@
 
 extern "C" int admpc_set_error(int code, const char* msg);          // admpc_kernels.hip: thread-local message behind admpc_last_error()
 
+#ifdef ADMPC_QUAD_TIMERS
+__device__ unsigned long long g_quad_ticks[8];
+#define QSTAMP(id) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); if (threadIdx.x == 0) atomicAdd(&g_quad_ticks[id], t_ - qlast); qlast = t_; } while (0)
+#define QSTART() unsigned long long qlast; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(qlast))
+#else
+#define QSTAMP(id) do { } while (0)
+#define QSTART() do { } while (0)
+#endif
+
 namespace {
 
 constexpr int QX = ADMPC_QUAD_NX, QU = ADMPC_QUAD_NU, QY = ADMPC_QUAD_NY;
@@ -83,6 +92,11 @@ __device__ __forceinline__ void rk4_col(const Cfg* __restrict__ c, const double*
     for (int i = 0; i < QX; ++i) { phi[i] = x[i] + h * ax[i]; scol[i] = (col == i ? 1.0 : 0.0) + h * as[i]; }
 }
 
+// value of lane l (wave-uniform l): two v_readlane, no LDS round trip
+__device__ __forceinline__ double bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
@@ -161,8 +175,10 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         const double* yr = yrefg + (size_t)inst * N * QY;
         const double* ye = yrefeg + (size_t)inst * QX;
         const double* x0 = x0g + (size_t)inst * QX;
+        QSTART();
         // ---- 1. shooting
         shoot_instance(c, xb, ub, L, lane, nullptr);
+        QSTAMP(0);
         // ---- 2. condensing (oracle: condense)
         for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0;
         double g[QX], xh[QX];
@@ -205,6 +221,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         }
         if (act) L.H[tri(li, li)] += Ts * c->W[QX + mi];
         __syncthreads();
+        QSTAMP(1);
         // ---- 3. box QP (oracle: box_qp)
         const double lo = c->lbu[mi] - ubar_i, hi = c->ubu[mi] - ubar_i;
         double du = 0.0;
@@ -227,30 +244,46 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
             if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
             __syncthreads();
+            QSTAMP(2);
             // Cholesky M = L L' (lower), row i on lane i, columns left to right (oracle: chol)
             bool posdef = true;
+            double myinv = 0.0;                                      // lane j: 1 / L_jj
             for (int j = 0; j < n; ++j) {
                 double s = 0.0;
-                if (act && li >= j) { s = L.M[tri(li, j)]; for (int k2 = 0; k2 < j; ++k2) s -= L.M[tri(li, k2)] * L.M[tri(j, k2)]; }
-                const double dj = __shfl(s, j);
+                if (act && li >= j) {
+                    const double* ri = L.M + tri(li, 0);
+                    const double* rj = L.M + tri(j, 0);
+                    s = ri[j];
+                    int k2 = 0;
+                    for (; k2 + 8 <= j; k2 += 8) {                   // eight products per round trip, subtracted in the oracle's order
+                        double a[8], b[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { a[q] = ri[k2 + q]; b[q] = rj[k2 + q]; }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) s -= a[q] * b[q];
+                    }
+                    for (; k2 < j; ++k2) s -= ri[k2] * rj[k2];
+                }
+                const double dj = bcast(s, j);
                 if (!(dj > 0.0)) { posdef = false; break; }
-                const double dsq = sqrt(dj);
+                const double inv = 1.0 / sqrt(dj);
                 __syncthreads();
-                if (act && li == j) L.M[tri(j, j)] = dsq;
-                if (act && li > j) L.M[tri(li, j)] = s / dsq;
+                if (lane == j) myinv = inv;
+                if (act && li > j) L.M[tri(li, j)] = s * inv;
                 __syncthreads();
             }
+            QSTAMP(3);
             if (!posdef) { st = 4; break; }
             // two solves with the factor: forward by columns (same subtraction order as the oracle's rows), backward by columns
             auto solve = [&](double rhs) -> double {
                 double r = rhs;
                 for (int k2 = 0; k2 < n; ++k2) {
-                    const double xk = __shfl(r, k2) / L.M[tri(k2, k2)];
+                    const double xk = bcast(r, k2) * bcast(myinv, k2);
                     if (lane == k2) r = xk;
                     if (act && li > k2) r -= L.M[tri(li, k2)] * xk;
                 }
                 for (int k2 = n - 1; k2 >= 0; --k2) {
-                    const double xk = __shfl(r, k2) / L.M[tri(k2, k2)];
+                    const double xk = bcast(r, k2) * bcast(myinv, k2);
                     if (lane == k2) r = xk;
                     if (act && li < k2) r -= L.M[tri(k2, li)] * xk;
                 }
@@ -288,6 +321,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             }
             alpha_prev = alpha;
             __syncthreads();
+            QSTAMP(4);
         }
         // ---- 4. expansion, full step, cost (oracle: rti_step)
         __syncthreads();
@@ -326,6 +360,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             for (int i = lane; i < (N + 1) * QX; i += 64) xb[i] = L.xnew[i];
             if (act) ub[li] = un;
         }
+        QSTAMP(5);
         if (lane == 0) {
             if (costg) costg[inst] = bad ? INFINITY : J;
             if (statusg) statusg[inst] = bad ? 4 : 0;
@@ -437,5 +472,18 @@ int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const 
     if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad shoot kernel launch failed");
     return ADMPC_OK;
 }
+
+#ifdef ADMPC_QUAD_TIMERS
+#include <cstdio>
+void admpc_quad_dump_timers(void)
+{
+    unsigned long long h[8] = {0};
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_quad_ticks), sizeof h) != hipSuccess) return;
+    static const char* nm[6] = {"shooting", "condensing", "residuals + Newton matrix", "Cholesky", "solves + step", "expansion"};
+    unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += h[i];
+    for (int i = 0; i < 6; ++i) fprintf(stderr, "[quad phase] %-28s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+}
+#endif
 
 }  // extern "C"

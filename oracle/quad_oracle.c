@@ -128,26 +128,27 @@ static void condense(const Cfg* c, const real* x0, const real* yref, const real*
     for (int i = 0; i < n; ++i) { w->H[i][i] += c->Ts * c->W[NX + i % NU]; for (int j = 0; j < i; ++j) w->H[j][i] = w->H[i][j]; }
 }
 
-/* in-place Cholesky M = L L' (lower) and solve M x = rhs; returns 0 on a non-positive pivot */
-static int chol(int n, real M[NMAX][NMAX])
+/* in-place Cholesky M = L L' (strictly lower part of L in M, reciprocals of its diagonal in invd) and solve M x = rhs;
+ * returns 0 on a non-positive pivot.  Divisions are one reciprocal per column (as the device does) */
+static int chol(int n, real M[NMAX][NMAX], real* invd)
 {
     for (int j = 0; j < n; ++j) {
         real d = M[j][j];
         for (int k = 0; k < j; ++k) d -= M[j][k] * M[j][k];
         if (!(d > 0)) return 0;
-        d = sqrt(d); M[j][j] = d;
+        invd[j] = 1.0 / sqrt(d);
         for (int i = j + 1; i < n; ++i) {
             real s = M[i][j];
             for (int k = 0; k < j; ++k) s -= M[i][k] * M[j][k];
-            M[i][j] = s / d;
+            M[i][j] = s * invd[j];
         }
     }
     return 1;
 }
-static void chol_solve(int n, real L[NMAX][NMAX], real* x)
+static void chol_solve(int n, real L[NMAX][NMAX], const real* invd, real* x)
 {
-    for (int i = 0; i < n; ++i) { real s = x[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * x[k]; x[i] = s / L[i][i]; }
-    for (int i = n - 1; i >= 0; --i) { real s = x[i]; for (int k = i + 1; k < n; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+    for (int i = 0; i < n; ++i) { real s = x[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * x[k]; x[i] = s * invd[i]; }
+    for (int i = n - 1; i >= 0; --i) { real s = x[i]; for (int k = i + 1; k < n; ++k) s -= L[k][i] * x[k]; x[i] = s * invd[i]; }
 }
 
 /* Mehrotra predictor-corrector on  min 1/2 du'H du + g'du,  lo <= du <= hi.  Returns 0 ok, 4 failure. */
@@ -174,17 +175,17 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
         mu /= 2 * n;
         if (!(mu == mu) || !(rmax == rmax)) { *iters = it; return 4; }
         if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
-        real M[NMAX][NMAX];
+        real M[NMAX][NMAX], invd[NMAX];
         real Dl[NMAX], Du[NMAX], da[NMAX], dtl[NMAX], dtu[NMAX], dll[NMAX], dlu[NMAX];
         for (int i = 0; i < n; ++i) {
             Dl[i] = ll[i] / tl[i]; Du[i] = lu[i] / tu[i];
             for (int j = 0; j <= i; ++j) M[i][j] = H[i][j];
             M[i][i] += Dl[i] + Du[i];
         }
-        if (!chol(n, M)) { *iters = it; return 4; }
+        if (!chol(n, M, invd)) { *iters = it; return 4; }
         /* predictor (sigma = 0) */
         for (int i = 0; i < n; ++i) da[i] = -rs[i] + (-ll[i] - Dl[i] * rl[i]) - (-lu[i] - Du[i] * ru[i]);
-        chol_solve(n, M, da);
+        chol_solve(n, M, invd, da);
         real amax = 1, muaff = 0;
         for (int i = 0; i < n; ++i) {
             dtl[i] = da[i] + rl[i]; dtu[i] = -da[i] + ru[i];
@@ -205,7 +206,7 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
             cl[i] = (smu - dtl[i] * dll[i]) / tl[i]; cu[i] = (smu - dtu[i] * dlu[i]) / tu[i];
             d[i] = -rs[i] + (cl[i] - ll[i] - Dl[i] * rl[i]) - (cu[i] - lu[i] - Du[i] * ru[i]);
         }
-        chol_solve(n, M, d);
+        chol_solve(n, M, invd, d);
         amax = 1;
         for (int i = 0; i < n; ++i) {
             dtl[i] = d[i] + rl[i]; dtu[i] = -d[i] + ru[i];

@@ -2,6 +2,8 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
+import ad_mpc_amd._lib as _lib
+if os.environ.get("ADMPC_LIB"): _lib.LIB_PATH = os.path.join(ROOT, "ad_mpc_amd", os.environ["ADMPC_LIB"])
 from ad_mpc_amd.quad_config import default_quad_config
 from ad_mpc_amd.quad_scenarios import random_quad_scenarios
 from ad_mpc_amd.engine import QuadBatchSolver
@@ -16,6 +18,11 @@ for rep in range(8):
     eng.solve(x0, yr, ye, xb, ub, co, st, it); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 t = np.median(ts[2:])
 print("quadrotor nx=13 nu=4 N=%d B=%d: %.3f ms/step, %.2f M solves/s; IPM iterations mean %.2f max %d; status != 0: %d" % (cfg.N, B, t * 1e3, B / t / 1e6, it.float().mean().item(), it.max().item(), int((st != 0).sum())))
+try:
+    import ctypes
+    ctypes.CDLL(eng.lib._name).admpc_quad_dump_timers()       # only in a -DADMPC_QUAD_TIMERS build
+except Exception:
+    pass
 from oracle.quad_oracle import QuadOracle   # CPU baseline of the same step (analysis script)
 o = QuadOracle(); n = min(B, 1024); t0 = time.perf_counter()
 o.solve_batch(cfg, s["x0"][:n], s["yref"][:n], s["yref_e"][:n], s["xbar"][:n], s["ubar"][:n], nthreads=os.cpu_count())
