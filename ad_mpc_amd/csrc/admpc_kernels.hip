@@ -1640,7 +1640,7 @@ struct AdmpcSolver {
     double* d_aux;           // [cap][128]
     int* d_sched;            // [SCHED_HDR + SCHED_NB * cap] work scheduler of the persistent interior-point waves
     int qmask;               // 7 when only x, y, psi carry tracking weights (specialised condensing kernel), else 127
-    double* d_ws;            // [cap][N+1][36] workspace of the row kernel (sweep-private state, L2-resident)
+    double* d_ws;            // [cap][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
     double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
 };
 

@@ -6,7 +6,7 @@
 // Data placement
 //   HBM / L2, read-only during the solve (streamed one stage ahead by every sweep): packed linearisation GT [B][N][7][6] and
 //     defects b [B][N][7] from the linearisation kernel, the references yref / yref_e; xbar / ubar at the start and the end.
-//   workspace [B][N+1][36] in global memory (L2 / Infinity Cache resident): what only the sweeps touch -- the absolute state,
+//   workspace [B][N+1][38] in global memory (L2 / Infinity Cache resident): what only the sweeps touch -- the absolute state,
 //     its Newton step, the feedback gains, the corrector's sigma-mu coefficients -- written by one sweep, streamed by the next.
 //   LDS: what the passes over the inequalities touch, 31 values per stage and instance (slacks, multipliers, inputs and their
 //     references, right-hand sides and steps of the inputs / the steering angle): 248 B (fp64) / 124 B (fp32) per stage ->
