@@ -39,6 +39,64 @@ __device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const doub
 {
     const double qw = x[3], qx = x[4], qy = x[5], qz = x[6], r0 = x[10], r1 = x[11], r2 = x[12];
     const double sw = sx[3], sxx = sx[4], sy = sx[5], sz = sx[6], t0 = sx[10], t1 = sx[11], t2 = sx[12];
+    double ga[3] = { 0, 0, 0 }, dga[3] = { 0, 0, 0 };        // GP residual of the acceleration, evaluated first (shorter live ranges)
+    if (c->n_gp > 0) {                       // wave-uniform.  GP residual: v' += R(q) mu(z), z = [x with v in the body frame; u]
+        const double R[3][3] = { { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy) },
+                                 { 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx) },
+                                 { 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy) } };
+        // dR = directional derivative of R along sq, formed where it is used (twice) instead of kept live across the GP loop
+        auto dRm = [&](double (&D)[3][3]) {
+            D[0][0] = -4 * (qy * sy + qz * sz); D[0][1] = 2 * (sxx * qy + qx * sy - sw * qz - qw * sz); D[0][2] = 2 * (sxx * qz + qx * sz + sw * qy + qw * sy);
+            D[1][0] = 2 * (sxx * qy + qx * sy + sw * qz + qw * sz); D[1][1] = -4 * (qx * sxx + qz * sz); D[1][2] = 2 * (sy * qz + qy * sz - sw * qx - qw * sxx);
+            D[2][0] = 2 * (sxx * qz + qx * sz - sw * qy - qw * sy); D[2][1] = 2 * (sy * qz + qy * sz + sw * qx + qw * sxx); D[2][2] = -4 * (qx * sxx + qy * sy);
+        };
+        // candidate features: entries 7..16 of z (body-frame velocity, body rates, inputs); position and attitude are not offered
+        double z[10], dz[10];
+        { double dR[3][3]; dRm(dR);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a2 = 0, d2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a2 += R[k][i] * x[7 + k]; d2 += dR[k][i] * x[7 + k] + R[k][i] * sx[7 + k]; }
+            z[i] = a2; dz[i] = d2;
+            z[3 + i] = x[10 + i]; dz[3 + i] = sx[10 + i];
+        } }
+#pragma unroll
+        for (int m = 0; m < QU; ++m) { z[6 + m] = u[m]; dz[6 + m] = su[m]; }
+        double mb[3] = { 0, 0, 0 }, dmb[3] = { 0, 0, 0 };
+        for (int g = 0; g < c->n_gp; ++g) {
+            const AdmpcGp& gp = c->gp[g];
+            // features by compare-select chains (a runtime-indexed private array would live in scratch memory)
+            double zf[ADMPC_GP_MAX_FEAT], dzf[ADMPC_GP_MAX_FEAT], il[ADMPC_GP_MAX_FEAT];
+#pragma unroll
+            for (int k = 0; k < ADMPC_GP_MAX_FEAT; ++k) {
+                const int fk = k < gp.n_feat ? gp.feat[k] - 7 : -1;
+                double zv = 0, dzv = 0;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { zv = fk == i ? z[i] : zv; dzv = fk == i ? dz[i] : dzv; }
+                zf[k] = zv; dzf[k] = dzv; il[k] = k < gp.n_feat ? gp.inv_l2[k] : 0.0;
+            }
+            double m = 0, dm = 0;
+            for (int i = 0; i < gp.n_points; ++i) {
+                double e = 0, de = 0;
+#pragma unroll
+                for (int k = 0; k < ADMPC_GP_MAX_FEAT; ++k) { const double dzk = zf[k] - gp.Z[k][i]; e += dzk * dzk * il[k]; de += dzk * il[k] * dzf[k]; }
+                const double ka = gp.sigma_f * exp(-0.5 * e) * gp.alpha[i];
+                m += ka; dm -= ka * de;
+            }
+            const int o = gp.out - 7;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { mb[i] += o == i ? m + gp.ymean : 0.0; dmb[i] += o == i ? dm : 0.0; }
+        }
+        double dR[3][3]; dRm(dR);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a2 = 0, d2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a2 += R[i][k] * mb[k]; d2 += dR[i][k] * mb[k] + R[i][k] * dmb[k]; }
+            ga[i] = a2; dga[i] = d2;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { f[i] = x[7 + i]; df[i] = sx[7 + i]; }
     f[3] = 0.5 * (-r0 * qx - r1 * qy - r2 * qz);
@@ -68,6 +126,7 @@ __device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const doub
     df[10] = (dtx + (c->J[1] - c->J[2]) * (t1 * r2 + r1 * t2)) / c->J[0];
     df[11] = (dty + (c->J[2] - c->J[0]) * (t2 * r0 + r2 * t0)) / c->J[1];
     df[12] = (dtz + (c->J[0] - c->J[1]) * (t0 * r1 + r0 * t1)) / c->J[2];
+    f[7] += ga[0]; f[8] += ga[1]; f[9] += ga[2]; df[7] += dga[0]; df[8] += dga[1]; df[9] += dga[2];
 }
 
 // classic RK4, one step of length h: the state and ONE sensitivity column (col < 13: d/dx_col, else d/du_(col-13))
@@ -416,6 +475,14 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
         if (!(cfg->lbu[m] < cfg->ubu[m])) return admpc_set_error(ADMPC_EINVAL, "quad: lbu < ubu required");
     }
     if (cfg->ipm_iter_max < 1 || !(cfg->ipm_mu0 > 0) || !(cfg->ipm_thr0 > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: bad interior-point parameters");
+    if (cfg->n_gp < 0 || cfg->n_gp > ADMPC_QUAD_GP_MAX) return admpc_set_error(ADMPC_EINVAL, "quad: n_gp out of range");
+    for (int g = 0; g < cfg->n_gp; ++g) {
+        const AdmpcGp& gp = cfg->gp[g];
+        bool okf = gp.n_feat >= 1 && gp.n_feat <= ADMPC_GP_MAX_FEAT;
+        for (int d = 0; okf && d < gp.n_feat; ++d) okf = gp.feat[d] >= 7 && gp.feat[d] < QY;
+        if (gp.out < 7 || gp.out > 9 || !okf || gp.n_points < 0 || gp.n_points > ADMPC_GP_MAX_POINTS)
+            return admpc_set_error(ADMPC_EINVAL, "quad GP: out must be in {7,8,9}, 1..3 features in [7,17), n_points <= 32");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return admpc_set_error(ADMPC_ENODEV, "no HIP device");
     if (device < 0 || device >= ndev) return admpc_set_error(ADMPC_ENODEV, "no such device");

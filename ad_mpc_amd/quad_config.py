@@ -3,7 +3,11 @@
 import ctypes as C
 import math
 
-QNX, QNU, QNY, QUAD_MAX_N = 13, 4, 17, 16
+import numpy as np
+
+from .config import AdmpcGp, GP_MAX_FEAT, GP_MAX_POINTS
+
+QNX, QNU, QNY, QUAD_MAX_N, QUAD_GP_MAX = 13, 4, 17, 16, 3
 
 
 class AdmpcQuadConfig(C.Structure):
@@ -14,6 +18,7 @@ class AdmpcQuadConfig(C.Structure):
         ("mass", C.c_double), ("J", C.c_double * 3), ("max_thrust", C.c_double),
         ("x_f", C.c_double * 4), ("y_f", C.c_double * 4), ("z_l_tau", C.c_double * 4), ("g", C.c_double),
         ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double), ("ipm_tol_comp", C.c_double), ("ipm_tol_res", C.c_double),
+        ("n_gp", C.c_int32), ("_pad", C.c_int32), ("gp", AdmpcGp * QUAD_GP_MAX),
     ]
 
     def copy(self):
@@ -42,3 +47,21 @@ def default_quad_config(N=10, t_horizon=1.0):
         c.x_f[i], c.y_f[i], c.z_l_tau[i] = xf, yf, zt
     c.ipm_mu0, c.ipm_thr0, c.ipm_tol_comp, c.ipm_tol_res = 1.0, 0.1, 1e-10, 1e-9
     return c
+
+
+def set_quad_gp(cfg, gps):
+    """Residual GPs of the quadrotor (quad_3d_optimizer.py:289-327).  ``gps``: dicts as for ``config.set_gp``; ``feat`` indexes
+    z = [x with the velocity in the body frame (13); u (4)], ``out`` in {7, 8, 9} is the body-frame acceleration component."""
+    from .config import AdmpcConfig, set_gp
+    gps = list(gps)
+    if len(gps) > QUAD_GP_MAX:
+        raise ValueError("at most %d GPs" % QUAD_GP_MAX)
+    tmp = AdmpcConfig()
+    set_gp(tmp, gps)                              # fills AdmpcGp entries (same struct)
+    for g, d in enumerate(gps):
+        feats = [int(f) for f in np.atleast_1d(d["feat"]).reshape(-1)]
+        if not (7 <= int(d["out"]) <= 9) or any(not (7 <= f < QNX + QNU) for f in feats):
+            raise ValueError("quadrotor GP: out must be in {7, 8, 9}, features in [7, 17) (body-frame velocity, body rates, inputs)")
+        C.memmove(C.byref(cfg.gp[g]), C.byref(tmp.gp[g]), C.sizeof(AdmpcGp))
+    cfg.n_gp = len(gps)
+    return cfg

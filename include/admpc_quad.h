@@ -19,6 +19,7 @@
 #define ADMPC_QUAD_H
 
 #include <stdint.h>
+#include "admpc.h"      /* AdmpcGp, ADMPC_* codes */
 
 #ifdef __cplusplus
 extern "C" {
@@ -28,6 +29,7 @@ extern "C" {
 #define ADMPC_QUAD_NU 4
 #define ADMPC_QUAD_NY 17
 #define ADMPC_QUAD_MAX_N 16      /* N * nu <= 64: one lane per input of the condensed QP */
+#define ADMPC_QUAD_GP_MAX 3      /* residual GPs: one per body-frame acceleration component */
 
 typedef struct AdmpcQuadConfig {
     int32_t N;                    /* shooting intervals (reference: 10)                                            */
@@ -42,6 +44,11 @@ typedef struct AdmpcQuadConfig {
     double  x_f[4], y_f[4], z_l_tau[4];                   /* rotor arms and yaw-torque coefficients (:62-74)       */
     double  g;                    /* 9.81                                                                          */
     double  ipm_mu0, ipm_thr0, ipm_tol_comp, ipm_tol_res; /* interior point: start and stop levels                 */
+    /* GP residual of the acceleration (quad_3d_optimizer.py:289-327): the features are taken from z = [x with the velocity in the
+     * BODY frame; u] (feat[] indexes these 17 entries; 7..16 are offered: body-frame velocity, body rates, inputs), gp[g].out in {7, 8, 9} names the body-frame acceleration component the mean
+     * is added to; the sum is rotated back to the world frame:  v' += R(q) mu(z).  n_gp = 0: nominal model (the shipped code). */
+    int32_t n_gp, _pad;
+    AdmpcGp gp[ADMPC_QUAD_GP_MAX];
 } AdmpcQuadConfig;
 
 typedef struct AdmpcQuadSolver AdmpcQuadSolver;

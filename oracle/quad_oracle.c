@@ -54,6 +54,41 @@ static void quad_f_tan(const Cfg* c, const real* x, const real* u, const real* s
     df[10] = (dtx + (c->J[1] - c->J[2]) * (t1 * r2 + r1 * t2)) / c->J[0];
     df[11] = (dty + (c->J[2] - c->J[0]) * (t2 * r0 + r2 * t0)) / c->J[1];
     df[12] = (dtz + (c->J[0] - c->J[1]) * (t0 * r1 + r0 * t1)) / c->J[2];
+    if (c->n_gp > 0) {
+        /* GP residual (quad_3d_optimizer.py:289-327): features from z = [x with v in the body frame; u], means of the body-frame
+         * acceleration components rotated back to the world frame:  v' += R(q) mu(z);  utils.py:323-338 for R */
+        real R[3][3] = { { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy) },
+                         { 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx) },
+                         { 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy) } };
+        real dR[3][3] = { { -4 * (qy * sy + qz * sz), 2 * (sxx * qy + qx * sy - sw * qz - qw * sz), 2 * (sxx * qz + qx * sz + sw * qy + qw * sy) },
+                          { 2 * (sxx * qy + qx * sy + sw * qz + qw * sz), -4 * (qx * sxx + qz * sz), 2 * (sy * qz + qy * sz - sw * qx - qw * sxx) },
+                          { 2 * (sxx * qz + qx * sz - sw * qy - qw * sy), 2 * (sy * qz + qy * sz + sw * qx + qw * sxx), -4 * (qx * sxx + qy * sy) } };
+        real z[17], dz[17];
+        for (int i = 0; i < NX; ++i) { z[i] = x[i]; dz[i] = sx[i]; }
+        for (int i = 0; i < 3; ++i) {                                  /* v_b = R' v  (v_dot_q(v, q^-1)) */
+            real a2 = 0, d2 = 0;
+            for (int k = 0; k < 3; ++k) { a2 += R[k][i] * x[7 + k]; d2 += dR[k][i] * x[7 + k] + R[k][i] * sx[7 + k]; }
+            z[7 + i] = a2; dz[7 + i] = d2;
+        }
+        for (int m = 0; m < NU; ++m) { z[NX + m] = u[m]; dz[NX + m] = su[m]; }
+        real mb[3] = {0, 0, 0}, dmb[3] = {0, 0, 0};
+        for (int g = 0; g < c->n_gp; ++g) {
+            const AdmpcGp* gp = &c->gp[g];
+            real m = 0, dm = 0;
+            for (int i = 0; i < gp->n_points; ++i) {
+                real e = 0, de = 0;
+                for (int k = 0; k < gp->n_feat; ++k) { const real dzk = z[gp->feat[k]] - gp->Z[k][i]; e += dzk * dzk * gp->inv_l2[k]; de += dzk * gp->inv_l2[k] * dz[gp->feat[k]]; }
+                const real ka = gp->sigma_f * exp(-0.5 * e) * gp->alpha[i];
+                m += ka; dm -= ka * de;
+            }
+            mb[gp->out - 7] += m + gp->ymean; dmb[gp->out - 7] += dm;
+        }
+        for (int i = 0; i < 3; ++i) {
+            real a2 = 0, d2 = 0;
+            for (int k = 0; k < 3; ++k) { a2 += R[i][k] * mb[k]; d2 += dR[i][k] * mb[k] + R[i][k] * dmb[k]; }
+            f[7 + i] += a2; df[7 + i] += d2;
+        }
+    }
 }
 
 /* classic RK4 (one step of length h) of the state and ONE sensitivity column: col < 13 -> d/dx_col, col >= 13 -> d/du_(col-13) */

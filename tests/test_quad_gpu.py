@@ -116,3 +116,31 @@ def test_quad_3d_optimizer_shim_against_oracle(qoracle):
     assert (opt.yref[T:, :3] == 1.0).all() and (opt.yref_e[:3] == 1.0).all() and opt.yref.shape == (10, 17)
     w = opt.run_optimization(x0)
     assert w.shape == (40,) and opt.status == 0
+
+
+def test_quad_gp_residual_on_the_device(qoracle):
+    """GP residual of the body-frame acceleration (quad_3d_optimizer.py:289-327): device shooting against the oracle at 1e-11, the
+    solve with identical iteration counts at 1e-8, and the GP really changes the answer."""
+    import torch
+    from ad_mpc_amd.engine import QuadBatchSolver
+    from ad_mpc_amd.quad_config import set_quad_gp
+    from test_quad_oracle import quad_gps
+    cfg = default_quad_config(); set_quad_gp(cfg, quad_gps())
+    eng = QuadBatchSolver(cfg, device=0)
+    s = random_quad_scenarios(96, cfg, seed=31)
+    d = lambda a: torch.as_tensor(a, device="cuda")
+    phi, A, Bm = eng.shoot(d(s["xbar"]), d(s["ubar"]))
+    torch.cuda.synchronize()
+    phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
+    for b in range(0, 96, 11):
+        for k in (0, 4, 9):
+            po, Ao, Bo = qoracle.rk4_sens(cfg, s["xbar"][b, k], s["ubar"][b, k], cfg.Ts)
+            for got, ref in ((phi[b, k], po), (A[b, k], Ao), (Bm[b, k], Bo)):
+                assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    np.testing.assert_array_equal(g[3], o[3]); np.testing.assert_array_equal(g[4], o[4]); assert (o[3] == 0).all()
+    assert np.abs(g[1] - o[1]).max() <= 1e-8 and np.abs(g[0] - o[0]).max() <= 1e-8
+    base = qoracle.solve_batch(default_quad_config(), s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    assert np.abs(base[1] - o[1]).max() > 1e-3
+    eng.close()

@@ -93,3 +93,43 @@ def test_batch_solve_statuses_and_failure(qoracle):
     # a second step from the new iterate lowers the (linearised) cost for most instances: RTI steps converging on the tracking problem
     x2, u2, cost2, st2, _ = qoracle.solve_batch(cfg, s["x0"][ok], s["yref"][ok], s["yref_e"][ok], x[ok], u[ok], nthreads=4)
     assert (st2 == 0).all() and (cost2 <= cost[ok] * (1 + 1e-9) + 1e-12).mean() >= 0.7
+
+
+def quad_gps(seed=1):
+    """Three residual GPs of the body-frame acceleration: v_bx -> a_bx, (v_by, u_0) -> a_by with two length scales, v_bz -> a_bz."""
+    rng = np.random.default_rng(seed)
+    gps = [dict(feat=7 + i, out=7 + i, Z=np.linspace(-3, 3, 15), alpha=0.3 * rng.standard_normal(15), length_scale=1.0, sigma_f=1.0, ymean=0.01 * i) for i in range(3)]
+    gps[1] = dict(feat=[8, 13], out=8, Z=np.c_[rng.uniform(-3, 3, 20), rng.uniform(0, 1, 20)], alpha=0.3 * rng.standard_normal(20), length_scale=[1.0, 0.3], sigma_f=0.8, ymean=0.0)
+    return gps
+
+
+def test_quad_gp_residual_formula_and_sensitivities(qoracle):
+    """quad_3d_optimizer.py:289-327: the GP means of the body-frame acceleration, features from the body-frame velocity (and an input),
+    rotated back to the world frame.  The oracle against a direct numpy evaluation, and its ERK4 sensitivities (forward-mode tangents
+    through the rotation and the kernels) against central differences."""
+    from ad_mpc_amd.quad_config import set_quad_gp
+    from ad_mpc_amd.quad_3d_optimizer import q_to_rot_mat
+    cfg = default_quad_config(); gps = quad_gps()
+    cg = default_quad_config(); set_quad_gp(cg, gps)
+    rng = np.random.default_rng(9)
+    for trial in range(5):
+        x = rng.standard_normal(QNX); x[3:7] /= np.linalg.norm(x[3:7]); u = rng.uniform(0, 1, QNU)
+        R = q_to_rot_mat(x[3:7])
+        z = np.concatenate([x[:7], R.T @ x[7:10], x[10:], u])
+        mu = np.zeros(3)
+        for g in gps:
+            feats = np.atleast_1d(g["feat"]); Z = np.asarray(g["Z"]).reshape(len(g["alpha"]), -1)
+            ell = np.broadcast_to(np.atleast_1d(g["length_scale"]), (len(feats),))
+            mu[g["out"] - 7] += g["sigma_f"] * np.exp(-0.5 * (((z[feats] - Z) / ell) ** 2).sum(1)) @ g["alpha"] + g["ymean"]
+        d = qoracle.f(cg, x, u) - qoracle.f(cfg, x, u)
+        assert np.abs(d[7:10] - R @ mu).max() <= 1e-13 and np.abs(np.delete(d, [7, 8, 9])).max() == 0.0
+        phi, A, B = qoracle.rk4_sens(cg, x, u, 0.1)
+        h = 1e-6
+        for i in range(QNX):
+            e = np.zeros(QNX); e[i] = h
+            np.testing.assert_allclose(A[:, i], (qoracle.rk4_sens(cg, x + e, u, 0.1)[0] - qoracle.rk4_sens(cg, x - e, u, 0.1)[0]) / (2 * h), atol=5e-8)
+        for j in range(QNU):
+            e = np.zeros(QNU); e[j] = h
+            np.testing.assert_allclose(B[:, j], (qoracle.rk4_sens(cg, x, u + e, 0.1)[0] - qoracle.rk4_sens(cg, x, u - e, 0.1)[0]) / (2 * h), atol=5e-8)
+    with pytest.raises(ValueError):
+        set_quad_gp(default_quad_config(), [dict(feat=2, out=7, Z=[0.0], alpha=[0.0], length_scale=1.0)])      # position is not an offered feature
