@@ -56,6 +56,7 @@ class AdmpcConfig(C.Structure):
         ("ipm_tol_step", C.c_double),
         ("ipm_try_unconstrained", C.c_double),
         ("ipm_warm_thr", C.c_double),
+        ("ipm_warm_restart", C.c_double),
         ("sqp_tol", C.c_double),
         ("gp", AdmpcGp * GP_MAX),
     ]
@@ -97,6 +98,7 @@ IPM_ITER_MAX = 50
 IPM_MU0 = 1.0
 IPM_THR0 = 0.1
 IPM_WARM_THR = 0.01
+IPM_WARM_RESTART = 0.1
 IPM_TOL_COMP = 1e-10
 IPM_TOL_RES = 1e-9
 IPM_TOL_STEP = 1e-6
@@ -127,6 +129,7 @@ def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TER
     c.ipm_tol_comp, c.ipm_tol_res, c.ipm_tol_step = IPM_TOL_COMP, IPM_TOL_RES, IPM_TOL_STEP
     c.ipm_try_unconstrained = 1.0
     c.ipm_warm_thr = IPM_WARM_THR
+    c.ipm_warm_restart = IPM_WARM_RESTART
     return c
 
 

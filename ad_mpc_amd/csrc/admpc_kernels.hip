@@ -835,7 +835,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const double tol_comp = cfg->ipm_tol_comp, tol_res = cfg->ipm_tol_res, tol_step = cfg->ipm_tol_step;
     const int itmax = cfg->ipm_iter_max;
     const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
-    const double thw = cfg->ipm_warm_thr;
+    const double thw = cfg->ipm_warm_thr, wrest = cfg->ipm_warm_restart;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
     // Factorisation of the Newton matrix M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) into L D L' (LDS: Lp, invd).
     // Used twice per instance at most: once without barrier terms (the unconstrained trial) and once per interior-point iteration.
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         // (H + R) du = -g0 is one factorisation and one solve (about 0.6 of an interior-point iteration).  If that minimiser
         // respects the input box and the steering box it is the solution of the full QP -- no bound is active, the slacks are
         // zero -- and the interior point is skipped (iters = 0).  True for 55 % of the config-2 scenarios; the oracle does the same.
-        bool solved = false;
+        bool solved = false, warmed = false;
         if (try_unc) {
             int lt = lane; asm volatile("" : "+v"(lt));
             factorise(uact ? Rj : 1.0, 0.0, lt);
@@ -978,6 +978,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             else if (thw > 0.0) {
                 // warm start (cfg.ipm_warm_thr): the interior point starts from that minimiser.  A violated input bound is absorbed
                 // by its slack (the input box is soft), a violated steering bound stays as a primal residual.
+                warmed = true;
                 du = duc;
                 sl = fmax(dl_i - duc, 0.0) + thw; su = fmax(duc - duu_i, 0.0) + thw;
                 const double r0[4] = { duc + sl - dl_i, su + duu_i - duc, sl, su };
@@ -1135,6 +1136,21 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 } else {
                     double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
                     const double alpha = fmin(tau * amax, 1.0);
+                    if (it == 0 && warmed && alpha < wrest) {
+                        // the first step from the warm start is blocked (cfg.ipm_warm_restart): start over from the cold start; the
+                        // iteration counts.  Wave-uniform (alpha is).
+                        warmed = false;
+                        const double dlc = PK_DL, duc2 = PK_DUU;
+                        du = 0.0; sl = thr; su = thr;
+                        const double r0[4] = { thr - dlc, thr + duc2, thr, thr };
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
+                        dx6 = dact ? xh6_own : 0.0;
+                        const double q0[2] = { dx6 - PK_DDL, PK_DDU - dx6 };
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { Dt[i] = dact ? (q0[i] > thr ? q0[i] : thr) : 1.0; Dlam[i] = dact ? mu0 * rcp_nr(Dt[i]) : 0.0; }
+                        alpha_prev = 1.0; stp_local = 1e300;
+                    } else {
                     alpha_prev = alpha;
                     stp_local = uact ? fabs(alpha * ddu) : 0.0;
                     // idle lanes carry harmless finite values (their steps are computed from finite data)
@@ -1147,6 +1163,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                         Dlam[i] = dact ? fmax(Dlam[i] + alpha * Ddlam[i], IPM_FLOOR) : 1.0;
                     }
                     dx6 += dact ? alpha * ddx6 : 0.0;
+                    }
                 }
                 WSYNC();
             }
@@ -1693,7 +1710,7 @@ int admpc_default_config(AdmpcConfig* c, int N, double Ts)
     c->Iz = c->L_F * c->L_R * (r_mass + f_mass);
     c->Cf = f_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195; c->Cr = r_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195;
     c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9; c->ipm_tol_step = 1e-6;
-    c->ipm_try_unconstrained = 1.0; c->ipm_warm_thr = 0.01;
+    c->ipm_try_unconstrained = 1.0; c->ipm_warm_thr = 0.01; c->ipm_warm_restart = 0.1;
     return ADMPC_OK;
 }
 
@@ -1712,7 +1729,7 @@ static int validate(const AdmpcConfig* c)
     if (!(c->W[NX] > 0 && c->W[NX + 1] > 0)) return fail(ADMPC_EINVAL, "input weights must be positive (strict convexity)");
     if (c->ipm_iter_max < 1) return fail(ADMPC_EINVAL, "ipm_iter_max < 1");
     if (!(c->sqp_tol >= 0)) return fail(ADMPC_EINVAL, "sqp_tol must be >= 0");
-    if (!(c->ipm_mu0 > 0) || !(c->ipm_thr0 > 0) || !(c->ipm_warm_thr >= 0)) return fail(ADMPC_EINVAL, "ipm_mu0, ipm_thr0 must be > 0 and ipm_warm_thr >= 0");
+    if (!(c->ipm_mu0 > 0) || !(c->ipm_thr0 > 0) || !(c->ipm_warm_thr >= 0) || !(c->ipm_warm_restart >= 0 && c->ipm_warm_restart < 1)) return fail(ADMPC_EINVAL, "ipm_mu0, ipm_thr0 must be > 0, ipm_warm_thr >= 0, ipm_warm_restart in [0, 1)");
     return ADMPC_OK;
 }
 

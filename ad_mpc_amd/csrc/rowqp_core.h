@@ -76,6 +76,7 @@ struct RqParams {              // wave-uniform scalars
     T floor_;                  // lower clamp of t, lam
     T sqp_tol;                 // > 0 in SQP mode with a tolerance: finish() reports convergence of the outer iteration
     T blocked;                 // centring safeguard: step length below which the next iteration centres (ADMPC_IPM_BLOCKED_STEP)
+    T wrest;                   // a warm start whose first step is shorter than this is abandoned for the cold start (0: never)
 };
 
 template <class T>
@@ -101,6 +102,7 @@ struct RowQp {
     Lds lds;
     const int N;
     M owns;                    // the row works on an instance of its own (rows that only shadow another row's instance never write its workspace)
+    M wrows;                   // rows whose LDS records / workspace may be written right now (all, except while single rows are re-initialised)
 
     // ---- lane constants -------------------------------------------------------------------------------------------
     I lane;
@@ -123,6 +125,7 @@ struct RowQp {
     // inst: index of the row's instance (row-uniform); owns_: it is this row's own instance
     RQ_FN RowQp(const RqParams<T>& q_, const RqArrays<T>& io_, Lds lds_, I inst, M owns_) : q(q_), io(io_), lds(lds_), N(q_.N), owns(owns_)
     {
+        wrows = X::mtrue();
         ix0 = inst * 7; iye = ix0; iyr = inst * (N * 9); igt = inst * (N * RQ_GTS); ibl = inst * (N * 7); ixb = inst * ((N + 1) * 7);
         iub = inst * (N * 2); iws = inst * ((N + 1) * RQ_RW); ipi = ixb; iiq = inst * (N * 20);
         lane = X::lane();
@@ -180,16 +183,16 @@ struct RowQp {
 
     // ---- small helpers ----------------------------------------------------------------------------------------------
     RQ_FN V ld(I off, int imm) { return X::lds_ld(lds, off, imm); }
-    RQ_FN void st(I off, int imm, V v, M m) { X::lds_st(lds, off, imm, v, m); }
+    RQ_FN void st(I off, int imm, V v, M m) { X::lds_st(lds, off, imm, v, m & wrows); }
     RQ_FN static V fma(V a, V b, V c) { return X::fma(a, b, c); }
     RQ_FN static int rec(int k) { return RQ_HDR + k * RQ_RS; }
     // workspace: written by one sweep / pass and read back by a later one of the same wave -> accessors of their own (the device
     // reads it past the CU's L1, whose lines do not follow the wave's own stores)
     RQ_FN V wld(I off, int imm) { return X::wld(io.ws, iws + off + imm); }
     // masked-off lanes store into the unused gain slots of record 0 (there is no stage -1): no EXEC branch around the store
-    RQ_FN void wst(I off, int imm, V v, M m) { X::wst(io.ws, iws + off + imm, iws + lane + RW_KK, v, m & owns); }
+    RQ_FN void wst(I off, int imm, V v, M m) { X::wst(io.ws, iws + off + imm, iws + lane + RW_KK, v, m & owns & wrows); }
     RQ_FN void wld2(I off, int imm, V& a, V& b) { X::wld2(io.ws, iws + off + imm, a, b); }      // two consecutive values (even offset)
-    RQ_FN void wst2(I off, int imm, V a, V b, M m) { X::wst2(io.ws, iws + off + imm, iws + (lane & 7) * 2 + RW_KK, a, b, m & owns); }
+    RQ_FN void wst2(I off, int imm, V a, V b, M m) { X::wst2(io.ws, iws + off + imm, iws + (lane & 7) * 2 + RW_KK, a, b, m & owns & wrows); }
 
     // column layout of stage k: Gc[l] = G[l][c] for the lane's column c (rows 0..5)
     RQ_FN void load_gc(int k, V Gc[6]) { X::gld6(io.GT, igt + o_gc + k * RQ_GTS, Gc); }
@@ -743,7 +746,7 @@ struct RowQp {
         sweep_rollout(false);
         X::fence();
         X::stamp(1);
-        M active = valid, failed = X::mfalse();
+        M active = valid, failed = X::mfalse(), warmrow = X::mfalse();
         I iters = X::isplat(0);
         V rstat;                                                   // stationarity residual of the interior point's iterate (tracked)
         pass_trial_setup();
@@ -758,6 +761,7 @@ struct RowQp {
             const V a0 = X::sel(ok | warm, one, zero);
             rstat = pass_init(a0, X::sel(warm, splat(q.thw), splat(q.thr)), warm, ok);
             active = active & !ok;
+            warmrow = warm;
             X::stamp(2);
         } else {
             rstat = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());
@@ -813,15 +817,39 @@ struct RowQp {
             X::stamp(10);
             const V amax = X::sel(rc > one, X::rcp(rc), one);
             V tau = one - mu_aff; tau = X::vmax(tau, splat((T)0.995)); tau = X::vmin(tau, splat((T)0.999999));
-            const V alpha = X::sel(active, X::vmin(tau * amax, one), zero);
+            const V alpha0 = X::sel(active, X::vmin(tau * amax, one), zero);
+            // a warm start whose very first step is blocked (cfg.ipm_warm_restart) is abandoned: the row starts over from the cold
+            // start (zero input step, rolled-out states), the iteration counts.  From a minimiser far outside the hard steering
+            // box the method otherwise creeps for ten iterations (N = 80: 24 iterations warm, 17 cold)
+            M rst = X::mfalse();
+            if (guard == 0 && q.wrest > (T)0) rst = active & warmrow & (alpha0 < splat(q.wrest));
+            const M upd = active & !rst;
+            const V alpha = X::sel(rst, zero, alpha0);
             RQ_DBG("[emu]      alpha=%.6e\n", X::first(alpha));
-            const V stn = pass_e3b_e1(smu, alpha, active, R);
+            const V stn = pass_e3b_e1(smu, alpha, upd, R);
             X::fence();
             X::stamp(11);
-            step = X::sel(active, stn, step);
-            alpha_prev = X::sel(active, alpha, alpha_prev);
-            rstat = X::sel(active, (one - alpha) * rstat, rstat);
+            step = X::sel(upd, stn, step);
+            alpha_prev = X::sel(upd, alpha, alpha_prev);
+            rstat = X::sel(upd, (one - alpha) * rstat, rstat);
             iters = iters + X::isel(active, X::isplat(1), X::isplat(0));
+            if (X::any(rst)) {
+                wrows = rst;                                        // only the records of the restarting rows are rewritten
+                sweep_rollout(false);
+                X::fence();
+                pass_trial_setup();
+                X::fence();
+                const V rs0 = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());
+                X::fence();
+                Red R2;
+                pass_e1(R2);
+                X::fence();
+                wrows = X::mtrue();
+                R.mu = X::sel(rst, R2.mu, R.mu); R.cmax = X::sel(rst, R2.cmax, R.cmax); R.rmax = X::sel(rst, R2.rmax, R.rmax);
+                rstat = X::sel(rst, rs0, rstat);
+                step = X::sel(rst, splat((T)1e30), step);
+                alpha_prev = X::sel(rst, one, alpha_prev);
+            }
         }
         res.failed = failed; res.iters = iters; res.rmax = rmax_last;
         // ---- H6: expand the states from the input step through the linearised dynamics (as acados' expand step)
@@ -915,5 +943,6 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     q.big = f32 ? (T)1e30 : (T)1e300;
     q.floor_ = f32 ? (T)1e-8 : (T)1e-40;
     q.blocked = (T)ADMPC_IPM_BLOCKED_STEP;
+    q.wrest = (T)c.ipm_warm_restart;
     q.sqp_tol = (T)((c.sqp_iters > 1 && c.sqp_tol > 0) ? (f32 && c.sqp_tol < 1e-4 ? 1e-4 : c.sqp_tol) : 0.0);
 }

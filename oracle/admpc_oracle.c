@@ -422,14 +422,11 @@ static real ipm_max_step(const StageQP* qp, const IpmState* s, const IpmWork* w)
     return a;
 }
 
-/* Mehrotra predictor-corrector primal-dual IPM in residual (Newton-step) form.
- * returns number of IPM iterations, negative on numerical failure */
-static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWork* w, RicFactor* F)
+/* cold start (qp_solver_warm_start 0, sim_car_acados_ocp.json:885): zero step, slacks at thr */
+static void ipm_cold_start(const AdmpcConfig* c, const StageQP* qp, IpmState* s)
 {
     const int N = qp->N;
-    const int n_ineq = 8 * N + 2 * (N - 1);
     const real thr = c->ipm_thr0, mu0 = c->ipm_mu0;
-    /* cold start (qp_solver_warm_start 0, sim_car_acados_ocp.json:885): zero step, slacks at thr */
     memset(s, 0, sizeof *s);
     /* primal start: zero input step, states rolled out through the linearised dynamics, so every
      * iterate satisfies dx[k+1] = A dx[k] + B du[k] + b up to rounding */
@@ -452,6 +449,17 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             for (int i = 0; i < 2; ++i) { s->td[k][i] = r0[i] > thr ? r0[i] : thr; s->lamd[k][i] = mu0 / s->td[k][i]; }
         }
     }
+}
+
+/* Mehrotra predictor-corrector primal-dual IPM in residual (Newton-step) form.
+ * returns number of IPM iterations, negative on numerical failure */
+static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWork* w, RicFactor* F)
+{
+    const int N = qp->N;
+    const int n_ineq = 8 * N + 2 * (N - 1);
+    const real mu0 = c->ipm_mu0;
+    int warmed = 0;                      /* the interior point starts from the trial's minimiser (cfg.ipm_warm_thr) */
+    ipm_cold_start(c, qp, s);
     if (c->ipm_try_unconstrained != 0) {
         /* Newton step of the QP WITHOUT its inequalities from the start point (du = 0, rolled-out dx, pi = 0): the exact
          * minimiser of the equality-constrained QP.  If it respects the input box and the delta box it is the solution of
@@ -485,6 +493,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             return 0;
         }
         if (c->ipm_warm_thr > 0) {
+            warmed = 1;
             /* warm start (cfg.ipm_warm_thr): the interior point starts from that minimiser instead of from the zero step.
              * Inputs, states and dynamics multipliers are the minimiser's; a violated input bound is absorbed by its slack
              * (the bounds are soft), a violated delta bound is left as a primal residual (residual form of the method). */
@@ -552,6 +561,13 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         real a_max = ipm_max_step(qp, s, w);
         real tau = 1 - mu_aff; if (tau < (real)0.995) tau = (real)0.995; if (tau > (real)0.999999) tau = (real)0.999999;
         real alpha = tau * a_max; if (alpha > 1) alpha = 1;
+        if (it == 0 && warmed && alpha < (real)c->ipm_warm_restart) {
+            /* the first step from the warm start is blocked (cfg.ipm_warm_restart): start over from the cold start; the iteration counts */
+            warmed = 0;
+            ipm_cold_start(c, qp, s);
+            alpha_prev = 1; step = 1e300; rmax_prev = 0;
+            continue;
+        }
         alpha_prev = alpha;
         step = 0;
         for (int k = 0; k < N; ++k) {

@@ -62,6 +62,30 @@ def test_emulated_kernel_randomised_problem_data(emu, oracle):
             _strict(*_both(emu, oracle, cfg, s), 1e-8 if N <= 32 else 1e-7)
 
 
+def test_emulated_kernel_abandons_a_blocked_warm_start(emu, oracle):
+    """cfg.ipm_warm_restart: (a) forced (0.99: most warm starts is abandoned after its first step) on short and long horizons;
+    (b) the default 0.1 on the N = 80 instances it exists for -- they restart (the oracle needs fewer iterations than with the rule
+    off) and the emulated kernel follows iteration for iteration."""
+    for N, B in ((20, 48), (40, 24)):
+        c = default_config(N=N); c.ipm_warm_restart = 0.99
+        s = random_scenarios(B, N=N, seed=21, blend=(3.0, 5.0))
+        g, o = _both(emu, oracle, c, s)
+        off = default_config(N=N); off.ipm_warm_restart = 0.0
+        assert (oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])[4] != o[4]).sum() >= 5   # the rule really fires
+        _strict(g, o, 1e-8 if N <= 32 else 1e-7)
+    N = 80
+    s = random_scenarios(2048, N=N, seed=1234)
+    idx = [107, 119, 223, 924, 103, 5]
+    s = {k: v[idx] for k, v in s.items()}
+    c = default_config(N=N); off = c.copy(); off.ipm_warm_restart = 0.0
+    assert c.ipm_warm_restart == 0.1
+    g, o = _both(emu, oracle, c, s)
+    slow = oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert (o[4] <= slow[4] + 1).all() and (o[4][:4] < slow[4][:4]).sum() >= 3 and slow[4].max() >= 21 and o[4].max() <= 19
+    assert np.abs(o[1] - slow[1]).max() <= 1e-8                      # the same minimiser either way
+    _strict(g, o, 1e-7)
+
+
 def test_emulated_kernel_active_slacks_steering_bound_and_failure(emu, oracle):
     cfg = default_config()
     x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
