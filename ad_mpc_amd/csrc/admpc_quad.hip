@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             double amax = ratio();
             const double muaff = wave_sum(act ? (tl + amax * dtl) * (ll + amax * dll) + (tu + amax * dtu) * (lu + amax * dlu) : 0.0) / (2.0 * n);
             double sigma = muaff / mu; sigma = sigma * sigma * sigma;
-            if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;
+            if (alpha_prev < ADMPC_QUAD_IPM_BLOCKED_STEP) sigma = 1.0;
             const double smu = sigma * mu;
             const double cl = act ? (smu - dtl * dll) / tl : 0.0, cu = act ? (smu - dtu * dlu) / tu : 0.0;
             const double d = solve(act ? -rs + (cl - ll - Dl * rl) - (cu - lu - Du * ru) : 0.0);

@@ -233,7 +233,7 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
         for (int i = 0; i < n; ++i) muaff += (tl[i] + amax * dtl[i]) * (ll[i] + amax * dll[i]) + (tu[i] + amax * dtu[i]) * (lu[i] + amax * dlu[i]);
         muaff /= 2 * n;
         real sigma = muaff / mu; sigma = sigma * sigma * sigma;
-        if (alpha_prev < 0.05) sigma = 1;                                     /* blocked step: centre (ADMPC_IPM_BLOCKED_STEP of admpc.h) */
+        if (alpha_prev < ADMPC_QUAD_IPM_BLOCKED_STEP) sigma = 1;              /* blocked step: centre (admpc_quad.h) */
         const real smu = sigma * mu;
         /* corrector: complementarity target  sigma mu - dt_aff dlam_aff */
         real d[NMAX], cl[NMAX], cu[NMAX];

@@ -46,7 +46,7 @@ def test_quad_shooting_against_the_reference_golden_vectors(qeng):
             assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("N,B", [(10, 257), (5, 64), (16, 40)])
+@pytest.mark.parametrize("N,B", [(10, 257), (10, 2048), (5, 64), (16, 40)])
 def test_quad_solve_parity_with_oracle(qoracle, N, B):
     """One RTI step per instance: identical status and interior-point iteration counts, inputs and states within 1e-8, cost 1e-9
     relative; saturated inputs in the batch; x_0 pinned; inputs inside the box."""

@@ -95,6 +95,23 @@ def test_batch_solve_statuses_and_failure(qoracle):
     assert (st2 == 0).all() and (cost2 <= cost[ok] * (1 + 1e-9) + 1e-12).mean() >= 0.7
 
 
+def test_no_limit_cycle_on_aggressive_scenarios(qoracle):
+    """ADMPC_QUAD_IPM_BLOCKED_STEP: instance 1540 of this batch cycled until iter_max with the car solver's threshold (0.05) and came
+    back 0.09 away from the minimiser; now every instance converges well before iter_max and the former cycler agrees with the exact
+    active-set solution."""
+    from scipy.optimize import lsq_linear
+    cfg = default_quad_config()
+    s = random_quad_scenarios(2048, cfg, seed=1)
+    x, u, cost, st, it = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    assert (st == 0).all() and it.max() <= 20
+    b = 1540
+    d = qoracle.qp_debug(cfg, s["x0"][b], s["yref"][b], s["yref_e"][b], s["xbar"][b], s["ubar"][b])
+    lo = -s["ubar"][b].reshape(-1); hi = 1 - s["ubar"][b].reshape(-1)
+    Lc = np.linalg.cholesky(d["H"])
+    r = lsq_linear(Lc.T, -np.linalg.solve(Lc, d["g"]), bounds=(lo, hi), method="bvls", tol=1e-14, max_iter=2000)
+    assert np.abs((d["u"] - s["ubar"][b]).reshape(-1) - r.x).max() <= 1e-6
+
+
 def quad_gps(seed=1):
     """Three residual GPs of the body-frame acceleration: v_bx -> a_bx, (v_by, u_0) -> a_by with two length scales, v_bz -> a_bz."""
     rng = np.random.default_rng(seed)
