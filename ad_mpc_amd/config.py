@@ -57,6 +57,7 @@ class AdmpcConfig(C.Structure):
         ("ipm_try_unconstrained", C.c_double),
         ("ipm_warm_thr", C.c_double),
         ("ipm_warm_restart", C.c_double),
+        ("ipm_fallback_iter", C.c_double),
         ("sqp_tol", C.c_double),
         ("gp", AdmpcGp * GP_MAX),
     ]
@@ -99,6 +100,7 @@ IPM_MU0 = 1.0
 IPM_THR0 = 0.1
 IPM_WARM_THR = 0.01
 IPM_WARM_RESTART = 0.1
+IPM_FALLBACK_ITER = 25.0
 IPM_TOL_COMP = 1e-10
 IPM_TOL_RES = 1e-9
 IPM_TOL_STEP = 1e-6
@@ -130,6 +132,7 @@ def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TER
     c.ipm_try_unconstrained = 1.0
     c.ipm_warm_thr = IPM_WARM_THR
     c.ipm_warm_restart = IPM_WARM_RESTART
+    c.ipm_fallback_iter = IPM_FALLBACK_ITER
     return c
 
 

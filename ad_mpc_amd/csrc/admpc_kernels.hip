@@ -836,6 +836,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
     const int itmax = cfg->ipm_iter_max;
     const bool try_unc = cfg->ipm_try_unconstrained != 0.0;
     const double thw = cfg->ipm_warm_thr, wrest = cfg->ipm_warm_restart;
+    const int fbit = (int)cfg->ipm_fallback_iter;
     const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
     // Factorisation of the Newton matrix M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) into L D L' (LDS: Lp, invd).
     // Used twice per instance at most: once without barrier terms (the unconstrained trial) and once per interior-point iteration.
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
         // (H + R) du = -g0 is one factorisation and one solve (about 0.6 of an interior-point iteration).  If that minimiser
         // respects the input box and the steering box it is the solution of the full QP -- no bound is active, the slacks are
         // zero -- and the interior point is skipped (iters = 0).  True for 55 % of the config-2 scenarios; the oracle does the same.
-        bool solved = false, warmed = false;
+        bool solved = false, warmed = false, cons = false;
         if (try_unc) {
             int lt = lane; asm volatile("" : "+v"(lt));
             factorise(uact ? Rj : 1.0, 0.0, lt);
@@ -993,8 +994,21 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
             }
         }
         PHASE_STAMP(8);
+        // the cold start of the interior point, in place (wave-uniform callers): cfg.ipm_warm_restart and cfg.ipm_fallback_iter
+        auto cold_start = [&]() __attribute__((always_inline)) {
+            const double dlc = PK_DL, duc2 = PK_DUU;
+            du = 0.0; sl = thr; su = thr;
+            const double r0[4] = { thr - dlc, thr + duc2, thr, thr };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
+            dx6 = dact ? xh6_own : 0.0;
+            const double q0[2] = { dx6 - PK_DDL, PK_DDU - dx6 };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { Dt[i] = dact ? (q0[i] > thr ? q0[i] : thr) : 1.0; Dlam[i] = dact ? mu0 * rcp_nr(Dt[i]) : 0.0; }
+            alpha_prev = 1.0; stp_local = 1e300;
+        };
         if (!solved)
-        for (; it < itmax; ++it) {
+        for (; it < itmax + (cons ? fbit : 0); ++it) {
             int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
             asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops (hipcc parked ~200 of them in scratch)
             const int trz = lz * (lz + 1) / 2;
@@ -1054,6 +1068,15 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
                 if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
                 rmax_prev = rmax;
+            }
+            if (fbit > 0 && !cons && it >= fbit) {
+                // cfg.ipm_fallback_iter: still iterating, most likely in a limit cycle of the centring heuristic.  Start over and finish
+                // with plain predictor-centring steps (no second-order term) on a budget of its own; this pass is redone from the cold start.
+                cons = true; warmed = false;
+                cold_start();
+                rmax_prev = 0.0;
+                --it;
+                continue;
             }
             PHASE_STAMP(1);
             // ---- Newton matrix row: M = H + diag(R + barrier) + h^2 S_{max(k,k')} on the u1 x u1 block, then its factorisation
@@ -1129,10 +1152,17 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     double sigma = mu_aff * rcp_nr(mu); sigma = sigma * sigma * sigma;
                     if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;      // centring safeguard (admpc.h)
                     const double smu = sigma * mu;
+                    if (!cons) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
+                        for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] + Ddt[i] * Ddlam[i] - smu;
+                        for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] + Ddt[i] * Ddlam[i] - smu;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] - smu;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] - smu;
+                    }
                 } else {
                     double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
                     const double alpha = fmin(tau * amax, 1.0);
@@ -1140,16 +1170,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                         // the first step from the warm start is blocked (cfg.ipm_warm_restart): start over from the cold start; the
                         // iteration counts.  Wave-uniform (alpha is).
                         warmed = false;
-                        const double dlc = PK_DL, duc2 = PK_DUU;
-                        du = 0.0; sl = thr; su = thr;
-                        const double r0[4] = { thr - dlc, thr + duc2, thr, thr };
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
-                        dx6 = dact ? xh6_own : 0.0;
-                        const double q0[2] = { dx6 - PK_DDL, PK_DDU - dx6 };
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) { Dt[i] = dact ? (q0[i] > thr ? q0[i] : thr) : 1.0; Dlam[i] = dact ? mu0 * rcp_nr(Dt[i]) : 0.0; }
-                        alpha_prev = 1.0; stp_local = 1e300;
+                        cold_start();
                     } else {
                     alpha_prev = alpha;
                     stp_local = uact ? fabs(alpha * ddu) : 0.0;
@@ -1710,7 +1731,7 @@ int admpc_default_config(AdmpcConfig* c, int N, double Ts)
     c->Iz = c->L_F * c->L_R * (r_mass + f_mass);
     c->Cf = f_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195; c->Cr = r_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195;
     c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9; c->ipm_tol_step = 1e-6;
-    c->ipm_try_unconstrained = 1.0; c->ipm_warm_thr = 0.01; c->ipm_warm_restart = 0.1;
+    c->ipm_try_unconstrained = 1.0; c->ipm_warm_thr = 0.01; c->ipm_warm_restart = 0.1; c->ipm_fallback_iter = 25.0;
     return ADMPC_OK;
 }
 
@@ -1729,7 +1750,7 @@ static int validate(const AdmpcConfig* c)
     if (!(c->W[NX] > 0 && c->W[NX + 1] > 0)) return fail(ADMPC_EINVAL, "input weights must be positive (strict convexity)");
     if (c->ipm_iter_max < 1) return fail(ADMPC_EINVAL, "ipm_iter_max < 1");
     if (!(c->sqp_tol >= 0)) return fail(ADMPC_EINVAL, "sqp_tol must be >= 0");
-    if (!(c->ipm_mu0 > 0) || !(c->ipm_thr0 > 0) || !(c->ipm_warm_thr >= 0) || !(c->ipm_warm_restart >= 0 && c->ipm_warm_restart < 1)) return fail(ADMPC_EINVAL, "ipm_mu0, ipm_thr0 must be > 0, ipm_warm_thr >= 0, ipm_warm_restart in [0, 1)");
+    if (!(c->ipm_mu0 > 0) || !(c->ipm_thr0 > 0) || !(c->ipm_warm_thr >= 0) || !(c->ipm_warm_restart >= 0 && c->ipm_warm_restart < 1) || !(c->ipm_fallback_iter >= 0 && c->ipm_fallback_iter <= 1e6)) return fail(ADMPC_EINVAL, "ipm_mu0, ipm_thr0 must be > 0, ipm_warm_thr >= 0, ipm_warm_restart in [0, 1), ipm_fallback_iter in [0, 1e6]");
     return ADMPC_OK;
 }
 

@@ -77,6 +77,7 @@ struct RqParams {              // wave-uniform scalars
     T sqp_tol;                 // > 0 in SQP mode with a tolerance: finish() reports convergence of the outer iteration
     T blocked;                 // centring safeguard: step length below which the next iteration centres (ADMPC_IPM_BLOCKED_STEP)
     T wrest;                   // a warm start whose first step is shorter than this is abandoned for the cold start (0: never)
+    int fbit;                  // fallback: a row still iterating after this many iterations restarts without the second-order term (0: never)
 };
 
 template <class T>
@@ -103,6 +104,7 @@ struct RowQp {
     const int N;
     M owns;                    // the row works on an instance of its own (rows that only shadow another row's instance never write its workspace)
     M wrows;                   // rows whose LDS records / workspace may be written right now (all, except while single rows are re-initialised)
+    V w2;                      // weight of the second-order corrector term of the row: 1, or 0 in fallback mode (cfg.ipm_fallback_iter)
 
     // ---- lane constants -------------------------------------------------------------------------------------------
     I lane;
@@ -539,7 +541,7 @@ struct RowQp {
             rr = X::vmax(rr, X::sel(S.act, r, zero));
             const V mb = P.dtb * P.dlb, ms = X::sel(e_isd, zero, P.dts * P.dls);
             s2 = s2 + X::sel(S.act, mb + ms, zero);
-            const V mbi = mb * B.itb, msi = ms * B.its;
+            const V mbi = w2 * mb * B.itb, msi = w2 * ms * B.its;      // second-order term of the corrector (dropped in fallback mode)
             const V P1 = mbi - B.Gb * B.is * (mbi + msi);
             const V P2 = B.itb - B.Gb * B.is * (B.itb + B.its);
             const V pa = X::sel(S.act, sgn * (B.psi + P1), zero), pb = X::sel(S.act, sgn * P2, zero);
@@ -557,7 +559,7 @@ struct RowQp {
         const V zero = splat((T)0);
         const V uua = sgn * S.sa, uu = sgn * S.sc;
         Step P; side_step_pred(S, B, uua, P);
-        const V mb = P.dtb * P.dlb, ms = P.dts * P.dls;
+        const V mb = w2 * (P.dtb * P.dlb), ms = w2 * (P.dts * P.dls);
         const V cb = (mb - smu) * B.itb, cs = X::sel(e_isd, zero, (ms - smu) * B.its);
         const V ec = B.e + cb + cs;
         const V ds = -((ec + B.Gb * uu) * B.is);
@@ -738,6 +740,27 @@ struct RowQp {
     // =================================================================================================================
     struct Result { M failed; I iters; V rmax; };
 
+    // The rows of `rows` start over from the cold start (zero input step, rolled-out states, slacks at thr); the other rows of the wave
+    // keep their records bit for bit (write mask).  Leaves the quantities of the next iteration (R, rstat, step, alpha_prev) for them.
+    RQ_FN void restart_cold(M rows, Red& R, V& rstat, V& step, V& alpha_prev) {
+        const V zero = splat((T)0);
+        wrows = rows;
+        sweep_rollout(false);
+        X::fence();
+        pass_trial_setup();
+        X::fence();
+        const V rs0 = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());
+        X::fence();
+        Red R2;
+        pass_e1(R2);
+        X::fence();
+        wrows = X::mtrue();
+        R.mu = X::sel(rows, R2.mu, R.mu); R.cmax = X::sel(rows, R2.cmax, R.cmax); R.rmax = X::sel(rows, R2.rmax, R.rmax);
+        rstat = X::sel(rows, rs0, rstat);
+        step = X::sel(rows, splat((T)1e30), step);
+        alpha_prev = X::sel(rows, splat((T)1), alpha_prev);
+    }
+
     // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the multipliers of the returned iterate
     // (io.pi, io.ineq) on the rows of pim.
     RQ_FN void solve(M valid, Result& res, bool want_pi, M pim) {
@@ -772,11 +795,13 @@ struct RowQp {
         X::fence();
         X::stamp(3);
         V step = splat((T)1e30), rmax_prev = zero, rmax_last = zero, alpha_prev = one;
+        M cons = X::mfalse();                                      // rows in fallback mode
+        w2 = one;
         RQ_NOUNROLL
-        for (int guard = 0; guard <= q.itmax; ++guard) {
+        for (int guard = 0; guard <= q.itmax + q.fbit; ++guard) {
             // every linear residual of a Newton iteration in residual form shrinks by (1 - alpha) per step; the inequality rows are
             // re-evaluated (R.rmax), the stationarity rows (which would need the dynamics multipliers) are tracked: rstat
-            const V mu = R.mu * splat(q.inv_nineq);
+            V mu = R.mu * splat(q.inv_nineq);
             const V rmax = X::vmaxnan(R.rmax, rstat);
             const M nan = (!(mu == mu)) | (!(rmax == rmax));
             failed = failed | (active & nan);
@@ -785,8 +810,20 @@ struct RowQp {
                            ((rmax <= splat(q.tol_res)) | (X::mfrom(guard > 0) & (rmax > splat((T)0.1) * rmax_prev)));
             rmax_last = X::sel(active, rmax, rmax_last);
             rmax_prev = rmax;
-            active = active & !conv & (iters < q.itmax);
+            active = active & !conv & (iters < X::isel(cons, X::isplat(q.itmax + q.fbit), X::isplat(q.itmax)));
             if (!X::any(active)) break;
+            if (q.fbit > 0) {
+                // cfg.ipm_fallback_iter: a row that is still iterating has most likely fallen into a limit cycle of the centring
+                // heuristic: it starts over and finishes with plain predictor-centring steps (no second-order term), on a budget of its own
+                const M fb = active & !cons & (iters >= q.fbit);
+                if (X::any(fb)) {
+                    restart_cold(fb, R, rstat, step, alpha_prev);
+                    cons = cons | fb;
+                    w2 = X::sel(cons, zero, one);
+                    warmrow = warmrow & !fb;
+                    mu = R.mu * splat(q.inv_nineq);
+                }
+            }
             // ---- predictor
             X::stamp(4);
             sweep_factor();
@@ -833,23 +870,7 @@ struct RowQp {
             alpha_prev = X::sel(upd, alpha, alpha_prev);
             rstat = X::sel(upd, (one - alpha) * rstat, rstat);
             iters = iters + X::isel(active, X::isplat(1), X::isplat(0));
-            if (X::any(rst)) {
-                wrows = rst;                                        // only the records of the restarting rows are rewritten
-                sweep_rollout(false);
-                X::fence();
-                pass_trial_setup();
-                X::fence();
-                const V rs0 = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());
-                X::fence();
-                Red R2;
-                pass_e1(R2);
-                X::fence();
-                wrows = X::mtrue();
-                R.mu = X::sel(rst, R2.mu, R.mu); R.cmax = X::sel(rst, R2.cmax, R.cmax); R.rmax = X::sel(rst, R2.rmax, R.rmax);
-                rstat = X::sel(rst, rs0, rstat);
-                step = X::sel(rst, splat((T)1e30), step);
-                alpha_prev = X::sel(rst, one, alpha_prev);
-            }
+            if (X::any(rst)) restart_cold(rst, R, rstat, step, alpha_prev);
         }
         res.failed = failed; res.iters = iters; res.rmax = rmax_last;
         // ---- H6: expand the states from the input step through the linearised dynamics (as acados' expand step)
@@ -944,5 +965,6 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     q.floor_ = f32 ? (T)1e-8 : (T)1e-40;
     q.blocked = (T)ADMPC_IPM_BLOCKED_STEP;
     q.wrest = (T)c.ipm_warm_restart;
+    q.fbit = (int)c.ipm_fallback_iter;
     q.sqp_tol = (T)((c.sqp_iters > 1 && c.sqp_tol > 0) ? (f32 && c.sqp_tol < 1e-4 ? 1e-4 : c.sqp_tol) : 0.0);
 }

@@ -115,6 +115,12 @@ typedef struct AdmpcConfig {
                                 * box the method otherwise creeps for about ten blocked steps (N = 80: the slowest instances take
                                 * 24 iterations warm, 17 cold; no instance of the N = 20 / 40 batches is affected).  Default 0.1;
                                 * 0: never. */
+    double  ipm_fallback_iter; /* an instance that is still iterating after this many interior-point iterations has most likely fallen
+                                * into a limit cycle of Mehrotra's heuristic (seen on about 1 in 20 000 long-horizon scenarios: mu
+                                * cycling with period 4 around 1e-4 behind one badly centred pair, until iter_max).  It starts over from
+                                * the cold start and finishes WITHOUT the second-order corrector term (plain predictor-centring steps,
+                                * which do not cycle); the iterations keep counting and the instance may use ipm_iter_max further iterations.
+                                * Default 25; 0: never. */
     double  sqp_tol;           /* sqp_iters > 1 only (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): > 0 stops an instance as soon
                                 * as a full step is no longer than sqp_tol (max-norm over states and inputs) from a linearisation point
                                 * whose shooting defects are below sqp_tol too; an instance that has not got there after sqp_iters

@@ -459,6 +459,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
     const int n_ineq = 8 * N + 2 * (N - 1);
     const real mu0 = c->ipm_mu0;
     int warmed = 0;                      /* the interior point starts from the trial's minimiser (cfg.ipm_warm_thr) */
+    int cons = 0;                        /* fallback mode (cfg.ipm_fallback_iter): no second-order corrector term */
     ipm_cold_start(c, qp, s);
     if (c->ipm_try_unconstrained != 0) {
         /* Newton step of the QP WITHOUT its inequalities from the start point (du = 0, rolled-out dx, pi = 0): the exact
@@ -518,8 +519,10 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
     int it;
     real rmax_prev = 0, step = 1e300;   /* step: max-norm of the last applied input step */
     real alpha_prev = 1;                /* step length of the previous iteration (centring safeguard, admpc.h) */
-    for (it = 0; it < c->ipm_iter_max; ++it) {
-        real mu = 0, cmax = 0;
+    for (it = 0; it < c->ipm_iter_max + (cons ? (int)c->ipm_fallback_iter : 0); ++it) {      /* the fallback gets a full budget of its own */
+        real mu, cmax;
+    residuals:
+        mu = 0; cmax = 0;
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i) { real v = s->t[k][j][i] * s->lam[k][j][i]; w->rc[k][j][i] = v; mu += v; if (v > cmax) cmax = v; }
             if (k >= 1) for (int i = 0; i < 2; ++i) { real v = s->td[k][i] * s->lamd[k][i]; w->rcd[k][i] = v; mu += v; if (v > cmax) cmax = v; }
@@ -531,6 +534,13 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         if (cmax <= c->ipm_tol_comp && step <= c->ipm_tol_step &&
             (rmax <= c->ipm_tol_res || (it > 0 && rmax > (real)0.1 * rmax_prev))) break;
         rmax_prev = rmax;
+        if (!cons && c->ipm_fallback_iter > 0 && it >= (int)c->ipm_fallback_iter) {
+            /* still iterating: most likely a limit cycle of the centring heuristic.  Start over, finish with plain predictor-centring steps */
+            cons = 1; warmed = 0;
+            ipm_cold_start(c, qp, s);
+            alpha_prev = 1; step = 1e300; rmax_prev = 0;
+            goto residuals;
+        }
 
         /* predictor (affine scaling direction) */
         ipm_reduce(qp, s, w, 1);
@@ -548,12 +558,13 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         mu_aff /= n_ineq;
         real sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
         if (alpha_prev < (real)ADMPC_IPM_BLOCKED_STEP) sigma = 1;       /* blocked step: centre (breaks the method's limit cycles) */
-        /* corrector: centring + second-order term */
+        /* corrector: centring + second-order term (dropped in fallback mode) */
+        const real w2 = cons ? 0 : 1;
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i)
-                w->rc[k][j][i] = s->t[k][j][i] * s->lam[k][j][i] + w->dt[k][j][i] * w->dlam[k][j][i] - sigma * mu;
+                w->rc[k][j][i] = s->t[k][j][i] * s->lam[k][j][i] + w2 * (w->dt[k][j][i] * w->dlam[k][j][i]) - sigma * mu;
             if (k >= 1) for (int i = 0; i < 2; ++i)
-                w->rcd[k][i] = s->td[k][i] * s->lamd[k][i] + w->dtd[k][i] * w->dlamd[k][i] - sigma * mu;
+                w->rcd[k][i] = s->td[k][i] * s->lamd[k][i] + w2 * (w->dtd[k][i] * w->dlamd[k][i]) - sigma * mu;
         }
         ipm_reduce(qp, s, w, 0);
         riccati_solve(qp, F, (const real (*)[NX])w->gx, (const real (*)[NU])w->gu, (const real (*)[NX])w->req, w->ddu, w->ddx, w->dpi);

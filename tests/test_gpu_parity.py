@@ -165,6 +165,31 @@ def test_blocked_warm_start_is_abandoned(gpu_engine_factory, oracle_omp):
     assert slow[4].max() >= 24 and 10 <= (slow[4] != o[4]).sum() <= 100 and np.abs(slow[1] - o[1]).max() <= 1e-7
 
 
+def test_fallback_mode(gpu_engine_factory, oracle_omp):
+    """cfg.ipm_fallback_iter on the device: forced (3) through the condensed pipeline (N = 20) and kernel R (N = 40, 24), then the default
+    on the batches that hold the four known cycling instances (tests/test_rowqp_emu.py CYCLING): every instance of those batches
+    converges, iteration for iteration with the oracle."""
+    from test_rowqp_emu import CYCLING
+    for N, B in ((20, 512), (40, 256), (24, 130)):
+        cfg = default_config(N=N); cfg.ipm_fallback_iter = 3.0
+        s = random_scenarios(B, N=N, seed=33, blend=(3.0, 5.0))
+        g, o = _solve_both(gpu_engine_factory(cfg), oracle_omp, cfg, s, nthreads=8)
+        assert (o[4] > 3).sum() >= B // 4 and (o[4] <= 3).sum() >= 1
+        _assert_parity(g, o, tol_for(N))
+    for N, B, kw, seed in ((40, 4096, {"blend": (3.0, 5.0)}, 2), (80, 2048, {}, 4), (80, 2048, {"blend": (3.0, 5.0)}, 4)):
+        cfg = default_config(N=N)
+        s = random_scenarios(B, N=N, seed=seed, **kw)
+        g, o = _solve_both(gpu_engine_factory(cfg), oracle_omp, cfg, s, nthreads=8)
+        np.testing.assert_array_equal(g[3], o[3]); assert (o[3] == 0).all()
+        for n_, b_, kw_, seed_, idx, its in CYCLING:
+            if (n_, b_, kw_, seed_) == (N, B, kw, seed):
+                assert g[4][idx] == o[4][idx] == its
+        assert g[4].max() < cfg.ipm_iter_max + 25 and o[4].max() < cfg.ipm_iter_max + 25      # nobody runs out of iterations
+        off1 = np.nonzero(g[4] != o[4])[0]                     # instances on the stopping test (see test_blocked_warm_start_is_abandoned)
+        assert len(off1) <= 4 and (np.abs(g[4][off1] - o[4][off1]) == 1).all() and np.abs(g[1][off1] - o[1][off1]).max(initial=0) <= 1e-10
+        assert np.abs(g[1] - o[1]).max() <= tol_for(N) and np.abs(g[0] - o[0]).max() <= tol_for(N)
+
+
 def test_all_state_weights_nonzero(gpu_engine_factory, oracle):
     """The shipped weights only track x, y, psi (specialised condensing kernel); with velocity / yaw-rate / steering weights
     the general instantiation runs.  N = 20 (condensed path) and N = 24 (Riccati path) against the oracle."""

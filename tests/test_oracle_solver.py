@@ -156,3 +156,22 @@ def test_sqp_mode_stops_on_tolerance_and_reports_maxiter(oracle, golden_kat):
     cfg0 = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"], sqp_iters=3)
     x0_, u0_, _, st0, _ = oracle.solve_batch(cfg0, x0, yref, ye, np.array([0.0]), *z)
     assert st0[0] == 0 and np.array_equal(u0_, u3)
+
+
+def test_fallback_mode_ends_the_limit_cycles(oracle):
+    """cfg.ipm_fallback_iter (admpc.h): the four instances found cycling until iter_max in 25k random scenarios converge with the
+    fallback, to the point a run without the second-order term reaches from the cold start, and that point satisfies the QP's KKT
+    conditions (checked through the stopping test: iterations < the fallback's budget)."""
+    from test_rowqp_emu import CYCLING
+    for N, B, kw, seed, idx, its in CYCLING:
+        s = random_scenarios(B, N=N, seed=seed, **kw)
+        s = {k: v[[idx]] for k, v in s.items()}
+        c = default_config(N=N)
+        r = oracle.solve_batch(c, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        assert r[3][0] == 0 and r[4][0] == its < c.ipm_iter_max + 25
+        c1 = c.copy(); c1.ipm_fallback_iter = 1.0
+        r1 = oracle.solve_batch(c1, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        assert r1[4][0] == its - 24 and np.abs(r1[1] - r[1]).max() == 0
+        off = c.copy(); off.ipm_fallback_iter = 0.0
+        r0 = oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        assert r0[4][0] == c.ipm_iter_max and np.abs(r0[1] - r[1]).max() > 5e-3

@@ -86,6 +86,39 @@ def test_emulated_kernel_abandons_a_blocked_warm_start(emu, oracle):
     _strict(g, o, 1e-7)
 
 
+CYCLING = [  # (N, batch, scenario kwargs, seed, index, iterations with the fallback): instances that never leave a limit cycle of
+    # Mehrotra's centring heuristic (status 0 at iter_max, 1e-2 off the minimiser) without cfg.ipm_fallback_iter
+    (40, 4096, {"blend": (3.0, 5.0)}, 2, 3285, 48),
+    (80, 2048, {}, 4, 465, 52),
+    (80, 2048, {"blend": (3.0, 5.0)}, 4, 741, 42),
+    (80, 2048, {"blend": (3.0, 5.0)}, 4, 985, 50),
+]
+
+
+def test_emulated_kernel_fallback_mode(emu, oracle):
+    """cfg.ipm_fallback_iter: (a) forced (3: every row that needs more than three iterations starts over without the second-order
+    term) on a short and a long horizon -- rows of one wave enter the mode at different times or not at all; (b) the default 25 on
+    the instances it exists for: without it they cycle until iter_max, with it they converge to the minimiser a conservative run finds."""
+    for N, B in ((20, 48), (40, 24)):
+        c = default_config(N=N); c.ipm_fallback_iter = 3.0
+        s = random_scenarios(B, N=N, seed=33, blend=(3.0, 5.0))
+        g, o = _both(emu, oracle, c, s)
+        assert (o[4] > 3).sum() >= B // 4 and (o[4] <= 3).sum() >= 1
+        ref = oracle.solve_batch(default_config(N=N), s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        assert np.abs(ref[1] - o[1]).max() <= 1e-7                 # the same minimiser by the other route
+        _strict(g, o, 1e-8 if N <= 32 else 1e-7)
+    for N, B, kw, seed, idx, its in CYCLING[:2]:
+        s = random_scenarios(B, N=N, seed=seed, **kw)
+        s = {k: v[[idx, 3]] for k, v in s.items()}
+        c = default_config(N=N); assert c.ipm_fallback_iter == 25.0
+        g, o = _both(emu, oracle, c, s)
+        assert o[4][0] == its and o[4][1] < 25
+        off = c.copy(); off.ipm_fallback_iter = 0.0
+        cyc = oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        assert cyc[4][0] == c.ipm_iter_max and np.abs(cyc[1][0] - o[1][0]).max() > 5e-3 and np.abs(cyc[1][1] - o[1][1]).max() == 0
+        _strict(g, o, 1e-7)
+
+
 def test_emulated_kernel_active_slacks_steering_bound_and_failure(emu, oracle):
     cfg = default_config()
     x0, xref, uref = straight_scenario(N=cfg.N, Ts=cfg.Ts, v=5.0)
