@@ -100,7 +100,7 @@ IPM_MU0 = 1.0
 IPM_THR0 = 0.1
 IPM_WARM_THR = 0.01
 IPM_WARM_RESTART = 0.1
-IPM_FALLBACK_ITER = 25.0
+IPM_FALLBACK_ITER = 30.0
 IPM_TOL_COMP = 1e-10
 IPM_TOL_RES = 1e-9
 IPM_TOL_STEP = 1e-6

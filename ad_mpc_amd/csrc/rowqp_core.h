@@ -664,14 +664,18 @@ struct RowQp {
     }
 
     // does the step in U / X respect every bound?
-    RQ_FN M pass_trial_check() {
+    RQ_FN M pass_trial_check(V& nviol) {
         M ok = X::mtrue();
+        V nv = splat((T)0);
         RQ_NOUNROLL
         for (int s = 0; 2 * s < N; ++s) {
             Side S; side_load(s, S, false, true);
             const V qv = sgn * (S.vabs + S.sc - bound);
-            ok = ok & ((!S.act) | (qv >= splat((T)0)));
+            const M in = (!S.act) | (qv >= splat((T)0));
+            ok = ok & in;
+            nv = nv + X::sel(in, splat((T)0), splat((T)1));
         }
+        nviol = X::row_sum(nv);
         return X::row_and(ok);
     }
 
@@ -738,7 +742,9 @@ struct RowQp {
     // =================================================================================================================
     // one instance
     // =================================================================================================================
-    struct Result { M failed; I iters; V rmax; };
+    // deferred / nviol (solve mode 1 only): the trial's minimiser leaves a bound -- nothing of this row has been written; nviol = number
+    // of violated bounds (sort key of the second phase)
+    struct Result { M failed; I iters; V rmax; M deferred; V nviol; };
 
     // The rows of `rows` start over from the cold start (zero input step, rolled-out states, slacks at thr); the other rows of the wave
     // keep their records bit for bit (write mask).  Leaves the quantities of the next iteration (R, rstat, step, alpha_prev) for them.
@@ -763,7 +769,10 @@ struct RowQp {
 
     // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the multipliers of the returned iterate
     // (io.pi, io.ineq) on the rows of pim.
-    RQ_FN void solve(M valid, Result& res, bool want_pi, M pim) {
+    // mode (wave-uniform) 0: the whole solve.  1: first phase of a split batch -- roll-out and unconstrained trial only; rows whose
+    // trial fails are reported in res.deferred and must not be finished (a second launch solves them from scratch, packed with
+    // their like: rows of one wave iterate until the slowest has converged).
+    RQ_FN void solve(M valid, Result& res, bool want_pi, M pim, int mode) {
         const V zero = splat((T)0), one = splat((T)1);
         X::stamp(0);
         sweep_rollout(false);
@@ -771,6 +780,7 @@ struct RowQp {
         X::stamp(1);
         M active = valid, failed = X::mfalse(), warmrow = X::mfalse();
         I iters = X::isplat(0);
+        res.deferred = X::mfalse(); res.nviol = zero;
         V rstat;                                                   // stationarity residual of the interior point's iterate (tracked)
         pass_trial_setup();
         X::fence();
@@ -779,12 +789,13 @@ struct RowQp {
             X::fence();
             sweep_forward(true);
             X::fence();
-            const M ok = pass_trial_check();
+            const M ok = pass_trial_check(res.nviol);
             const M warm = (!ok) & X::mfrom(q.thw > (T)0);
             const V a0 = X::sel(ok | warm, one, zero);
             rstat = pass_init(a0, X::sel(warm, splat(q.thw), splat(q.thr)), warm, ok);
             active = active & !ok;
             warmrow = warm;
+            if (mode == 1) { res.deferred = active; active = X::mfalse(); pim = pim & !res.deferred; }
             X::stamp(2);
         } else {
             rstat = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());

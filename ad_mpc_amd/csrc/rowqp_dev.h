@@ -64,9 +64,16 @@ struct DevCommon {
     // earlier sweep are dropped (acquire at agent scope = buffer_inv sc1) -- the L1 does not follow the wave's own stores
     // (measured: stale states after the roll-out, run-to-run different results).  No sweep reads what it wrote itself.
     RQ_FN static void fence() {
+#ifdef ADMPC_PHASE_TIMERS
+        unsigned long long f0, f1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f0) :: "memory");
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef ADMPC_PHASE_TIMERS
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1) :: "memory");
+        if (threadIdx.x == 0) { atomicAdd(&g_rq_ticks[14], f1 - f0); atomicAdd(&g_rq_ticks[15], 1ull); }      // slots outside the phase sum
+#endif
     }
     // scheduling fence: memory operations are not moved across it, and what is computed from a, b, c, d starts after it (hipcc otherwise
     // sinks the loads of the next step below the arithmetic of the current one and waits for them at once)

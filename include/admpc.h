@@ -120,7 +120,8 @@ typedef struct AdmpcConfig {
                                 * cycling with period 4 around 1e-4 behind one badly centred pair, until iter_max).  It starts over from
                                 * the cold start and finishes WITHOUT the second-order corrector term (plain predictor-centring steps,
                                 * which do not cycle); the iterations keep counting and the instance may use ipm_iter_max further iterations.
-                                * Default 25; 0: never. */
+                                * Default 30 (healthy instances need up to 18 / 23 / 27 iterations at N = 40 / 80 / 128:
+                                * scripts/sweep_convergence.py); 0: never. */
     double  sqp_tol;           /* sqp_iters > 1 only (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): > 0 stops an instance as soon
                                 * as a full step is no longer than sqp_tol (max-norm over states and inputs) from a linearisation point
                                 * whose shooting defects are below sqp_tol too; an instance that has not got there after sqp_iters

@@ -36,7 +36,7 @@ class Emu:
     def __init__(self):
         self.lib = C.CDLL(build())
 
-    def solve(self, cfg, x0, yref, yref_e, GT, bl, xbar, ubar, dtype=np.float64, want_pi=False):
+    def solve(self, cfg, x0, yref, yref_e, GT, bl, xbar, ubar, dtype=np.float64, want_pi=False, split=False):
         N = cfg.N
         c = lambda a: np.ascontiguousarray(a, dtype=dtype)
         x0 = c(x0).reshape(-1, NX); B = x0.shape[0]
@@ -46,9 +46,16 @@ class Emu:
         pi = np.zeros((B, N + 1, NX), dtype=dtype) if want_pi else None
         ineq = np.zeros((B, N, 20), dtype=dtype) if want_pi else None
         rmax = np.zeros(B, dtype=dtype)
-        f = self.lib.rowqp_emu_solve_f64 if dtype == np.float64 else self.lib.rowqp_emu_solve_f32
         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
-        f.argtypes = [C.POINTER(AdmpcConfig), C.c_int] + [C.c_void_p] * 13
-        rc = f(C.byref(cfg), B, vp(x0), vp(yref), vp(yref_e), vp(GT), vp(bl), vp(x), vp(u), vp(cost), vp(st), vp(it), vp(pi), vp(ineq), vp(rmax))
+        if split:               # the device's two-phase path for large batches; self.key: sort keys of the deferred instances
+            assert dtype == np.float64
+            f = self.lib.rowqp_emu_solve_split_f64
+            f.argtypes = [C.POINTER(AdmpcConfig), C.c_int] + [C.c_void_p] * 14
+            self.key = np.zeros(B, dtype=np.int32)
+            rc = f(C.byref(cfg), B, vp(x0), vp(yref), vp(yref_e), vp(GT), vp(bl), vp(x), vp(u), vp(cost), vp(st), vp(it), vp(pi), vp(ineq), vp(rmax), vp(self.key))
+        else:
+            f = self.lib.rowqp_emu_solve_f64 if dtype == np.float64 else self.lib.rowqp_emu_solve_f32
+            f.argtypes = [C.POINTER(AdmpcConfig), C.c_int] + [C.c_void_p] * 13
+            rc = f(C.byref(cfg), B, vp(x0), vp(yref), vp(yref_e), vp(GT), vp(bl), vp(x), vp(u), vp(cost), vp(st), vp(it), vp(pi), vp(ineq), vp(rmax))
         assert rc == 0
         return (x, u, cost, st, it) + ((pi, ineq) if want_pi else ()) + (rmax,)

@@ -116,7 +116,7 @@ struct EmuX {
 
 template <class T>
 int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T* yref_e, const T* GT, const T* bl,
-              T* xbar, T* ubar, T* cost, int32_t* status, int32_t* iters, T* pi, T* ineq, T* rmax)
+              T* xbar, T* ubar, T* cost, int32_t* status, int32_t* iters, T* pi, T* ineq, T* rmax, int split = 0, int32_t* key = nullptr)
 {
     typedef EmuX<T> X;
     const int N = cfg->N;
@@ -130,7 +130,24 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
         typename X::Lds L{lds.data(), (int)lds.size()};
         RowQp<X> S(q, io, L, X::isplat(b), X::mtrue());
         typename RowQp<X>::Result res;
-        S.solve(X::mtrue(), res, pi != nullptr, X::mtrue());
+        if (split) {            // the device's split batches: phase 1 (trial only), then -- if deferred -- the whole solve from scratch
+            S.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 1);
+            if (key) key[b] = res.deferred.v[0] ? (int32_t)res.nviol.v[0] : 0;
+            if (res.deferred.v[0]) {
+                for (auto& v : lds) v = std::nan("");
+                for (auto& v : ws) v = std::nan("");
+                RowQp<X> S2(q, io, L, X::isplat(b), X::mtrue());
+                S2.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 2);
+                typename X::M failed2 = res.failed; typename X::V J2; typename X::M conv2;
+                S2.finish(X::mtrue(), failed2, J2, conv2);
+                status[b] = failed2.v[0] ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+                iters[b] = res.iters.v[0];
+                cost[b] = failed2.v[0] ? (T)INFINITY : J2.v[0];
+                if (rmax) rmax[b] = res.rmax.v[0];
+                continue;
+            }
+        } else
+        S.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 0);
         typename X::M failed = res.failed;
         typename X::V J;
         typename X::M conv;
@@ -151,4 +168,8 @@ int rowqp_emu_solve_f64(const AdmpcConfig* cfg, int B, const double* x0, const d
 int rowqp_emu_solve_f32(const AdmpcConfig* cfg, int B, const float* x0, const float* yref, const float* yref_e, const float* GT,
                         const float* bl, float* xbar, float* ubar, float* cost, int32_t* status, int32_t* iters, float* pi, float* ineq, float* rmax)
 { return emu_solve<float>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, ineq, rmax); }
+// the split-batch path of the device (admpc_rowqp.hip): key [B] receives the sort key of the deferred instances (0: solved by the trial)
+int rowqp_emu_solve_split_f64(const AdmpcConfig* cfg, int B, const double* x0, const double* yref, const double* yref_e, const double* GT,
+                              const double* bl, double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, double* pi, double* ineq, double* rmax, int32_t* key)
+{ return emu_solve<double>(cfg, B, x0, yref, yref_e, GT, bl, xbar, ubar, cost, status, iters, pi, ineq, rmax, 1, key); }
 }

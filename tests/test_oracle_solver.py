@@ -168,10 +168,10 @@ def test_fallback_mode_ends_the_limit_cycles(oracle):
         s = {k: v[[idx]] for k, v in s.items()}
         c = default_config(N=N)
         r = oracle.solve_batch(c, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-        assert r[3][0] == 0 and r[4][0] == its < c.ipm_iter_max + 25
+        assert r[3][0] == 0 and r[4][0] == its < c.ipm_iter_max + 30
         c1 = c.copy(); c1.ipm_fallback_iter = 1.0
         r1 = oracle.solve_batch(c1, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
-        assert r1[4][0] == its - 24 and np.abs(r1[1] - r[1]).max() == 0
+        assert r1[4][0] == its - 29 and np.abs(r1[1] - r[1]).max() == 0
         off = c.copy(); off.ipm_fallback_iter = 0.0
         r0 = oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
         assert r0[4][0] == c.ipm_iter_max and np.abs(r0[1] - r[1]).max() > 5e-3
