@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("linearize", "condense", "qp_dense", "expand", "rowqp", "argmin", "epilogue", "waypoints", "shoot"):
+    for key in ("linearize", "condense", "qp_dense", "expand", "rowqp_sort", "rowqp", "argmin", "epilogue", "waypoints", "shoot"):
         if key in name:
             return key
     return None
