@@ -559,12 +559,15 @@ def test_one_engine_growing_and_shrinking_batches(gpu_engine_factory, oracle):
         _assert_parity(g, o)
 
 
-def test_solve_is_capturable_in_a_hip_graph(gpu_engine_factory):
+@pytest.mark.parametrize("N,split", [(20, None), (40, "1")])
+def test_solve_is_capturable_in_a_hip_graph(gpu_engine_factory, monkeypatch, N, split):
     """admpc_solve_batch is launches only (no allocation, no copy, no synchronisation after admpc_reserve): it can be
-    captured into a hipGraph on the caller's stream and replayed; the replay reproduces the eager result bit for bit."""
+    captured into a hipGraph on the caller's stream and replayed; the replay reproduces the eager result bit for bit.
+    N = 20: the four kernels of the condensed pipeline; N = 40 with the split forced: linearise, trial launch, sort, second launch."""
     import torch
-    cfg = default_config(N=20)
-    s = random_scenarios(300, N=20, seed=21, blend=(3.0, 5.0))
+    if split: monkeypatch.setenv("ADMPC_ROWQP_SPLIT", split)
+    cfg = default_config(N=N)
+    s = random_scenarios(300, N=N, seed=21, blend=(3.0, 5.0))
     eng = gpu_engine_factory(cfg)
     d = eng.to_device
     x0, yref, yref_e, p = d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"])
