@@ -330,11 +330,7 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
 // ---------------------------------------------------------------------------------------------
 // wave-level primitives
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rdlane(double v, int l) {        // l must be wave-uniform
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
+#include "dense40.h"      // rdlane, WSYNC, lds_byte_addr, the 40 x 40 factorisation / substitution helpers, rcp_nr
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov(double ident, double v) {
     int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
@@ -358,12 +354,6 @@ __device__ __forceinline__ double wave_reduce(double v) {
     return rdlane(v, 63);
 }
 
-// A workgroup is ONE wavefront.  WSYNC orders a cross-lane exchange through LDS (write, WSYNC, read).
-#ifdef ADMPC_WSYNC_FENCE_ONLY
-#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#else
-#define WSYNC() __syncthreads()
-#endif
 
 // x / 7 for 0 <= x < 13107 as a 32-bit multiply-shift: hipcc 7.2 narrows small non-negative ints to 16 bits and its backend
 // cannot select the 16-bit udivrem by 7 at -Oz ("Cannot select: i16 udivrem"); there is no `/ 7` or `% 7` on the device.
@@ -465,141 +455,6 @@ __device__ __forceinline__ void stage_dq(double* __restrict__ dq, const double* 
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
-}
-
-// ---- triangular substitutions of the condensed interior-point kernel: hand-scheduled assembly, generated by gen_subst_asm.py
-//      (register contract and rationale there).  y lives in v[100:101], the per-lane LDS byte address in v102.
-#include "subst_asm.inc"
-__device__ __forceinline__ unsigned lds_byte_addr(const double* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const double*)p;
-}
-// L z = y in place (unit lower-triangular L, rows packed at Lp[i (i + 1) / 2 + j], the diagonal slots hold 0.0);
-// row_addr = &Lp[row start of this lane], pub_addr = &buffer[lane % 16] of a 64-double LDS exchange buffer
-__device__ __forceinline__ void fwd_subst_40(double& y, const unsigned row_addr, const unsigned pub_addr) {
-    asm volatile(ADMPC_FWD_SUBST_ASM_40 : "+{v[100:101]}"(y) : "{v102}"(row_addr), "{v103}"(pub_addr) : ADMPC_SUBST_CLOBBERS);
-}
-// L' x = z in place; col_addr = &Lp[lane]
-__device__ __forceinline__ void bwd_subst_40(double& x, const unsigned col_addr, const unsigned pub_addr) {
-    asm volatile(ADMPC_BWD_SUBST_ASM_40 : "+{v[100:101]}"(x) : "{v102}"(col_addr), "{v103}"(pub_addr) : ADMPC_SUBST_CLOBBERS);
-}
-
-// Newton-matrix row of this lane (see rowbuild() in gen_subst_asm.py): 20 columns per statement (operand limit of inline assembly)
-#define RB_OUT(a, o) "=&v"(a[o + 0]), "=&v"(a[o + 1]), "=&v"(a[o + 2]), "=&v"(a[o + 3]), "=&v"(a[o + 4]), "=&v"(a[o + 5]), "=&v"(a[o + 6]), \
-                     "=&v"(a[o + 7]), "=&v"(a[o + 8]), "=&v"(a[o + 9]), "=&v"(a[o + 10]), "=&v"(a[o + 11]), "=&v"(a[o + 12]), "=&v"(a[o + 13]), \
-                     "=&v"(a[o + 14]), "=&v"(a[o + 15]), "=&v"(a[o + 16]), "=&v"(a[o + 17]), "=&v"(a[o + 18]), "=&v"(a[o + 19])
-__device__ __forceinline__ void newton_row_40(double (&a)[40], const unsigned row_addr, const double dbar, const double s_odd) {
-    asm volatile(ADMPC_ROWBUILD_ASM_40_A : RB_OUT(a, 0) : "v"(row_addr), "v"(dbar), "v"(s_odd) : "s46", "s47", "memory");
-    asm volatile(ADMPC_ROWBUILD_ASM_40_B : RB_OUT(a, 20) : "v"(row_addr), "v"(dbar), "v"(s_odd) : "s46", "s47", "memory");
-}
-
-// full row `lane` of the symmetric H (packed lower-triangular rows in LDS) for the mat-vec: symrow() in gen_subst_asm.py
-__device__ __forceinline__ void sym_row_40(double (&a)[40], const unsigned row_addr, const unsigned col_addr) {
-    asm volatile(ADMPC_SYMROW_ASM_40_A : RB_OUT(a, 0) : "v"(row_addr), "v"(col_addr) : "memory");
-    asm volatile(ADMPC_SYMROW_ASM_40_B : RB_OUT(a, 20) : "v"(row_addr), "v"(col_addr) : "memory");
-}
-#define RB_IN(a, o) "v"(a[o + 0]), "v"(a[o + 1]), "v"(a[o + 2]), "v"(a[o + 3]), "v"(a[o + 4]), "v"(a[o + 5]), "v"(a[o + 6]), "v"(a[o + 7]), "v"(a[o + 8]), \
-                    "v"(a[o + 9]), "v"(a[o + 10]), "v"(a[o + 11]), "v"(a[o + 12]), "v"(a[o + 13]), "v"(a[o + 14]), "v"(a[o + 15]), "v"(a[o + 16]), \
-                    "v"(a[o + 17]), "v"(a[o + 18]), "v"(a[o + 19])
-// packed lower-triangular row of this lane to LDS (rowstore() in gen_subst_asm.py); lanes >= 40 store nothing
-__device__ __forceinline__ void store_row_40(const double (&a)[40], const unsigned row_addr) {
-    asm volatile(ADMPC_ROWSTORE_ASM_40_A : : RB_IN(a, 0), "v"(row_addr) : "s46", "s47", "memory");
-    asm volatile(ADMPC_ROWSTORE_ASM_40_B : : RB_IN(a, 20), "v"(row_addr) : "s46", "s47", "memory");
-}
-
-// ---- compile-time loop (indices must be immediates of the DPP instructions below)
-template <int I, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < E) { f(std::integral_constant<int, I>{}); static_for<I + 1, E>(f); }
-}
-// acc += L[lane BC of this lane's 16-lane row] * s : v_fmac_f64 with a DPP row broadcast on its first source (gfx90a+ "DP ALU DPP",
-// row_newbcast is the one control it supports).  The leading s_nop covers the VALU-write -> DPP-read hazard on L (2 wait states);
-// inline assembly is invisible to the compiler's hazard recogniser.
-template <int BC>
-__device__ __forceinline__ void fmac_rowbc(double& acc, const double L, const double s) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
-}
-template <int BC>
-__device__ __forceinline__ void fmac_rowbc4(double& a0, double& a1, double& a2, double& a3, const double L, const double s) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(L), "v"(s), "n"(BC), "n"(BC + 1), "n"(BC + 2), "n"(BC + 3));
-}
-// The same without the hazard pad: for a broadcast source that was loaded from LDS (the s_waitcnt that guards the load is enough)
-template <int BC>
-__device__ __forceinline__ void fmac_rowbc_ld(double& acc, const double L, const double s) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
-}
-template <int BC>
-__device__ __forceinline__ void fmac_rowbc4_ld(double& a0, double& a1, double& a2, double& a3, const double L, const double s) {
-    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(L), "v"(s), "n"(BC), "n"(BC + 1), "n"(BC + 2), "n"(BC + 3));
-}
-// Single update whose result is read by a v_readlane right behind it (the pivot of the next column): pads on both sides.
-// HAZARD (measured, scripts/probes/subst_probe.hip): a v_readlane of a VGPR needs one wait state after the VALU write.
-template <int BC>
-__device__ __forceinline__ void fmac_rowbc_then_readlane(double& acc, const double L, const double s) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(acc) : "v"(L), "v"(s), "n"(BC));
-}
-// Head of a factorisation column, one assembly statement so that hipcc cannot sink its LDS reads down to their first use:
-//   wait for the previous column's block reads (R) -> first update acc += R[J1/16][J1%16] * nl (makes column J1 final) -> pad for
-//   the v_readlane of the pivot that follows -> publish the finished column J1 in LDS -> start reading it back as "block m in
-//   every 16-lane row" (Rn[m], m = MLO..2) WITHOUT waiting: the reads land under the reciprocal chain and the remaining updates
-//   of the previous column.  The wait is lgkmcnt(2): the two LDS stores of the previous pivot chain (1/D and the factor column)
-//   are younger than the reads and need not have retired.  R and nl are in/out operands only to order their later users
-//   behind the wait.  PUBLISH = false (columns whose remaining rows all sit in the last 16-lane block): no LDS traffic.
-template <int J1, int MLO, bool PUBLISH, bool PAD>
-__device__ __forceinline__ void col_head(double& acc, double (&R)[3], double& nl, double (&Rn)[3], const unsigned wr_addr, const unsigned rd_addr) {
-    constexpr int BO = (J1 & 1) * 1024;            // alternate exchange buffers cb / sb (sb = cb + 128 doubles)
-    if constexpr (!PUBLISH) {
-        if constexpr (PAD) asm volatile("s_waitcnt lgkmcnt(2)\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
-                                        : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3]) : "n"(J1 % 16));
-        else asm volatile("s_waitcnt lgkmcnt(2)\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\ts_nop 0"
-                          : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3]) : "n"(J1 % 16));
-    } else if constexpr (MLO == 0) {
-        asm volatile("s_waitcnt lgkmcnt(2)\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                     "ds_write_b64 %8, %0 offset:%11\n\tds_read_b64 %3, %9 offset:%11\n\tds_read_b64 %4, %9 offset:%12\n\tds_read_b64 %5, %9 offset:%13"
-                     : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "=&v"(Rn[0]), "=&v"(Rn[1]), "=&v"(Rn[2]), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3])
-                     : "v"(wr_addr), "v"(rd_addr), "n"(J1 % 16), "n"(BO), "n"(BO + 128), "n"(BO + 256) : "memory");
-    } else if constexpr (MLO == 1) {
-        asm volatile("s_waitcnt lgkmcnt(2)\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-                     "ds_write_b64 %7, %0 offset:%10\n\tds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12"
-                     : "+v"(acc), "+v"(R[J1 / 16]), "+v"(nl), "=&v"(Rn[1]), "=&v"(Rn[2]), "+v"(R[(J1 / 16 + 1) % 3]), "+v"(R[(J1 / 16 + 2) % 3])
-                     : "v"(wr_addr), "v"(rd_addr), "n"(J1 % 16), "n"(BO), "n"(BO + 128), "n"(BO + 256) : "memory");
-    }
-}
-// Copies of 16-lane row r of v in all four rows, r = 0..2 (row 3 is idle in the 40-row factorisation): gfx950's
-// v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
-//   swap16(X, X) -> (R0,R0,R2,R2), (R1,R1,R3,R3);  swap32(E, E) -> (R0 x4), (R2 x4);  swap32(O, O) -> (R1 x4), (R3 x4)
-template <int FIRST_ROW, int LAST_ROW = 2>
-__device__ __forceinline__ void rows_replicate(const double v, double (&R)[3]) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const auto plo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto phi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    if (FIRST_ROW <= 0 || LAST_ROW >= 2) {
-        const auto elo = __builtin_amdgcn_permlane32_swap(plo[0], plo[0], false, false);
-        const auto ehi = __builtin_amdgcn_permlane32_swap(phi[0], phi[0], false, false);
-        if (FIRST_ROW <= 0) R[0] = __hiloint2double((int)ehi[0], (int)elo[0]);
-        if (LAST_ROW >= 2) R[2] = __hiloint2double((int)ehi[1], (int)elo[1]);
-    }
-    if (FIRST_ROW <= 1 && LAST_ROW >= 1) {
-        const auto olo = __builtin_amdgcn_permlane32_swap(plo[1], plo[1], false, false);
-        const auto ohi = __builtin_amdgcn_permlane32_swap(phi[1], phi[1], false, false);
-        R[1] = __hiloint2double((int)ohi[0], (int)olo[0]);
-    }
-}
-
-// 1/d: hardware estimate + two Newton steps (full double accuracy; no range handling, the pivots seen here are 1e-3 .. 1e15)
-__device__ __forceinline__ double rcp_nr(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
-    return fma(r, e, r);
 }
 
 // ---- optional in-kernel phase timers of the interior-point kernel (build with -DADMPC_PHASE_TIMERS; totals are printed by

@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <new>
+#include <type_traits>
 #include "../../include/admpc.h"
 #include "../../include/admpc_quad.h"
 
@@ -151,6 +153,8 @@ __device__ __forceinline__ void rk4_col(const Cfg* __restrict__ c, const double*
     for (int i = 0; i < QX; ++i) { phi[i] = x[i] + h * ax[i]; scol[i] = (col == i ? 1.0 : 0.0) + h * as[i]; }
 }
 
+#include "dense40.h"      // the 40 x 40 LDL' / substitution machinery of the car's condensed kernel (fast path for N nu = 40)
+
 // value of lane l (wave-uniform l): two v_readlane, no LDS round trip
 __device__ __forceinline__ double bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(64) void admpc_quad_shoot_kernel(const Cfg* __restr
     }
 }
 
+// FAST (N nu = 40, the shipped horizon): the Newton systems go through dense40.h -- register-resident LDL' with DPP rank-1 updates and
+// the generated substitution assembly instead of the LDS-resident Cholesky below (3.9x less time per interior-point iteration).
+template <bool FAST>
 __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                              const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                              double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg)
@@ -228,6 +235,8 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
     const bool act = lane < n;
     const int li = act ? lane : 0, ji = li / QU, mi = li - ji * QU;
     const double Ts = c->Ts;
+    const Dense40Lds W{L.H, L.M, L.gam, L.gam + 64};                // FAST: factor in the M region, exchange buffer / pivots in gam (free after condensing)
+    if (FAST) { if (act) L.M[tri(li, li)] = 0.0; __syncthreads(); }     // diagonal slots of the packed unit factor: 0.0, never overwritten
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
         double* xb = xbarg + (size_t)inst * (N + 1) * QX;
         double* ub = ubarg + (size_t)inst * N * QU;
@@ -289,10 +298,17 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         double alpha_prev = 1.0;
         int it = 0, st = 0;
         for (;; ++it) {
-            L.vec[lane] = du;
-            __syncthreads();
+            int lz = lane;                                           // laundered lane id (dense40.h)
+            asm volatile("" : "+v"(lz));
             double rs = grad - ll + lu;
-            if (act) for (int j = 0; j < n; ++j) rs += L.H[sym(li, j)] * L.vec[j];
+            if constexpr (FAST) {
+                const double hdu = dense40_symv(W, lane, act ? du : 0.0, lz);
+                rs = act ? rs + hdu : 0.0;
+            } else {
+                L.vec[lane] = du;
+                __syncthreads();
+                if (act) for (int j = 0; j < n; ++j) rs += L.H[sym(li, j)] * L.vec[j];
+            }
             const double rl = du - lo - tl, ru = hi - du - tu;
             const double mu = wave_sum(act ? tl * ll + tu * lu : 0.0) / (2.0 * n);
             const double cmax = wave_max(act ? fmax(tl * ll, tu * lu) : 0.0);
@@ -301,12 +317,16 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
             if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
             const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
-            if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
-            __syncthreads();
+            if constexpr (!FAST) {
+                if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
+                __syncthreads();
+            }
             QSTAMP(2);
             // Cholesky M = L L' (lower), row i on lane i, columns left to right (oracle: chol)
             bool posdef = true;
             double myinv = 0.0;                                      // lane j: 1 / L_jj
+            if constexpr (FAST) dense40_factorise(W, lane, act ? Dl + Du : 1.0, 0.0, lz);
+            else
             for (int j = 0; j < n; ++j) {
                 double s = 0.0;
                 if (act && li >= j) {
@@ -335,6 +355,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             if (!posdef) { st = 4; break; }
             // two solves with the factor: forward by columns (same subtraction order as the oracle's rows), backward by columns
             auto solve = [&](double rhs) -> double {
+                if constexpr (FAST) { const double x = dense40_solve(W, rhs, lz); return act ? x : 0.0; }
                 double r = rhs;
                 for (int k2 = 0; k2 < n; ++k2) {
                     const double xk = bcast(r, k2) * bcast(myinv, k2);
@@ -384,6 +405,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         }
         // ---- 4. expansion, full step, cost (oracle: rti_step)
         __syncthreads();
+        if (FAST) { if (act) L.M[tri(li, li)] = 0.0; }               // (the factor never writes its diagonal; kept for the next instance)
         L.vec[lane] = act ? du : 0.0;
         if (lane < QX) L.xnew[lane] = xb[lane] + (x0[lane] - xb[lane]);
         __syncthreads();
@@ -435,6 +457,7 @@ struct AdmpcQuadSolver {
     AdmpcQuadConfig cfg;
     AdmpcQuadConfig* d_cfg;
     int device, num_cu, lds_bytes;
+    int generic;             // ADMPC_QUAD_GENERIC=1: the LDS-resident Cholesky path also at N nu = 40 (A/B tests)
 };
 
 namespace {
@@ -495,9 +518,11 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return admpc_set_error(ADMPC_EHIP, "hipGetDeviceProperties failed"); }
     s->num_cu = prop.multiProcessorCount;
     s->lds_bytes = quad_lds_doubles(cfg->N) * (int)sizeof(double);
+    { const char* e = getenv("ADMPC_QUAD_GENERIC"); s->generic = e && e[0] == '1'; }
     if (hipMalloc((void**)&s->d_cfg, sizeof(AdmpcQuadConfig)) != hipSuccess ||
         hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcQuadConfig), hipMemcpyHostToDevice) != hipSuccess) { if (s->d_cfg) (void)hipFree(s->d_cfg); delete s; return admpc_set_error(ADMPC_EHIP, "device allocation failed"); }
-    (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_shoot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
@@ -522,7 +547,10 @@ int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const do
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
     int per_cu = (160 * 1024) / s->lds_bytes; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
     int grid = s->num_cu * per_cu; if (grid > B) grid = B;
-    hipLaunchKernelGGL(admpc_quad_solve_kernel, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters);
+    if (s->cfg.N * QU == 40 && !s->generic)
+        hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters);
+    else
+        hipLaunchKernelGGL(admpc_quad_solve_kernel<false>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters);
     if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad solve kernel launch failed");
     return ADMPC_OK;
 }
