@@ -22,12 +22,17 @@
 extern "C" int admpc_set_error(int code, const char* msg);          // admpc_kernels.hip: thread-local message behind admpc_last_error()
 
 #ifdef ADMPC_QUAD_TIMERS
-__device__ unsigned long long g_quad_ticks[8];
-#define QSTAMP(id) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); if (threadIdx.x == 0) atomicAdd(&g_quad_ticks[id], t_ - qlast); qlast = t_; } while (0)
-#define QSTART() unsigned long long qlast; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(qlast))
+// per-wave accumulators, flushed once at the end of the kernel (an atomic per stamp costs more than most phases)
+__device__ unsigned long long g_quad_ticks[16];
+#define QDECL() unsigned long long qacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, qlast = 0
+#define QSTAMP(id) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); qacc[id] += t_ - qlast; qlast = t_; } while (0)
+#define QSTART() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(qlast))
+#define QFLUSH() do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_quad_ticks[q_], qacc[q_]); } while (0)
 #else
+#define QDECL() do { } while (0)
 #define QSTAMP(id) do { } while (0)
 #define QSTART() do { } while (0)
+#define QFLUSH() do { } while (0)
 #endif
 
 namespace {
@@ -177,16 +182,20 @@ __device__ __forceinline__ double wave_min(double v) {
 }
 
 // LDS layout (doubles): A [N][13][13] | B [N][13][4] | b [N][13] | H, M: packed lower triangles n(n+1)/2 | gam [13][n] | vec [64] | xnew [(N+1)*13]
+//   | xbs [(N+1)*13] the linearisation point | yrs [N*17 + 13] the references (stage, terminal): read stage by stage in the condensing and
+//   expansion loops, where a global load would put a memory round trip into every stage | xhs [13] free response of the current stage
+//   (the same for every lane: computed once, by lanes 0..12) | wts [26] stage and terminal weights (registers are the scarce resource)
 struct Lds {
-    double *A, *B, *b, *H, *M, *gam, *vec, *xnew;
+    double *A, *B, *b, *H, *M, *gam, *vec, *xnew, *xbs, *yrs, *xhs, *wts;
     __device__ Lds(double* p, int N) {
         const int n = N * QU, tri = n * (n + 1) / 2;
         A = p; B = A + N * QX * QX; b = B + N * QX * QU; H = b + N * QX; M = H + tri; gam = M + tri; vec = gam + QX * n; xnew = vec + 64;
+        xbs = xnew + (N + 1) * QX; yrs = xbs + (N + 1) * QX; xhs = yrs + N * QY + QX; wts = xhs + QX;
     }
 };
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }                    // j <= i
 __device__ __forceinline__ int sym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
-__host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + n * (n + 1) + QX * n + 64 + (N + 1) * QX; }
+__host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + n * (n + 1) + QX * n + 64 + 2 * (N + 1) * QX + N * QY + QX + QX + 2 * QX; }
 
 __device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const Lds& L, int lane, double* phi_out)
 {
@@ -235,8 +244,14 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
     const bool act = lane < n;
     const int li = act ? lane : 0, ji = li / QU, mi = li - ji * QU;
     const double Ts = c->Ts;
+    // problem constants in registers / LDS: a read of *c inside a stage loop is a scalar load from global memory
+    if (lane < QX) { L.wts[lane] = Ts * c->W[lane]; L.wts[QX + lane] = c->We[lane]; }
+    const double Rw = Ts * c->W[QX + mi], lbm = c->lbu[mi], ubm = c->ubu[mi];
+    const double thr0 = c->ipm_thr0, mu0 = c->ipm_mu0, tolc = c->ipm_tol_comp, tolr = c->ipm_tol_res;
+    const int itmax = c->ipm_iter_max;
     const Dense40Lds W{L.H, L.M, L.gam, L.gam + 64};                // FAST: factor in the M region, exchange buffer / pivots in gam (free after condensing)
     if (FAST) { if (act) L.M[tri(li, li)] = 0.0; __syncthreads(); }     // diagonal slots of the packed unit factor: 0.0, never overwritten
+    QDECL();
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
         double* xb = xbarg + (size_t)inst * (N + 1) * QX;
         double* ub = ubarg + (size_t)inst * N * QU;
@@ -244,39 +259,71 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         const double* ye = yrefeg + (size_t)inst * QX;
         const double* x0 = x0g + (size_t)inst * QX;
         QSTART();
+        for (int i = lane; i < (N + 1) * QX; i += 64) L.xbs[i] = xb[i];
+        for (int i = lane; i < N * QY + QX; i += 64) L.yrs[i] = i < N * QY ? yr[i] : ye[i - N * QY];
         // ---- 1. shooting
         shoot_instance(c, xb, ub, L, lane, nullptr);
         QSTAMP(0);
         // ---- 2. condensing (oracle: condense)
-        for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0;
-        double g[QX], xh[QX];
+        if constexpr (!FAST) { for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0; }
+        double hrow[FAST ? 40 : 1];                                  // FAST: row li of H in registers, Gamma of the other inputs through DPP broadcasts
 #pragma unroll
-        for (int i = 0; i < QX; ++i) { g[i] = 0.0; xh[i] = x0[i] - xb[i]; }
+        for (int j = 0; j < (FAST ? 40 : 1); ++j) hrow[j] = 0.0;
+        double g[QX];
+#pragma unroll
+        for (int i = 0; i < QX; ++i) g[i] = 0.0;
+        if (lane < QX) L.xhs[lane] = x0[lane] - xb[lane];
         const double ubar_i = ub[li];
-        double grad = Ts * c->W[QX + mi] * (ubar_i - yr[ji * QY + QX + mi]);
+        double grad = Rw * (ubar_i - yr[ji * QY + QX + mi]);
         __syncthreads();
         for (int k = 0; k < N; ++k) {
-            double gn[QX], xn[QX];
+            double gn[QX];
+            const int rr = lane < QX ? lane : 0;
+            double xn = L.b[k * QX + rr];                                    // free response: row `lane` of A xh + b on lanes 0..12
+#pragma unroll
+            for (int cc = 0; cc < QX; ++cc) xn += L.A[(k * QX + rr) * QX + cc] * L.xhs[cc];
 #pragma unroll
             for (int r = 0; r < QX; ++r) {
-                double a = L.b[k * QX + r], s = 0.0;
+                double s = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < QX; ++cc) { const double ark = L.A[(k * QX + r) * QX + cc]; a += ark * xh[cc]; s += ark * g[cc]; }
-                xn[r] = a;
+                for (int cc = 0; cc < QX; ++cc) s += L.A[(k * QX + r) * QX + cc] * g[cc];
                 gn[r] = ji == k ? L.B[(k * QX + r) * QU + mi] : (ji < k ? s : 0.0);
             }
+            QSTAMP(8);
 #pragma unroll
-            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; if (act) L.gam[r * n + lane] = gn[r]; }
+            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; if (act) L.gam[r * n + lane] = gn[r]; }
+            if (lane < QX) L.xhs[lane] = xn;                                 // (LDS operations of one wave execute in order: every read above is done)
             __syncthreads();
-            const double* ref = k + 1 < N ? yr + (k + 1) * QY : ye;
+            QSTAMP(9);
+            const double* ref = L.yrs + (k + 1) * QY;                        // stage k + 1 (yrs[N * 17 ...] = terminal reference)
             const int lim = (k + 1) * QU;                                   // inputs of stages <= k
             double wg[QX];
 #pragma unroll
             for (int cc = 0; cc < QX; ++cc) {
-                const double wq = k + 1 < N ? Ts * c->W[cc] : c->We[cc];
+                const double wq = L.wts[(k + 1 < N ? 0 : QX) + cc];
                 wg[cc] = g[cc] * wq;
-                if (wq != 0.0) grad += wg[cc] * (xb[(k + 1) * QX + cc] + xh[cc] - ref[cc]);
+                if (wq != 0.0) grad += wg[cc] * (L.xbs[(k + 1) * QX + cc] + L.xhs[cc] - ref[cc]);
             }
+            if constexpr (FAST) {
+                // H[li][j] += sum_cc wg[cc] Gamma_j[cc] for every j at once: Gamma_j[cc] = lane j's value, picked up inside the FMAs
+                // (columns of inputs of later stages are zero on both sides)
+                (void)lim;
+#pragma unroll 1
+                for (int cc = 0; cc < QX; ++cc) {
+                    const double wq = L.wts[(k + 1 < N ? 0 : QX) + cc];
+                    if (wq == 0.0) continue;                                // wave-uniform
+                    double Rb[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) Rb[m] = L.gam[cc * n + 16 * m + (lane & 15)];
+                    double wv = wg[0];
+#pragma unroll
+                    for (int q = 1; q < QX; ++q) wv = cc == q ? wg[q] : wv;
+                    static_for<0, 10>([&](auto qq) __attribute__((always_inline)) {
+                        constexpr int i2 = 4 * decltype(qq)::value;
+                        fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[i2 / 16], wv);
+                    });
+                }
+            } else
             if (act && li < lim) {
                 for (int j = 0; j <= li; ++j) {
                     double s = L.H[tri(li, j)];
@@ -286,15 +333,20 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
                 }
             }
             __syncthreads();
+            QSTAMP(10);
         }
-        if (act) L.H[tri(li, li)] += Ts * c->W[QX + mi];
+        if constexpr (FAST) {
+            store_row_40(hrow, lds_byte_addr(L.H + (act ? tri(li, 0) : 0)));
+            __syncthreads();
+        }
+        if (act) L.H[tri(li, li)] += Rw;
         __syncthreads();
         QSTAMP(1);
         // ---- 3. box QP (oracle: box_qp)
-        const double lo = c->lbu[mi] - ubar_i, hi = c->ubu[mi] - ubar_i;
+        const double lo = lbm - ubar_i, hi = ubm - ubar_i;
         double du = 0.0;
-        double tl = act ? fmax(du - lo, c->ipm_thr0) : 1.0, tu = act ? fmax(hi - du, c->ipm_thr0) : 1.0;
-        double ll = act ? c->ipm_mu0 / tl : 0.0, lu = act ? c->ipm_mu0 / tu : 0.0;
+        double tl = act ? fmax(du - lo, thr0) : 1.0, tu = act ? fmax(hi - du, thr0) : 1.0;
+        double ll = act ? mu0 / tl : 0.0, lu = act ? mu0 / tu : 0.0;
         double alpha_prev = 1.0;
         int it = 0, st = 0;
         for (;; ++it) {
@@ -315,7 +367,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             const double rmax = wave_max(act ? fmax(fabs(rs), fmax(fabs(rl), fabs(ru))) : 0.0);
             __syncthreads();
             if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
-            if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
+            if ((cmax <= tolc && rmax <= tolr) || it >= itmax) break;
             const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
             if constexpr (!FAST) {
                 if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
@@ -414,7 +466,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         if (act && !(fabs(un) <= 1e300)) bad = true;
         double dx = lane < QX ? x0[lane] - xb[lane] : 0.0;
         double J = 0.0;
-        if (act) { const double e = un - yr[ji * QY + QX + mi]; J += 0.5 * Ts * c->W[QX + mi] * e * e; }
+        if (act) { const double e = un - yr[ji * QY + QX + mi]; J += 0.5 * Rw * e * e; }
         for (int k = 0; k < N; ++k) {
             if (lane < QX) L.gam[lane] = dx;                         // dx_k of all components
             __syncthreads();
@@ -423,7 +475,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
                 dn = L.b[k * QX + lane];
                 for (int cc = 0; cc < QX; ++cc) dn += L.A[(k * QX + lane) * QX + cc] * L.gam[cc];
                 for (int m = 0; m < QU; ++m) dn += L.B[(k * QX + lane) * QU + m] * L.vec[k * QU + m];
-                const double xv = xb[(k + 1) * QX + lane] + dn;
+                const double xv = L.xbs[(k + 1) * QX + lane] + dn;
                 L.xnew[(k + 1) * QX + lane] = xv;
                 if (!(fabs(xv) <= 1e300)) bad = true;
             }
@@ -432,8 +484,8 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         }
         for (int i = lane; i < (N + 1) * QX; i += 64) {
             const int k = i / QX, cc = i - k * QX;
-            const double e = L.xnew[i] - (k < N ? yr[k * QY + cc] : ye[cc]);
-            J += 0.5 * (k < N ? Ts * c->W[cc] : c->We[cc]) * e * e;
+            const double e = L.xnew[i] - L.yrs[k * QY + cc];
+            J += 0.5 * (k < N ? Ts * c->W[cc] : c->We[cc]) * e * e;        // (once per instance, parallel over lanes)
         }
         bad = __any(bad) != 0;
         J = wave_sum(J);
@@ -449,6 +501,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         }
         __syncthreads();
     }
+    QFLUSH();
 }
 
 }  // namespace
@@ -572,12 +625,13 @@ int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const 
 #include <cstdio>
 void admpc_quad_dump_timers(void)
 {
-    unsigned long long h[8] = {0};
+    unsigned long long h[16] = {0};
     (void)hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_quad_ticks), sizeof h) != hipSuccess) return;
-    static const char* nm[6] = {"shooting", "condensing", "residuals + Newton matrix", "Cholesky", "solves + step", "expansion"};
-    unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += h[i];
-    for (int i = 0; i < 6; ++i) fprintf(stderr, "[quad phase] %-28s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+    static const char* nm[11] = {"shooting", "condensing: setup + final store", "residuals + Newton matrix", "factorisation", "solves + step", "expansion", "-", "-",
+                                 "condensing: propagation", "condensing: publish Gamma", "condensing: gradient + Hessian"};
+    unsigned long long tot = 0; for (int i = 0; i < 11; ++i) tot += h[i];
+    for (int i = 0; i < 11; ++i) if (h[i]) fprintf(stderr, "[quad phase] %-32s %14llu ticks %5.1f %%\n", nm[i], h[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
 }
 #endif
 

@@ -9,6 +9,7 @@ from ad_mpc_amd.quad_scenarios import random_quad_scenarios
 from ad_mpc_amd.engine import QuadBatchSolver
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = default_quad_config(); s = random_quad_scenarios(B, cfg, seed=1)
+if os.environ.get("QUAD_ITMAX"): cfg.ipm_iter_max = int(os.environ["QUAD_ITMAX"])      # 0: shooting + condensing + expansion only (cost split)
 eng = QuadBatchSolver(cfg); d = lambda a: torch.as_tensor(a, device="cuda")
 x0, yr, ye, xb0, ub0 = d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["xbar"]), d(s["ubar"])
 it = torch.empty(B, dtype=torch.int32, device="cuda"); st = torch.empty(B, dtype=torch.int32, device="cuda"); co = torch.empty(B, dtype=torch.float64, device="cuda")
@@ -18,6 +19,10 @@ for rep in range(8):
     eng.solve(x0, yr, ye, xb, ub, co, st, it); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 t = np.median(ts[2:])
 print("quadrotor nx=13 nu=4 N=%d B=%d: %.3f ms/step, %.2f M solves/s; IPM iterations mean %.2f max %d; status != 0: %d" % (cfg.N, B, t * 1e3, B / t / 1e6, it.float().mean().item(), it.max().item(), int((st != 0).sum())))
+ts = []
+for rep in range(6):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); eng.shoot(xb0, ub0); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print("  shooting alone (admpc_quad_shoot_batch, includes writing A, B, phi to global memory): %.3f ms" % (np.median(ts[2:]) * 1e3))
 try:
     import ctypes
     ctypes.CDLL(eng.lib._name).admpc_quad_dump_timers()       # only in a -DADMPC_QUAD_TIMERS build
