@@ -282,11 +282,16 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             double xn = L.b[k * QX + rr];                                    // free response: row `lane` of A xh + b on lanes 0..12
 #pragma unroll
             for (int cc = 0; cc < QX; ++cc) xn += L.A[(k * QX + rr) * QX + cc] * L.xhs[cc];
+            // A_k is the same for every lane: its 169 entries are fetched by three coalesced loads (entry e on lane e mod 64) and handed
+            // to the FMAs as scalar operands (v_readlane), instead of 169 broadcast reads of LDS per lane
+            double Ar[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int e = lane + 64 * m; Ar[m] = L.A[k * QX * QX + (e < QX * QX ? e : QX * QX - 1)]; }
 #pragma unroll
             for (int r = 0; r < QX; ++r) {
                 double s = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < QX; ++cc) s += L.A[(k * QX + r) * QX + cc] * g[cc];
+                for (int cc = 0; cc < QX; ++cc) s += bcast(Ar[(r * QX + cc) / 64], (r * QX + cc) % 64) * g[cc];
                 gn[r] = ji == k ? L.B[(k * QX + r) * QU + mi] : (ji < k ? s : 0.0);
             }
             QSTAMP(8);
@@ -308,21 +313,18 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
                 // H[li][j] += sum_cc wg[cc] Gamma_j[cc] for every j at once: Gamma_j[cc] = lane j's value, picked up inside the FMAs
                 // (columns of inputs of later stages are zero on both sides)
                 (void)lim;
-#pragma unroll 1
-                for (int cc = 0; cc < QX; ++cc) {
-                    const double wq = L.wts[(k + 1 < N ? 0 : QX) + cc];
-                    if (wq == 0.0) continue;                                // wave-uniform
-                    double Rb[3];
+                double Rb[QX][3];                                           // all 39 loads first: one LDS round trip per stage, not one per component
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) Rb[m] = L.gam[cc * n + 16 * m + (lane & 15)];
-                    double wv = wg[0];
+                for (int cc = 0; cc < QX; ++cc)
 #pragma unroll
-                    for (int q = 1; q < QX; ++q) wv = cc == q ? wg[q] : wv;
+                    for (int m = 0; m < 3; ++m) Rb[cc][m] = L.gam[cc * n + 16 * m + (lane & 15)];
+                static_for<0, QX>([&](auto ccc) __attribute__((always_inline)) {
+                    constexpr int cc = decltype(ccc)::value;
                     static_for<0, 10>([&](auto qq) __attribute__((always_inline)) {
                         constexpr int i2 = 4 * decltype(qq)::value;
-                        fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[i2 / 16], wv);
+                        fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[cc][i2 / 16], wg[cc]);
                     });
-                }
+                });
             } else
             if (act && li < lim) {
                 for (int j = 0; j <= li; ++j) {
