@@ -331,28 +331,6 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
 // wave-level primitives
 // ---------------------------------------------------------------------------------------------
 #include "dense40.h"      // rdlane, WSYNC, lds_byte_addr, the 40 x 40 factorisation / substitution helpers, rcp_nr
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_mov(double ident, double v) {
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-struct OpSum { static __device__ __forceinline__ double id() { return 0.0; } static __device__ __forceinline__ double f(double a, double b) { return a + b; } };
-struct OpMax { static __device__ __forceinline__ double id() { return -INFINITY; } static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); } };
-// NaN-propagating max for residual norms
-struct OpMaxNan { static __device__ __forceinline__ double id() { return -INFINITY; }
-                  static __device__ __forceinline__ double f(double a, double b) { return (b > a || b != b) ? b : a; } };
-// DPP scan: after the six steps lane 63 holds the reduction of all 64 lanes; returned wave-uniform.
-template <class Op>
-__device__ __forceinline__ double wave_reduce(double v) {
-    v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));   // row_shr:1
-    v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));   // row_shr:2
-    v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));   // row_shr:4
-    v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));   // row_shr:8   -> lane 15 of every row = row total
-    v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));   // row_bcast:15 into rows 1,3
-    v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));   // row_bcast:31 into rows 2,3
-    return rdlane(v, 63);
-}
 
 
 // x / 7 for 0 <= x < 13107 as a 32-bit multiply-shift: hipcc 7.2 narrows small non-negative ints to 16 bits and its backend

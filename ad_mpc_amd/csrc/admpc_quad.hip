@@ -165,21 +165,11 @@ __device__ __forceinline__ double bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {         // NaN-propagating
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = (w > v || w != w) ? w : v; }
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
-}
+// wave reductions: DPP scans (dense40.h); every lane receives the result
+struct OpMin { static __device__ __forceinline__ double id() { return INFINITY; } static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); } };
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMaxNan>(v); }         // NaN-propagating
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
 
 // LDS layout (doubles): A [N][13][13] | B [N][13][4] | b [N][13] | H, M: packed lower triangles n(n+1)/2 | gam [13][n] | vec [64] | xnew [(N+1)*13]
 //   | xbs [(N+1)*13] the linearisation point | yrs [N*17 + 13] the references (stage, terminal): read stage by stage in the condensing and
