@@ -6,10 +6,13 @@
 //      [S_x S_u] through classic RK4 with the model's forward-mode tangent (the model is polynomial: no Jacobian matrix is formed);
 //   2. condensing: lane i <-> input i = (stage, rotor) carries column i of Gamma_k = d x_k / d u through the stages; the tracking
 //      terms Gamma' Q Gamma accumulate into the dense Hessian in LDS (the reference solves the same condensed QP: FULL_CONDENSING_HPIPM);
-//   3. box-constrained dense QP (N nu <= 64 inputs, one per lane): Mehrotra predictor-corrector, Cholesky with row i on lane i;
+//   3. box-constrained dense QP (N nu <= 64 inputs, one per lane): Mehrotra predictor-corrector.  N nu = 40 (the shipped N = 10): the
+//      Newton systems go through dense40.h, the machinery of the car's condensed kernel (register-resident LDL' with DPP rank-1
+//      updates, generated substitution assembly, DPP symmetric mat-vec); the Hessian row of a lane is accumulated in registers with
+//      the other lanes' Gamma picked up by DPP broadcasts.  Other horizons: Cholesky in LDS with row i on lane i (generic path);
 //   4. expansion of the states, full step, cost, status.
-// Arithmetic follows oracle/quad_oracle.c operation by operation where the order matters (Cholesky, forward substitution).
-// This path is built for coverage and parity, not tuned: the quadrotor problem is not a BASELINE config.
+// The generic path follows oracle/quad_oracle.c operation by operation where the order matters (Cholesky, forward substitution); the
+// fast path reaches the same iterates (identical iteration counts on every tested batch).  DESIGN section 7 has the numbers.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
