@@ -305,18 +305,19 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             if constexpr (FAST) {
                 // H[li][j] += sum_cc wg[cc] Gamma_j[cc] for every j at once: Gamma_j[cc] = lane j's value, picked up inside the FMAs
                 // (columns of inputs of later stages are zero on both sides)
-                (void)lim;
                 double Rb[QX][3];                                           // all 39 loads first: one LDS round trip per stage, not one per component
 #pragma unroll
                 for (int cc = 0; cc < QX; ++cc)
 #pragma unroll
                     for (int m = 0; m < 3; ++m) Rb[cc][m] = L.gam[cc * n + 16 * m + (lane & 15)];
-                static_for<0, QX>([&](auto ccc) __attribute__((always_inline)) {
-                    constexpr int cc = decltype(ccc)::value;
-                    static_for<0, 10>([&](auto qq) __attribute__((always_inline)) {
-                        constexpr int i2 = 4 * decltype(qq)::value;
-                        fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[cc][i2 / 16], wg[cc]);
-                    });
+                static_for<0, 10>([&](auto qq) __attribute__((always_inline)) {
+                    constexpr int i2 = 4 * decltype(qq)::value;
+                    if (i2 < lim) {                                         // wave-uniform: the columns of later stages' inputs are still zero
+                        static_for<0, QX>([&](auto ccc) __attribute__((always_inline)) {
+                            constexpr int cc = decltype(ccc)::value;
+                            fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[cc][i2 / 16], wg[cc]);
+                        });
+                    }
                 });
             } else
             if (act && li < lim) {
