@@ -229,7 +229,8 @@ __global__ __launch_bounds__(64) void admpc_quad_shoot_kernel(const Cfg* __restr
 template <bool FAST>
 __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                              const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
-                                                             double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg)
+                                                             double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
+                                                             int* __restrict__ ticket)
 {
     extern __shared__ double lds_raw[];
     const int N = c->N, n = N * QU, lane = threadIdx.x;
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
     const Dense40Lds W{L.H, L.M, L.gam, L.gam + 64};                // FAST: factor in the M region, exchange buffer / pivots in gam (free after condensing)
     if (FAST) { if (act) L.M[tri(li, li)] = 0.0; __syncthreads(); }     // diagonal slots of the packed unit factor: 0.0, never overwritten
     QDECL();
-    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+    // instances need 5 .. 18 interior-point iterations: with many rounds per wave the instances are drawn from a work counter (zeroed by
+    // the host before the launch; + 5 % at B = 16384), with few a static stride is cheaper (no memset node, no atomics; + 5 % at B = 4096)
+    for (int inst = blockIdx.x; inst < B;) {
         double* xb = xbarg + (size_t)inst * (N + 1) * QX;
         double* ub = ubarg + (size_t)inst * N * QU;
         const double* yr = yrefg + (size_t)inst * N * QY;
@@ -496,6 +499,11 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             if (itersg) itersg[inst] = it;
         }
         __syncthreads();
+        if (ticket) {                                                // many rounds: the next instance from the work counter
+            int tk = 0;
+            if (lane == 0) tk = atomicAdd(ticket, 1);
+            inst = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tk);
+        } else inst += (int)gridDim.x;
     }
     QFLUSH();
 }
@@ -505,6 +513,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
 struct AdmpcQuadSolver {
     AdmpcQuadConfig cfg;
     AdmpcQuadConfig* d_cfg;
+    int* d_ticket;           // work counter of the solve kernel
     int device, num_cu, lds_bytes;
     int generic;             // ADMPC_QUAD_GENERIC=1: the LDS-resident Cholesky path also at N nu = 40 (A/B tests)
 };
@@ -562,14 +571,18 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
     AdmpcQuadSolver* s = new (std::nothrow) AdmpcQuadSolver();
     if (!s) return admpc_set_error(ADMPC_ENOMEM, "out of host memory");
-    s->cfg = *cfg; s->device = device; s->d_cfg = nullptr;
+    s->cfg = *cfg; s->device = device; s->d_cfg = nullptr; s->d_ticket = nullptr;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return admpc_set_error(ADMPC_EHIP, "hipGetDeviceProperties failed"); }
     s->num_cu = prop.multiProcessorCount;
     s->lds_bytes = quad_lds_doubles(cfg->N) * (int)sizeof(double);
     { const char* e = getenv("ADMPC_QUAD_GENERIC"); s->generic = e && e[0] == '1'; }
-    if (hipMalloc((void**)&s->d_cfg, sizeof(AdmpcQuadConfig)) != hipSuccess ||
-        hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcQuadConfig), hipMemcpyHostToDevice) != hipSuccess) { if (s->d_cfg) (void)hipFree(s->d_cfg); delete s; return admpc_set_error(ADMPC_EHIP, "device allocation failed"); }
+    if (hipMalloc((void**)&s->d_cfg, sizeof(AdmpcQuadConfig)) != hipSuccess || hipMalloc((void**)&s->d_ticket, sizeof(int)) != hipSuccess ||
+        hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcQuadConfig), hipMemcpyHostToDevice) != hipSuccess) {
+        if (s->d_cfg) (void)hipFree(s->d_cfg);
+        if (s->d_ticket) (void)hipFree(s->d_ticket);
+        delete s; return admpc_set_error(ADMPC_EHIP, "device allocation failed");
+    }
     (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_shoot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -582,6 +595,7 @@ void admpc_quad_destroy(AdmpcQuadSolver* s)
     if (!s) return;
     QGuard guard(s->device);
     if (s->d_cfg) (void)hipFree(s->d_cfg);
+    if (s->d_ticket) (void)hipFree(s->d_ticket);
     delete s;
 }
 
@@ -596,10 +610,12 @@ int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const do
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
     int per_cu = (160 * 1024) / s->lds_bytes; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
     int grid = s->num_cu * per_cu; if (grid > B) grid = B;
+    int* ticket = B > 8 * grid ? s->d_ticket : nullptr;
+    if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
     if (s->cfg.N * QU == 40 && !s->generic)
-        hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters);
+        hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
     else
-        hipLaunchKernelGGL(admpc_quad_solve_kernel<false>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters);
+        hipLaunchKernelGGL(admpc_quad_solve_kernel<false>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
     if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad solve kernel launch failed");
     return ADMPC_OK;
 }
