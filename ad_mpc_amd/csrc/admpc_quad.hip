@@ -348,6 +348,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
         double ll = act ? mu0 / tl : 0.0, lu = act ? mu0 / tu : 0.0;
         double alpha_prev = 1.0;
         int it = 0, st = 0;
+        bool cons = false;                                           // fallback mode (admpc_quad.h): no second-order term
         for (;; ++it) {
             int lz = lane;                                           // laundered lane id (dense40.h)
             asm volatile("" : "+v"(lz));
@@ -366,7 +367,16 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             const double rmax = wave_max(act ? fmax(fabs(rs), fmax(fabs(rl), fabs(ru))) : 0.0);
             __syncthreads();
             if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
-            if ((cmax <= tolc && rmax <= tolr) || it >= itmax) break;
+            if ((cmax <= tolc && rmax <= tolr) || it >= itmax + (cons ? ADMPC_QUAD_IPM_FALLBACK_ITER : 0)) break;
+            if (!cons && it >= ADMPC_QUAD_IPM_FALLBACK_ITER) {          // still iterating (a limit cycle): start over, finish with plain centring steps
+                cons = true;
+                du = 0.0;
+                tl = act ? fmax(du - lo, thr0) : 1.0; tu = act ? fmax(hi - du, thr0) : 1.0;
+                ll = act ? mu0 / tl : 0.0; lu = act ? mu0 / tu : 0.0;
+                alpha_prev = 1.0;
+                --it;
+                continue;                                              // this pass is redone from the cold start (the count is unchanged)
+            }
             const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
             if constexpr (!FAST) {
                 if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             double sigma = muaff / mu; sigma = sigma * sigma * sigma;
             if (alpha_prev < ADMPC_QUAD_IPM_BLOCKED_STEP) sigma = 1.0;
             const double smu = sigma * mu;
-            const double cl = act ? (smu - dtl * dll) / tl : 0.0, cu = act ? (smu - dtu * dlu) / tu : 0.0;
+            const double cl = act ? (smu - (cons ? 0.0 : dtl * dll)) / tl : 0.0, cu = act ? (smu - (cons ? 0.0 : dtu * dlu)) / tu : 0.0;
             const double d = solve(act ? -rs + (cl - ll - Dl * rl) - (cu - lu - Du * ru) : 0.0);
             dtl = d + rl; dtu = -d + ru;
             dll = cl - ll - Dl * dtl; dlu = cu - lu - Du * dtu;

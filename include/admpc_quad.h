@@ -35,6 +35,10 @@ extern "C" {
  * Mehrotra's heuristic (mu oscillating between 2e-4 and 8e-4 with period 12 until iter_max, 0.09 off the minimiser); with 0.3 none
  * does over five scenario seeds and the mean iteration count is unchanged (9.35). */
 #define ADMPC_QUAD_IPM_BLOCKED_STEP 0.3
+/* Fallback mode (cf. cfg.ipm_fallback_iter of admpc.h): an instance still iterating after this many iterations -- 1 in 20 000 aggressive
+ * scenarios cycles until iter_max even with the safeguard above -- starts over from the cold start and finishes WITHOUT the second-order
+ * term of the corrector, on a budget of ipm_iter_max further iterations (`iters` can exceed ipm_iter_max).  Healthy instances need <= 27. */
+#define ADMPC_QUAD_IPM_FALLBACK_ITER 30
 
 typedef struct AdmpcQuadConfig {
     int32_t N;                    /* shooting intervals (reference: 10)                                            */

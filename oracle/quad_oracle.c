@@ -196,9 +196,11 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
         ll[i] = c->ipm_mu0 / tl[i]; lu[i] = c->ipm_mu0 / tu[i];
     }
     real alpha_prev = 1;
-    int it = 0;
+    int it = 0, cons = 0;                 /* cons: fallback mode (admpc_quad.h), no second-order term */
     for (;; ++it) {
-        real rs[NMAX], rl[NMAX], ru[NMAX], mu = 0, cmax = 0, rmax = 0;
+        real rs[NMAX], rl[NMAX], ru[NMAX], mu, cmax, rmax;
+    residuals:
+        mu = 0; cmax = 0; rmax = 0;
         for (int i = 0; i < n; ++i) {
             real s = g[i] - ll[i] + lu[i];
             for (int j = 0; j < n; ++j) s += H[i][j] * du[j];
@@ -209,7 +211,17 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
         }
         mu /= 2 * n;
         if (!(mu == mu) || !(rmax == rmax)) { *iters = it; return 4; }
-        if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max) break;
+        if ((cmax <= c->ipm_tol_comp && rmax <= c->ipm_tol_res) || it >= c->ipm_iter_max + (cons ? ADMPC_QUAD_IPM_FALLBACK_ITER : 0)) break;
+        if (!cons && it >= ADMPC_QUAD_IPM_FALLBACK_ITER) {
+            cons = 1;
+            for (int i = 0; i < n; ++i) {
+                du[i] = 0;
+                tl[i] = fmax(du[i] - lo[i], c->ipm_thr0); tu[i] = fmax(hi[i] - du[i], c->ipm_thr0);
+                ll[i] = c->ipm_mu0 / tl[i]; lu[i] = c->ipm_mu0 / tu[i];
+            }
+            alpha_prev = 1;
+            goto residuals;
+        }
         real M[NMAX][NMAX], invd[NMAX];
         real Dl[NMAX], Du[NMAX], da[NMAX], dtl[NMAX], dtu[NMAX], dll[NMAX], dlu[NMAX];
         for (int i = 0; i < n; ++i) {
@@ -238,7 +250,7 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
         /* corrector: complementarity target  sigma mu - dt_aff dlam_aff */
         real d[NMAX], cl[NMAX], cu[NMAX];
         for (int i = 0; i < n; ++i) {
-            cl[i] = (smu - dtl[i] * dll[i]) / tl[i]; cu[i] = (smu - dtu[i] * dlu[i]) / tu[i];
+            cl[i] = (smu - (cons ? 0 : dtl[i] * dll[i])) / tl[i]; cu[i] = (smu - (cons ? 0 : dtu[i] * dlu[i])) / tu[i];
             d[i] = -rs[i] + (cl[i] - ll[i] - Dl[i] * rl[i]) - (cu[i] - lu[i] - Du[i] * ru[i]);
         }
         chol_solve(n, M, invd, d);

@@ -40,3 +40,24 @@ for N, B, dt in ((20, 4096, np.float64), (20, 8192, np.float64), (40, 4096, np.f
                   f"(inputs of size 10; tolerance 2e-3), max iterations {mx}  [{time.time() - t0:.0f} s]", flush=True)
     del eng
 print("total instances compared:", total)
+
+# ---- the quadrotor path (fast path at N = 10, generic path at N = 5 and 16)
+from oracle.quad_oracle import QuadOracle
+from ad_mpc_amd.quad_config import default_quad_config
+from ad_mpc_amd.quad_scenarios import random_quad_scenarios
+from ad_mpc_amd.engine import QuadBatchSolver
+qo = QuadOracle()
+for N, B in ((10, 4096), (5, 1024), (16, 1024)):
+    qc = default_quad_config(); qc.N = N
+    qe = QuadBatchSolver(qc)
+    n = 0; bad = 0; itoff = 0; du = 0.0; dx = 0.0; mx = 0
+    for seed in range(seeds):
+        s = random_quad_scenarios(B, qc, seed=200 + seed)
+        g = qe.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+        r = qo.solve_batch(qc, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=nth)
+        n += B; bad += int((g[3] != r[3]).sum()); ok = r[3] == 0
+        itoff += int((ok & (g[4] != r[4])).sum()); mx = max(mx, int(g[4].max()))
+        du = max(du, float(np.abs(g[1][ok] - r[1][ok]).max(initial=0))); dx = max(dx, float(np.abs(g[0][ok] - r[0][ok]).max(initial=0)))
+    print(f"quadrotor N {N:2d} B {B:5d}: {n:6d} instances, status mismatches {bad}, iteration counts differing {itoff}, max |du| {du:.2e}, max |dx| {dx:.2e}, max iterations {mx}", flush=True)
+    total += n
+print("total instances compared (car + quadrotor):", total)

@@ -65,6 +65,27 @@ def test_quad_solve_parity_with_oracle(qoracle, N, B):
     eng.close()
 
 
+@pytest.mark.parametrize("generic", ["0", "1"])
+def test_quad_fallback_mode_on_the_device(qoracle, monkeypatch, generic):
+    """ADMPC_QUAD_IPM_FALLBACK_ITER on both device paths (dense40 fast path, LDS-resident generic path): the batch that holds the known
+    cycling instance (3012; 47 iterations with the fallback) -- every instance, iteration for iteration with the oracle."""
+    from ad_mpc_amd.engine import QuadBatchSolver
+    monkeypatch.setenv("ADMPC_QUAD_GENERIC", generic)
+    cfg = default_quad_config()
+    eng = QuadBatchSolver(cfg, device=0)
+    s = random_quad_scenarios(4096, cfg, seed=202)
+    if generic == "1":
+        s = {k: v[2900:3100] for k, v in s.items()}
+    b = 3012 - (2900 if generic == "1" else 0)
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    np.testing.assert_array_equal(g[3], o[3]); assert (o[3] == 0).all()
+    np.testing.assert_array_equal(g[4], o[4])
+    assert o[4][b] == 47
+    assert np.abs(g[1] - o[1]).max() <= 1e-8 and np.abs(g[0] - o[0]).max() <= 1e-8
+    eng.close()
+
+
 def test_quad_failure_status_and_repeatability(qeng, qoracle):
     cfg = qeng.cfg
     s = random_quad_scenarios(48, cfg, seed=5)

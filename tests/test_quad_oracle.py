@@ -112,6 +112,23 @@ def test_no_limit_cycle_on_aggressive_scenarios(qoracle):
     assert np.abs((d["u"] - s["ubar"][b]).reshape(-1) - r.x).max() <= 1e-6
 
 
+def test_fallback_mode_ends_the_remaining_limit_cycle(qoracle):
+    """ADMPC_QUAD_IPM_FALLBACK_ITER: instance 3012 of this batch (found by the GPU parity census on unseen seeds) cycled until iter_max
+    even with the centring safeguard; with the fallback it starts over after 30 iterations without the second-order term, converges
+    (47 iterations in all) and agrees with the exact active-set solution.  Nothing else of the batch gets near the threshold."""
+    from scipy.optimize import lsq_linear
+    cfg = default_quad_config()
+    s = random_quad_scenarios(4096, cfg, seed=202)
+    x, u, cost, st, it = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    b = 3012
+    assert (st == 0).all() and it[b] == 47 and np.delete(it, b).max() <= 20
+    d = qoracle.qp_debug(cfg, s["x0"][b], s["yref"][b], s["yref_e"][b], s["xbar"][b], s["ubar"][b])
+    lo = -s["ubar"][b].reshape(-1); hi = 1 - s["ubar"][b].reshape(-1)
+    Lc = np.linalg.cholesky(d["H"])
+    r = lsq_linear(Lc.T, -np.linalg.solve(Lc, d["g"]), bounds=(lo, hi), method="bvls", tol=1e-14, max_iter=2000)
+    assert np.abs((d["u"] - s["ubar"][b]).reshape(-1) - r.x).max() <= 1e-6
+
+
 def quad_gps(seed=1):
     """Three residual GPs of the body-frame acceleration: v_bx -> a_bx, (v_by, u_0) -> a_by with two length scales, v_bz -> a_bz."""
     rng = np.random.default_rng(seed)
