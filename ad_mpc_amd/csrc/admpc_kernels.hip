@@ -1513,6 +1513,7 @@ struct AdmpcSolver {
     int qmask;               // 7 when only x, y, psi carry tracking weights (specialised condensing kernel), else 127
     double* d_ws;            // [cap][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
     int32_t* d_split;        // [2 cap + 1] keys, order and count of the row kernel's second phase (split batches)
+    double* d_dump;          // [cap][16 + 31 N] LDS regions of the deferred instances between the two phases
     int split_mode;          // -1: split batches of more than 1.25 rounds of waves (default), 0: never, 1: always (ADMPC_ROWQP_SPLIT)
     double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
 };
@@ -1538,10 +1539,10 @@ extern "C" int admpc_rowqp_plan(int N, int elem, int B, int num_cu, int* rows, i
 extern "C" void admpc_rowqp_prepare(void);
 extern "C" void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
-        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ineq, double* ws, int first, int* ticket, int32_t* split);
+        double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ineq, double* ws, int first, int* ticket, int32_t* split, double* dump);
 extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
-        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ineq, float* ws, int first, int* ticket, int32_t* split);
+        float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ineq, float* ws, int first, int* ticket, int32_t* split, float* dump);
 
 extern "C" {
 
@@ -1607,7 +1608,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         int r_, st_, lb_, g_;
         if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     }
-    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr;
+    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr; s->d_dump = nullptr;
     {   // ADMPC_ROWQP_SPLIT=0 / 1: never / always run the row kernel in two phases (A/B tests); default: by batch size
         const char* e = getenv("ADMPC_ROWQP_SPLIT");
         s->split_mode = e && e[0] == '0' ? 0 : (e && e[0] == '1' ? 1 : -1);
@@ -1657,6 +1658,7 @@ void admpc_destroy(AdmpcSolver* s)
     if (s->d_aux) (void)hipFree(s->d_aux);
     if (s->d_ws) (void)hipFree(s->d_ws);
     if (s->d_split) (void)hipFree(s->d_split);
+    if (s->d_dump) (void)hipFree(s->d_dump);
     if (s->d_pairs) (void)hipFree(s->d_pairs);
     delete s;
 }
@@ -1676,7 +1678,8 @@ int admpc_reserve(AdmpcSolver* s, int B)
     if (s->d_sched) (void)hipFree(s->d_sched);
     if (s->d_ws) (void)hipFree(s->d_ws);
     if (s->d_split) (void)hipFree(s->d_split);
-    s->d_ws = nullptr; s->d_split = nullptr;
+    if (s->d_dump) (void)hipFree(s->d_dump);
+    s->d_ws = nullptr; s->d_split = nullptr; s->d_dump = nullptr;
     s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_sched = nullptr; s->cap = 0;
     const size_t N = (size_t)s->cfg.N;
     HIPCHK(hipMalloc((void**)&s->d_GT, (size_t)B * N * GTS * sizeof(double)));
@@ -1691,6 +1694,7 @@ int admpc_reserve(AdmpcSolver* s, int B)
     }
     HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 38 * sizeof(double)));       // row kernel's workspace, RQ_RW = 38 values per record (every fp32 solve, fp64 for N != 20)
     HIPCHK(hipMalloc((void**)&s->d_split, ((size_t)2 * B + 1) * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void**)&s->d_dump, (size_t)B * (16 + 31 * N) * sizeof(double)));
     s->cap = B;
     return ADMPC_OK;
 }
@@ -1773,7 +1777,7 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
             if (admpc_rowqp_plan(N, 8, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
             if (!rowqp_fits(B, N, 8)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
             admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
-                                   xbar, ubar, cost, stat, iters, pi, ineq, s->d_ws, first, s->d_sched, rowqp_split(s, B, rows, gridR));
+                                   xbar, ubar, cost, stat, iters, pi, ineq, s->d_ws, first, s->d_sched, rowqp_split(s, B, rows, gridR), s->d_dump);
         }
     }
     if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
@@ -1808,7 +1812,7 @@ int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* y
         hipLaunchKernelGGL(admpc_linearize_kernel<float>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, (const float*)xbar, (const float*)ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, (float*)s->d_GT, (float*)s->d_bl, s->d_sched);
         admpc_rowqp_launch_f32(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const float*)s->d_GT, (const float*)s->d_bl,
-                               xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, (float*)s->d_ws, first, s->d_sched, rowqp_split(s, B, rows, gridR));
+                               xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, (float*)s->d_ws, first, s->d_sched, rowqp_split(s, B, rows, gridR), (float*)s->d_dump);
     }
     if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
         hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);

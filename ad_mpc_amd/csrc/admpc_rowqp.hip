@@ -18,7 +18,8 @@
 // Split batches (more quadruples than wave slots): launch 1 (mode 1) runs roll-out + unconstrained trial for every instance and
 // finishes those the trial solves (42-55 % of the bench scenarios; every row of a wave does the same work); the others are
 // deferred with a key = number of bounds their trial minimiser violates.  admpc_rowqp_sort_kernel orders them by key, hardest
-// first.  Launch 2 (mode 2) draws quadruples from that list and solves them from scratch: rows of one wave now need similar
+// first.  Launch 2 (mode 2) draws quadruples from that list, restores their LDS regions (saved by launch 1) and continues behind the
+// trial, exactly where the one-launch solve would be: rows of one wave now need similar
 // iteration counts and the slow instances start first (a wave iterates until its slowest row has converged -- in ticket order
 // the mean of the per-wave maxima is 8.5 iterations against a mean of 4.5 per instance).
 #include "../../include/admpc.h"
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
                                                          T* __restrict__ xbarg, T* __restrict__ ubarg,
                                                          T* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
                                                          T* __restrict__ pig, T* __restrict__ ineqg, T* __restrict__ wsg, int first_pass, int* __restrict__ ticket,
-                                                         int mode, int32_t* __restrict__ keyg, const int32_t* __restrict__ permg, const int32_t* __restrict__ countg)
+                                                         int mode, int32_t* __restrict__ keyg, const int32_t* __restrict__ permg, const int32_t* __restrict__ countg,
+                                                         T* __restrict__ dumpg)
 {
     typedef DevX<T> X;
     extern __shared__ double smem_raw[];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
     RqParams<T> q;
     rq_make_params<T>(*cfg, q);
     RqArrays<T> io;
-    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig; io.ineq = ineqg; io.ws = wsg;
+    io.x0 = x0g; io.yref = yrefg; io.yref_e = yrefeg; io.GT = GTg; io.bl = blg; io.xbar = xbarg; io.ubar = ubarg; io.pi = pig; io.ineq = ineqg; io.ws = wsg; io.dump = dumpg;
     const int total = mode == 2 ? __builtin_amdgcn_readfirstlane(*countg) : B;       // mode 2: the deferred instances, permg[0 .. total)
     const int nquads = (total + rows - 1) / rows;
     const bool has_lds = row < rows;
@@ -104,19 +106,19 @@ __global__ __launch_bounds__(1024) void admpc_rowqp_sort_kernel(int B, const int
 template <class T>
 static void rowqp_launch(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                          const T* x0, const T* yref, const T* yref_e, const T* GT, const T* bl, T* xbar, T* ubar, T* cost, int32_t* stat, int32_t* iters,
-                         T* pi, T* ineq, T* ws, int first, int* ticket, int32_t* split)
+                         T* pi, T* ineq, T* ws, int first, int* ticket, int32_t* split, T* dump)
 {
     if (!split) {
         hipLaunchKernelGGL((admpc_rowqp_kernel<T>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                           xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, 0, (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                           xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, 0, (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (T*)nullptr);
         return;
     }
     int32_t* key = split; int32_t* perm = split + B; int32_t* count = split + 2 * (size_t)B;
     hipLaunchKernelGGL((admpc_rowqp_kernel<T>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                       xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, 1, key, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                       xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, 1, key, (const int32_t*)nullptr, (const int32_t*)nullptr, dump);
     hipLaunchKernelGGL(admpc_rowqp_sort_kernel, dim3(1), dim3(1024), 0, st, B, (const int32_t*)key, perm, count, ticket);
     hipLaunchKernelGGL((admpc_rowqp_kernel<T>), dim3(grid), dim3(64), lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl,
-                       xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, 2, (int32_t*)nullptr, (const int32_t*)perm, (const int32_t*)count);
+                       xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, 2, (int32_t*)nullptr, (const int32_t*)perm, (const int32_t*)count, dump);
 }
 
 }  // namespace
@@ -159,23 +161,24 @@ void admpc_rowqp_prepare(void)
     (void)hipFuncSetAttribute((const void*)admpc_rowqp_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// split: nullptr = one launch; otherwise [2 B + 1] ints of scratch (keys, order, count) and the batch goes through the two phases above
+// split: nullptr = one launch; otherwise [2 B + 1] ints of scratch (keys, order, count) and the batch goes through the two phases above;
+// dump: [B][16 + 31 N] values, the LDS regions of the deferred instances between the phases
 extern "C" __attribute__((visibility("hidden")))
 void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                             const double* x0, const double* yref, const double* yref_e, const double* GT, const double* bl,
                             double* xbar, double* ubar, double* cost, int32_t* stat, int32_t* iters, double* pi, double* ineq, double* ws, int first, int* ticket,
-                            int32_t* split)
+                            int32_t* split, double* dump)
 {
-    rowqp_launch<double>(grid, lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl, xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, split);
+    rowqp_launch<double>(grid, lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl, xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, split, dump);
 }
 
 extern "C" __attribute__((visibility("hidden")))
 void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
                             const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
                             float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ineq, float* ws, int first, int* ticket,
-                            int32_t* split)
+                            int32_t* split, float* dump)
 {
-    rowqp_launch<float>(grid, lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl, xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, split);
+    rowqp_launch<float>(grid, lds_bytes, st, d_cfg, B, rows, inst_stride, x0, yref, yref_e, GT, bl, xbar, ubar, cost, stat, iters, pi, ineq, ws, first, ticket, split, dump);
 }
 
 #ifdef ADMPC_PHASE_TIMERS

@@ -87,6 +87,7 @@ struct RqArrays {              // wave-uniform array bases (device: kernel argum
     T *pi;                     // optional snapshot: [B][N+1][7] dynamics multipliers pi_0..pi_{N-1}, row N = multiplier of the x0 equality
     T *ineq;                   // optional snapshot: [B][N][20] slacks T[10] and multipliers LAM[10] of every stage (record order)
     T *ws;                     // [B][N+1][RQ_RW]
+    T *dump;                   // split batches: [B][RQ_HDR + N RQ_RS] the LDS region of a deferred instance after its trial (phase 1 -> phase 2)
 };
 
 template <class X>
@@ -99,7 +100,7 @@ struct RowQp {
 
     const RqParams<T>& q;
     const RqArrays<T>& io;
-    I ix0, iyr, iye, igt, ibl, ixb, iub, iws, ipi, iiq;   // element offsets of the row's instance in the arrays
+    I ix0, iyr, iye, igt, ibl, ixb, iub, iws, ipi, iiq, idp;   // element offsets of the row's instance in the arrays
     Lds lds;
     const int N;
     M owns;                    // the row works on an instance of its own (rows that only shadow another row's instance never write its workspace)
@@ -129,7 +130,7 @@ struct RowQp {
     {
         wrows = X::mtrue();
         ix0 = inst * 7; iye = ix0; iyr = inst * (N * 9); igt = inst * (N * RQ_GTS); ibl = inst * (N * 7); ixb = inst * ((N + 1) * 7);
-        iub = inst * (N * 2); iws = inst * ((N + 1) * RQ_RW); ipi = ixb; iiq = inst * (N * 20);
+        iub = inst * (N * 2); iws = inst * ((N + 1) * RQ_RW); ipi = ixb; iiq = inst * (N * 20); idp = inst * (RQ_HDR + N * RQ_RS);
         lane = X::lane();
         is_x = lane < 7; is_u = (lane == 7) | (lane == 8); is6 = lane == 6; is7 = lane == 7; lt2 = lane < 2;
         const V one = splat((T)1), zero = splat((T)0);
@@ -767,21 +768,53 @@ struct RowQp {
         alpha_prev = X::sel(rows, splat((T)1), alpha_prev);
     }
 
+    // split batches: the row's LDS region (after the trial: inputs, their references, the trial's steps, gains ...) to and from io.dump
+    RQ_FN void lds_dump(M rows) {
+        const int used = RQ_HDR + N * RQ_RS;
+        RQ_NOUNROLL
+        for (int j = 0; j * 16 < used; ++j) {
+            const I o = lane + X::isplat(16 * j);
+            const M in = o < X::isplat(used);
+            const I oc = X::isel(in, o, X::isplat(0));
+            X::gst(io.dump, idp + oc, ld(oc, 0), in & rows & owns);
+        }
+    }
+    RQ_FN void lds_restore() {
+        const int used = RQ_HDR + N * RQ_RS;
+        RQ_NOUNROLL
+        for (int j = 0; j * 16 < used; ++j) {
+            const I o = lane + X::isplat(16 * j);
+            const M in = o < X::isplat(used);
+            const I oc = X::isel(in, o, X::isplat(0));
+            st(oc, 0, X::gld(io.dump, idp + oc), in);
+        }
+    }
+
     // valid: the row carries an instance to solve.  want_pi (wave-uniform): also write the multipliers of the returned iterate
     // (io.pi, io.ineq) on the rows of pim.
     // mode (wave-uniform) 0: the whole solve.  1: first phase of a split batch -- roll-out and unconstrained trial only; rows whose
-    // trial fails are reported in res.deferred and must not be finished (a second launch solves them from scratch, packed with
-    // their like: rows of one wave iterate until the slowest has converged).
+    // trial fails are reported in res.deferred and must not be finished: their LDS region goes to io.dump, their workspace records
+    // (absolute states, the trial's state steps) stay as they are, nothing else of them is written.  2: second phase -- every row is
+    // such an instance: the region is restored and the solve continues behind the trial, exactly where mode 0 would be (rows of one
+    // wave now come packed with their like: a wave iterates until its slowest row has converged).
     RQ_FN void solve(M valid, Result& res, bool want_pi, M pim, int mode) {
         const V zero = splat((T)0), one = splat((T)1);
         X::stamp(0);
-        sweep_rollout(false);
-        X::fence();
-        X::stamp(1);
         M active = valid, failed = X::mfalse(), warmrow = X::mfalse();
         I iters = X::isplat(0);
         res.deferred = X::mfalse(); res.nviol = zero;
         V rstat;                                                   // stationarity residual of the interior point's iterate (tracked)
+        if (mode == 2) {
+            lds_restore();
+            X::fence();
+            const M warm = X::mfrom(q.thw > (T)0);
+            rstat = pass_init(X::sel(warm, one, zero), X::sel(warm, splat(q.thw), splat(q.thr)), warm, X::mfalse());
+            warmrow = warm;
+            X::stamp(2);
+        } else {
+        sweep_rollout(false);
+        X::fence();
+        X::stamp(1);
         pass_trial_setup();
         X::fence();
         if (q.try_unc) {
@@ -792,13 +825,20 @@ struct RowQp {
             const M ok = pass_trial_check(res.nviol);
             const M warm = (!ok) & X::mfrom(q.thw > (T)0);
             const V a0 = X::sel(ok | warm, one, zero);
+            if (mode == 1) {                                       // deferred rows: region to io.dump, then frozen (LDS and workspace) for the rest of this launch
+                res.deferred = active & !ok;
+                if (X::any(res.deferred)) lds_dump(res.deferred);
+                wrows = !res.deferred;
+                pim = pim & !res.deferred;
+            }
             rstat = pass_init(a0, X::sel(warm, splat(q.thw), splat(q.thr)), warm, ok);
             active = active & !ok;
+            if (mode == 1) active = X::mfalse();
             warmrow = warm;
-            if (mode == 1) { res.deferred = active; active = X::mfalse(); pim = pim & !res.deferred; }
             X::stamp(2);
         } else {
             rstat = pass_init(zero, splat(q.thr), X::mfalse(), X::mfalse());
+        }
         }
         X::fence();
         Red R;

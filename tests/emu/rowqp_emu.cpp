@@ -121,21 +121,21 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
     typedef EmuX<T> X;
     const int N = cfg->N;
     RqParams<T> q; rq_make_params<T>(*cfg, q);
-    std::vector<T> lds((size_t)RQ_HDR + (size_t)N * RQ_RS), ws((size_t)(N + 1) * RQ_RW);
+    std::vector<T> lds((size_t)RQ_HDR + (size_t)N * RQ_RS), ws((size_t)(N + 1) * RQ_RW), dump((size_t)RQ_HDR + (size_t)N * RQ_RS);
     for (int b = 0; b < B; ++b) {
         for (auto& v : lds) v = std::nan("");                    // any read of an unwritten slot that matters shows up
         for (auto& v : ws) v = std::nan("");
         RqArrays<T> io;
-        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi; io.ineq = ineq; io.ws = ws.data() - (size_t)b * (N + 1) * RQ_RW;
+        io.x0 = x0; io.yref = yref; io.yref_e = yref_e; io.GT = GT; io.bl = bl; io.xbar = xbar; io.ubar = ubar; io.pi = pi; io.ineq = ineq; io.ws = ws.data() - (size_t)b * (N + 1) * RQ_RW; io.dump = dump.data() - (size_t)b * (RQ_HDR + (size_t)N * RQ_RS);
         typename X::Lds L{lds.data(), (int)lds.size()};
         RowQp<X> S(q, io, L, X::isplat(b), X::mtrue());
         typename RowQp<X>::Result res;
-        if (split) {            // the device's split batches: phase 1 (trial only), then -- if deferred -- the whole solve from scratch
+        for (auto& v : dump) v = std::nan("");
+        if (split) {            // the device's split batches: phase 1 (trial only), then -- if deferred -- phase 2 from the saved LDS region
             S.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 1);
             if (key) key[b] = res.deferred.v[0] ? (int32_t)res.nviol.v[0] : 0;
             if (res.deferred.v[0]) {
-                for (auto& v : lds) v = std::nan("");
-                for (auto& v : ws) v = std::nan("");
+                for (auto& v : lds) v = std::nan("");            // the second launch finds nothing in LDS; workspace and dump persist
                 RowQp<X> S2(q, io, L, X::isplat(b), X::mtrue());
                 S2.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 2);
                 typename X::M failed2 = res.failed; typename X::V J2; typename X::M conv2;
