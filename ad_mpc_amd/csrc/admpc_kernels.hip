@@ -1514,7 +1514,7 @@ struct AdmpcSolver {
     double* d_ws;            // [cap][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
     int32_t* d_split;        // [2 cap + 1] keys, order and count of the row kernel's second phase (split batches)
     double* d_dump;          // [cap][16 + 31 N] LDS regions of the deferred instances between the two phases
-    int split_mode;          // -1: split batches of more than 1.25 rounds of waves (default), 0: never, 1: always (ADMPC_ROWQP_SPLIT)
+    int split_mode;          // -1: split batches of more than one round of waves (default), 0: never, 1: always (ADMPC_ROWQP_SPLIT)
     double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
 };
 
@@ -1699,13 +1699,13 @@ int admpc_reserve(AdmpcSolver* s, int B)
     return ADMPC_OK;
 }
 
-// Two phases for the row kernel (admpc_rowqp.hip)?  Only with the unconstrained trial on; by default when the batch is more than 1.25
-// rounds of waves (below that every instance starts at t = 0 anyway and the second launch only costs).
+// Two phases for the row kernel (admpc_rowqp.hip)?  Only with the unconstrained trial on; by default when the batch is more than one
+// round of waves (up to one round every instance starts at t = 0 anyway: -4 .. +4 % measured; at 1.2 rounds the split already wins 18 %).
 static int32_t* rowqp_split(const AdmpcSolver* s, int B, int rows, int grid)
 {
     if (s->cfg.ipm_try_unconstrained == 0.0 || s->split_mode == 0) return nullptr;
     const int nquads = (B + rows - 1) / rows;
-    return (s->split_mode == 1 || nquads > grid + grid / 4) ? s->d_split : nullptr;
+    return (s->split_mode == 1 || nquads > grid) ? s->d_split : nullptr;
 }
 
 // kernel R addresses its arrays with 32-bit byte offsets from the (64-bit) array bases

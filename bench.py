@@ -231,7 +231,7 @@ def main():
                          "frac": ach_tf / peak_tf, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": ("one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
-                                    if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than 1.25 rounds of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
+                                    if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than one round of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
                          "kernel_ms": kern_ms,
                          "note": "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt); roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)" % ("fp32" if f32 else "fp64", peak_tf)},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,

@@ -191,7 +191,7 @@ def test_fallback_mode(gpu_engine_factory, oracle_omp):
 
 
 def test_split_batches_give_the_bits_of_one_launch(gpu_engine_factory, oracle_omp, monkeypatch):
-    """Kernel R runs batches of more than 1.25 rounds of waves in two phases (trial for all; interior point for the deferred
+    """Kernel R runs batches of more than one round of waves in two phases (trial for all; interior point for the deferred
     instances, ordered by the number of bounds their trial minimiser violates).  ADMPC_ROWQP_SPLIT=1 / 0 force / forbid it: every
     output must be bit-identical either way -- fp64 and fp32, odd batch sizes, converged SQP with its per-instance stop, the
     multiplier snapshot -- and equal to the oracle's."""
