@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--gp", action="store_true", help="config 3: GP residual dynamics active")
     ap.add_argument("--dynamic", action="store_true", help="blend speeds 3/5 m/s so that the dynamic bicycle branch is active")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-in-flight", action="store_true",
+                    help="skip the side measurement `two_in_flight` (an extra field, never `value`): the same K steps with two solver handles on two "
+                         "streams, so that the tail of one step's interior-point kernel overlaps the next step (single-process runs only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +203,25 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     it_host = iters.cpu().numpy(); st_host = status.cpu().numpy()
+    two = None
+    if not args.no_two_in_flight and not launched:
+        # two handles (each owns its workspace: one solve in flight per handle), two streams, steps alternate between them
+        eng2 = BatchSolver(cfg, device=dev_index)
+        engs = (eng, eng2); sts = (torch.cuda.Stream(), torch.cuda.Stream())
+        outs = [(torch.empty_like(cost), torch.empty_like(status), torch.empty_like(iters)) for _ in range(2)]
+        xb2 = [xinit.clone() for _ in range(K + Wm)]; ub2 = [uinit.clone() for _ in range(K + Wm)]
+        torch.cuda.synchronize()
+        for phase in (0, 1):
+            if phase == 1:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            for i in (range(Wm) if phase == 0 else range(Wm, Wm + K)):
+                with torch.cuda.stream(sts[i & 1]):
+                    engs[i & 1].solve(x0, yref, yref_e, p, xb2[i], ub2[i], *outs[i & 1])
+        torch.cuda.synchronize()
+        two = {"ms_per_step": (time.perf_counter() - t1) / K * 1e3, "solves_per_s": B * K / (time.perf_counter() - t1),
+               "note": "two batches in flight (two handles, two streams): the idle tail of kernel D of one step is filled by the next step; not `value`"}
+        assert torch.equal(xb2[Wm + K - 1], xb[Wm + K - 1]) and torch.equal(ub2[Wm + K - 1], ub[Wm + K - 1])
+        del eng2
     mean_iters = float(it_host.mean())
     if rank == 0:
         total = world * B * K
@@ -239,6 +261,8 @@ def main():
             "host_enqueue_ms_per_step": t_enq / K * 1e3, "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
             "unconstrained_trial": {"enabled": bool(trial), "fraction_solved_without_interior_point": float((it_host == 0).mean())},
         }
+        if two is not None:
+            out["two_in_flight"] = two
         if best is not None:
             bc, bidx = adist.unpack_pair(best)
             out["argmin"] = {"cost": bc, "index": bidx}
