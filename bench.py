@@ -204,24 +204,28 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     it_host = iters.cpu().numpy(); st_host = status.cpu().numpy()
     two = None
-    if not args.no_two_in_flight and not launched:
-        # two handles (each owns its workspace: one solve in flight per handle), two streams, steps alternate between them
-        eng2 = BatchSolver(cfg, device=dev_index)
-        engs = (eng, eng2); sts = (torch.cuda.Stream(), torch.cuda.Stream())
-        outs = [(torch.empty_like(cost), torch.empty_like(status), torch.empty_like(iters)) for _ in range(2)]
-        xb2 = [xinit.clone() for _ in range(K + Wm)]; ub2 = [uinit.clone() for _ in range(K + Wm)]
-        torch.cuda.synchronize()
-        for phase in (0, 1):
-            if phase == 1:
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-            for i in (range(Wm) if phase == 0 else range(Wm, Wm + K)):
-                with torch.cuda.stream(sts[i & 1]):
-                    engs[i & 1].solve(x0, yref, yref_e, p, xb2[i], ub2[i], *outs[i & 1])
-        torch.cuda.synchronize()
-        two = {"ms_per_step": (time.perf_counter() - t1) / K * 1e3, "solves_per_s": B * K / (time.perf_counter() - t1),
-               "note": "two batches in flight (two handles, two streams): the idle tail of kernel D of one step is filled by the next step; not `value`"}
-        assert torch.equal(xb2[Wm + K - 1], xb[Wm + K - 1]) and torch.equal(ub2[Wm + K - 1], ub[Wm + K - 1])
-        del eng2
+    try:
+      if not args.no_two_in_flight and not launched:
+          # two handles (each owns its workspace: one solve in flight per handle), two streams, steps alternate between them
+          eng2 = BatchSolver(cfg, device=dev_index)
+          engs = (eng, eng2); sts = (torch.cuda.Stream(), torch.cuda.Stream())
+          outs = [(torch.empty_like(cost), torch.empty_like(status), torch.empty_like(iters)) for _ in range(2)]
+          xb2 = [xinit.clone() for _ in range(K + Wm)]; ub2 = [uinit.clone() for _ in range(K + Wm)]
+          torch.cuda.synchronize()
+          for phase in (0, 1):
+              if phase == 1:
+                  torch.cuda.synchronize(); t1 = time.perf_counter()
+              for i in (range(Wm) if phase == 0 else range(Wm, Wm + K)):
+                  with torch.cuda.stream(sts[i & 1]):
+                      engs[i & 1].solve(x0, yref, yref_e, p, xb2[i], ub2[i], *outs[i & 1])
+          torch.cuda.synchronize()
+          dt2 = time.perf_counter() - t1
+          two = {"ms_per_step": dt2 / K * 1e3, "solves_per_s": B * K / dt2,
+                 "note": "two batches in flight (two handles, two streams): the idle tail of kernel D of one step is filled by the next step; not `value`"}
+          two["bit_identical_to_the_timed_run"] = bool(torch.equal(xb2[Wm + K - 1], xb[Wm + K - 1]) and torch.equal(ub2[Wm + K - 1], ub[Wm + K - 1]))
+          del eng2
+    except Exception as e:                      # a side measurement: never a reason to lose the bench line
+        two = {"error": repr(e)}
     mean_iters = float(it_host.mean())
     if rank == 0:
         total = world * B * K
