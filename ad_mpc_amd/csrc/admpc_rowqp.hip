@@ -146,7 +146,8 @@ int admpc_rowqp_plan(int N, int elem, int B, int num_cu, int* rows, int* inst_st
     // small batches: fewer instances per wave spread the work over more SIMDs (one wave per SIMD before rows are shared)
     while (r > 1 && (B + r - 1) / r < num_cu * 4 && (B + r / 2 - 1) / (r / 2) <= num_cu * 4) r >>= 1;
     int per_cu = cap / (r * stride * elem);
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 4) per_cu = 4;          // one wave per SIMD whatever the LDS allows: 256 VGPR + 148 (fp64) / 64 (fp32) AGPR per wave.  The grid must be the
+                                         // number of waves that RUN at once: the caller counts rounds with it (split batches)
     int g = num_cu * per_cu;
     const int nquads = (B + r - 1) / r;
     if (g > nquads) g = nquads;
