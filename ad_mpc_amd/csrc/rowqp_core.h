@@ -842,8 +842,11 @@ struct RowQp {
         }
         X::fence();
         Red R;
-        pass_e1(R);
-        X::fence();
+        R.mu = zero; R.cmax = zero; R.rmax = zero;
+        if (mode != 1) {                                           // (phase 1 of a split batch iterates nothing: no statistics, no predictor right-hand side)
+            pass_e1(R);
+            X::fence();
+        }
         X::stamp(3);
         V step = splat((T)1e30), rmax_prev = zero, rmax_last = zero, alpha_prev = one;
         M cons = X::mfalse();                                      // rows in fallback mode
