@@ -594,6 +594,31 @@ def test_solve_is_capturable_in_a_hip_graph(gpu_engine_factory, monkeypatch, N, 
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("N", [20, 40])
+def test_two_handles_on_two_streams(gpu_engine_factory, N):
+    """One solve in flight per handle -- two handles, two streams: independent batches overlap on the device (the second fills the tail of
+    the first; bench.py's `two_in_flight`) and every result is bit-identical to the same solves issued one after the other."""
+    import torch
+    cfg = default_config(N=N)
+    B = 1500
+    sc = [random_scenarios(B, N=N, seed=300 + i, blend=(3.0, 5.0)) for i in range(4)]
+    e0, e1 = gpu_engine_factory(cfg), gpu_engine_factory(cfg)
+    ref = [e0.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"]) for s in sc]
+    d = e0.to_device
+    dev = [[d(s[k]) for k in ("x0", "yref", "yref_e", "p", "xbar", "ubar")] for s in sc]
+    outs = [(torch.empty(B, dtype=torch.float64, device="cuda"), torch.empty(B, dtype=torch.int32, device="cuda"), torch.empty(B, dtype=torch.int32, device="cuda")) for _ in sc]
+    streams = (torch.cuda.Stream(), torch.cuda.Stream())
+    torch.cuda.synchronize()
+    for i, a in enumerate(dev):
+        with torch.cuda.stream(streams[i & 1]):
+            (e0, e1)[i & 1].solve(a[0], a[1], a[2], a[3], a[4], a[5], *outs[i])
+    torch.cuda.synchronize()
+    for i, a in enumerate(dev):
+        got = (a[4].cpu().numpy(), a[5].cpu().numpy(), outs[i][0].cpu().numpy(), outs[i][1].cpu().numpy(), outs[i][2].cpu().numpy())
+        for g, r in zip(got, ref[i]):
+            np.testing.assert_array_equal(g, r)
+
+
 def test_empty_batch_and_argument_errors(gpu_engine_factory):
     import torch
     from ad_mpc_amd import _lib
