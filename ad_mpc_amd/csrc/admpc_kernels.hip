@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/admpc.h"
+#include "argmin_rule.h"
 
 #define NX ADMPC_NX
 #define NU ADMPC_NU
@@ -1325,50 +1326,43 @@ __global__ __launch_bounds__(WAVE) void admpc_shift_kernel(const AdmpcConfig* __
     }
 }
 
-// arg-min over cost[0..B): one block; ties -> lowest index; NaN treated as +inf
+// arg-min over cost[0..B): one block; the ordering rules (ties -> lowest index; NaN read as +inf) live in argmin_rule.h
 __global__ __launch_bounds__(256) void admpc_argmin_kernel(const double* __restrict__ cost, int B, int64_t offset,
                                                            double* __restrict__ val, int64_t* __restrict__ idx)
 {
     __shared__ double sv[4];
     __shared__ int64_t si[4];
-    double best = INFINITY; int64_t bi = INT64_MAX;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-        double c = cost[i]; if (!(c == c)) c = INFINITY;
-        if (c < best || (c == best && (int64_t)i < bi)) { best = c; bi = i; }
-    }
+    ArgminBest b = argmin_identity();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) argmin_fold(b, argmin_cost(cost[i]), (int64_t)i);
     for (int o = 32; o > 0; o >>= 1) {
-        double ov = __shfl_xor(best, o, WAVE);
-        int64_t oi = __shfl_xor((long long)bi, o, WAVE);
-        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        const double ov = __shfl_xor(b.v, o, WAVE);
+        const int64_t oi = __shfl_xor((long long)b.i, o, WAVE);
+        argmin_fold(b, ov, oi);
     }
     const int w = threadIdx.x / WAVE;
-    if ((threadIdx.x & (WAVE - 1)) == 0) { sv[w] = best; si[w] = bi; }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { sv[w] = b.v; si[w] = b.i; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) if (sv[i] < best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
-        *val = best;
-        *idx = (bi == INT64_MAX ? 0 : bi) + offset;
+        for (int i = 1; i < 4; ++i) argmin_fold(b, sv[i], si[i]);
+        *val = b.v;
+        *idx = argmin_final_index(b) + offset;
     }
 }
 
 // second level of the arg-min: W gathered (cost, global index) pairs, 16 bytes each, as the per-GPU admpc_argmin wrote them
-// and an all-gather laid them out; one wave; same tie-break (lowest index) and NaN rule
+// and an all-gather laid them out; one wave; same rules (argmin_rule.h)
 __global__ __launch_bounds__(WAVE) void admpc_argmin_pairs_kernel(const double* __restrict__ pairs, int W,
                                                                   double* __restrict__ val, int64_t* __restrict__ idx)
 {
-    double best = INFINITY; int64_t bi = INT64_MAX;
-    for (int i = threadIdx.x; i < W; i += WAVE) {
-        double c = pairs[2 * i];
-        const int64_t ix = (int64_t)__double_as_longlong(pairs[2 * i + 1]);
-        if (!(c == c)) c = INFINITY;
-        if (c < best || (c == best && ix < bi)) { best = c; bi = ix; }
-    }
+    ArgminBest b = argmin_identity();
+    for (int i = threadIdx.x; i < W; i += WAVE)
+        argmin_fold(b, argmin_cost(pairs[2 * i]), (int64_t)__double_as_longlong(pairs[2 * i + 1]));
     for (int o = 32; o > 0; o >>= 1) {
-        double ov = __shfl_xor(best, o, WAVE);
-        int64_t oi = __shfl_xor((long long)bi, o, WAVE);
-        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        const double ov = __shfl_xor(b.v, o, WAVE);
+        const int64_t oi = __shfl_xor((long long)b.i, o, WAVE);
+        argmin_fold(b, ov, oi);
     }
-    if (threadIdx.x == 0) { *val = best; *idx = bi == INT64_MAX ? 0 : bi; }
+    if (threadIdx.x == 0) { *val = b.v; *idx = argmin_final_index(b); }
 }
 
 // post-solve epilogue: validity test ad_3d_optimizer.py:385-394 + Ackermann mapping
@@ -1491,6 +1485,7 @@ __global__ void admpc_actuation_kernel(int N, int B, const double* __restrict__ 
 // =============================================================================================
 #include <string>
 #include <dlfcn.h>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -1856,24 +1851,52 @@ int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, 
     return ADMPC_OK;
 }
 
+/* Host-side twin of admpc_argmin_pairs for records that were gathered into HOST memory (gloo / MPI hosts; the CPU tests of the
+ * N > 1 path): same rules, same code (argmin_rule.h).  No device, no solver handle. */
+int admpc_argmin_pairs_host(const double* pairs, int W, double* val, int64_t* idx)
+{
+    if (W <= 0) return fail(ADMPC_EINVAL, "bad argument");
+    if (!pairs || !val || !idx) return fail(ADMPC_EINVAL, "null array argument");
+    ArgminBest b = argmin_identity();
+    for (int i = 0; i < W; ++i) {
+        int64_t ix; memcpy(&ix, pairs + 2 * i + 1, sizeof ix);
+        argmin_fold(b, argmin_cost(pairs[2 * i]), ix);
+    }
+    *val = b.v; *idx = argmin_final_index(b);
+    return ADMPC_OK;
+}
+
 // RCCL is resolved at the first call (dlopen): the library loads and every other entry point works on a host without it.
 namespace {
 typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*nccl_count_t)(void*, int*);
-struct RcclApi { nccl_allgather_t all_gather; nccl_count_t comm_count; bool tried; };
-RcclApi g_rccl = { nullptr, nullptr, false };
+struct RcclApi { nccl_allgather_t all_gather; nccl_count_t comm_count; };
+RcclApi g_rccl = { nullptr, nullptr };
+std::once_flag g_rccl_once;
+// The caller's ncclComm_t belongs to the RCCL copy that created it -- in a torch process that is the librccl torch bundles
+// (SONAME librccl.so.1), not necessarily the one under /opt/rocm.  Look the symbols up in what the process has ALREADY loaded
+// first (global scope, then the two sonames without loading anything); map a fresh copy only when none is there.
+void rccl_lookup() {
+    void* ag = dlsym(RTLD_DEFAULT, "ncclAllGather");
+    void* cc = dlsym(RTLD_DEFAULT, "ncclCommCount");
+    if (!(ag && cc)) {
+        static const char* names[2] = { "librccl.so.1", "librccl.so" };
+        for (int pass = 0; pass < 2 && !(ag && cc); ++pass)           // pass 0: RTLD_NOLOAD (already mapped copies only)
+            for (int k = 0; k < 2 && !(ag && cc); ++k) {
+                void* h = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (!h) continue;
+                ag = dlsym(h, "ncclAllGather"); cc = dlsym(h, "ncclCommCount");
+            }
+    }
+    if (ag && cc) { g_rccl.all_gather = (nccl_allgather_t)ag; g_rccl.comm_count = (nccl_count_t)cc; }
+}
 }
 
 int admpc_argmin_global(AdmpcSolver* s, const double* cost, int B, int64_t index_offset, void* nccl_comm,
                         double* val, int64_t* idx, void* stream)
 {
     if (!s || !cost || !val || !idx || B <= 0 || !nccl_comm) return fail(ADMPC_EINVAL, "bad argument");
-    if (!g_rccl.tried) {
-        g_rccl.tried = true;
-        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (h) { g_rccl.all_gather = (nccl_allgather_t)dlsym(h, "ncclAllGather"); g_rccl.comm_count = (nccl_count_t)dlsym(h, "ncclCommCount"); }
-    }
+    std::call_once(g_rccl_once, rccl_lookup);
     if (!g_rccl.all_gather || !g_rccl.comm_count) return fail(ADMPC_ENODEV, "librccl.so (ncclAllGather, ncclCommCount) not available");
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");

@@ -55,12 +55,29 @@ def pack_pair(val, idx):
 
 
 def pairs_min_torch(pairs):
-    """torch restatement of admpc_argmin_pairs (NaN -> +inf, ties -> lowest global index) on float64[W,2] records; used as the
-    reducer of the gloo CPU tests, where the record path below runs without a GPU."""
+    """torch restatement of admpc_argmin_pairs (NaN -> +inf, ties -> lowest global index) on float64[W,2] records.  Kept as an
+    independent second statement of the rules: tests/argmin_spec.py checks it, the library's host reducer and the device
+    kernels against one table."""
     vals = pairs[:, 0].contiguous()
     idxs = pairs[:, 1].contiguous().view(torch.int64)
     v, i = pick_min(vals, idxs)
+    i = torch.where(i == torch.iinfo(torch.int64).max, torch.zeros_like(i), i)       # nothing but NaN / +inf records without an index
     return pack_pair(v, i)
+
+
+def pairs_min_host(pairs):
+    """Second-level reducer for records gathered into HOST memory (gloo, MPI): libadmpc's admpc_argmin_pairs_host, i.e. the same
+    source (csrc/argmin_rule.h) the device kernel admpc_argmin_pairs_kernel is compiled from.  float64[W,2] CPU tensor in,
+    float64[2] record out."""
+    import ctypes as C
+    from . import _lib
+    if pairs.device.type != "cpu" or pairs.dtype != torch.float64 or pairs.dim() != 2 or pairs.shape[1] != 2:
+        raise ValueError("pairs_min_host: float64[W,2] CPU tensor expected")
+    pairs = pairs.contiguous()
+    out = torch.empty(2, dtype=torch.float64)
+    _lib.check(_lib.load().admpc_argmin_pairs_host(C.c_void_p(pairs.data_ptr()), int(pairs.shape[0]),
+                                                   C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 8)))
+    return out
 
 
 def global_argmin_records(pair, reduce_pairs, group=None, gathered=None):

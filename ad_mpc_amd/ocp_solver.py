@@ -110,7 +110,7 @@ class AdmpcOcpSolver:
                                                     tx, tu, cost, st, it)
         torch.cuda.synchronize(self._eng.device)
         st, it, cost = st.cpu().numpy(), it.cpu().numpy(), cost.cpu().numpy()
-        if st[0] == 0:          # acados leaves the iterate untouched only if the QP failed outright
+        if st[0] in (0, 2):     # acados leaves the iterate untouched only if the QP failed outright; status 2 (SQP limit) keeps the last iterate
             self._x, self._u = tx[0].cpu().numpy(), tu[0].cpu().numpy()
             self._pi, self._ineq = pi[0].cpu().numpy(), ineq[0].cpu().numpy()
         self._status, self._qp_iter, self._cost = int(st[0]), int(it[0]), float(cost[0])

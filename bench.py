@@ -15,6 +15,13 @@ Workloads (BASELINE.json):
   --dtype f32 --horizon 80 --batch-per-gpu 16384       configs[4]: long horizon, fp32 storage and arithmetic
   --gp                                                 configs[2]: GP residual dynamics active
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its N ranks ITSELF (a child
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`, spawned before any GPU call), relays rank 0's
+JSON line and exits with the child's code.  It refuses (non-zero exit, no JSON) to run on fewer GPUs or ranks than `--gpus` asks for:
+`n_gpus` in the line is never below the request, and `ranks_seen` is what the collective itself counted (an all-reduce of ones).
+`--dry-collective gloo` rehearses exactly that launcher / rendezvous / sharding / arg-min record path on CPU ranks (no solve, no
+GPU; `value` is null and `dry` is true): the CPU test of the N > 1 path.
+
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -98,6 +105,73 @@ def cpu_baseline(cfg, scen, target_seconds=12.0):
                       % (reps, B, cfg.N, nthreads, 1.0 / t1)}
 
 
+def spawn_ranks(n):
+    """Start the N ranks of this very command as a child `python -m torch.distributed.run` (never an exec: nothing in this process
+    has touched a GPU yet, and nothing will), relay the one JSON line of rank 0, return the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("bench.py: --gpus %d without a torch.distributed environment: starting the ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        try:
+            if isinstance(json.loads(ln), dict): line = ln
+        except ValueError:
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and line is None:
+        print("bench.py: the ranks exited with 0 but printed no JSON line", file=sys.stderr)
+        return 1
+    if line is not None and proc.returncode == 0:
+        print(line, flush=True)
+    return proc.returncode
+
+
+def dry_collective(args, world, rank, launched):
+    """--dry-collective gloo: the N > 1 plumbing of this file on CPU ranks -- rendezvous, the refusal rules, contiguous shard
+    offsets, the 16-byte record path of the arg-min (reduced by libadmpc's host twin of the device reducer), barrier + max-over-ranks
+    timing, the JSON line.  Nothing is solved: the 'costs' are a fixed function of the global scenario index."""
+    B, K, Wm = args.batch_per_gpu or 8192, args.steps, args.warmup
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: the process group has %d ranks, --gpus asks for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(3)
+    ones = torch.ones(1, dtype=torch.int64)
+    if launched: dist.all_reduce(ones)
+    lo, hi = adist.shard_range(world * B, rank, world)
+    g = torch.arange(lo, hi, dtype=torch.float64)
+    cost = torch.remainder((g + 1.0) * 0.6180339887498949, 1.0) + 1.0            # golden-ratio sequence: a distinct pseudo-random cost per global index
+    best = None
+    for phase, n in ((0, Wm), (1, K)):
+        if phase == 1:
+            if launched: dist.barrier()
+            t0 = time.perf_counter()
+        for _ in range(n):
+            v, i = adist.local_argmin_torch(cost, index_offset=lo)
+            best = adist.global_argmin_records(adist.pack_pair(v, i), adist.pairs_min_host) if launched else adist.pack_pair(v, i)
+    if launched: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if launched:
+        tt = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+    if rank == 0:
+        allc = torch.remainder((torch.arange(world * B, dtype=torch.float64) + 1.0) * 0.6180339887498949, 1.0) + 1.0
+        bc, bidx = adist.unpack_pair(best)
+        print(json.dumps({"metric": "MPC solves/sec (N=%d, nx=7, nu=2, fp64)" % args.horizon, "value": None, "unit": "solves/s", "dry": True,
+                          "n_gpus": world, "ranks_seen": int(ones.item()), "steps": K, "warmup": Wm, "ms_per_step": elapsed / max(K, 1) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": "DRY RUN of the N > 1 plumbing on CPU ranks (gloo): no solve", "batch_per_gpu": B,
+                                     "collective": "gloo all-gather arg-min (16 B/rank), reducer admpc_argmin_pairs_host"},
+                          "argmin": {"cost": bc, "index": bidx},
+                          "argmin_single_process": {"cost": float(allc.min()), "index": int(torch.argmin(allc))}}), flush=True)
+    if launched:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,12 +186,28 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true",
                     help="skip the side measurement `two_in_flight` (an extra field, never `value`): the same K steps with two solver handles on two "
                          "streams, so that the tail of one step's interior-point kernel overlaps the next step (single-process runs only)")
+    ap.add_argument("--dry-collective", choices=("gloo",), default=None,
+                    help="rehearse the N > 1 launcher / rendezvous / sharding / arg-min record path on CPU ranks (no solve, no GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # torch.distributed.run: one rank per GPU, also for N = 1
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr); sys.exit(2)
+    # ---- N ranks or nothing.  No GPU call has happened yet (torch.cuda.device_count() does not initialise the device).
+    if not args.dry_collective and torch.cuda.device_count() < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible: refusing to report a smaller job" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(3)
+    if not launched and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if launched and world != args.gpus:
+        if rank == 0:
+            print("bench.py: launched with WORLD_SIZE %d but --gpus %d: refusing (n_gpus would not be what was asked)" % (world, args.gpus), file=sys.stderr)
+        sys.exit(3)
+    if args.dry_collective:
+        return dry_collective(args, world, rank, launched)
     # stdout carries exactly one JSON line: whatever native libraries print there (the RCCL banner at communicator
     # creation) is sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -127,8 +217,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: the process group has %d ranks, --gpus asks for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(3)
     dev_index = local_rank if launched else 0
     torch.cuda.set_device(dev_index)
 
@@ -182,6 +273,14 @@ def main():
             return best
         return None
 
+    ranks_seen = 1
+    if launched:                                  # what the collective itself counts: every rank adds one
+        ones = torch.ones(1, dtype=torch.int64, device=eng.device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != args.gpus:
+            print("bench.py: the all-reduce counted %d ranks, --gpus asks for %d" % (ranks_seen, args.gpus), file=sys.stderr)
+            sys.exit(3)
     for i in range(Wm):
         step(i)
     torch.cuda.synchronize()
@@ -248,7 +347,7 @@ def main():
         dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
         out = {
             "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl + ", one SQP-RTI step" + (", dynamic branch (blend 3/5)" if args.dynamic else ""),
                        "batch_per_gpu": B, "horizon": N, "seed": 1234,

@@ -210,11 +210,17 @@ int admpc_argmin(AdmpcSolver* s, const double* cost, int B, int64_t index_offset
  * (val and idx of admpc_argmin may point into one such 16-byte pair; the index travels as the bit pattern of an int64.) */
 int admpc_argmin_pairs(AdmpcSolver* s, const double* pairs, int W, double* val, int64_t* idx, void* stream);
 
+/* Host-memory twin of admpc_argmin_pairs: the same reduction (same source: csrc/argmin_rule.h) over W records that an all-gather
+ * left in HOST memory (a gloo / MPI host, the world-size-2 CPU tests of the N > 1 path).  pairs, val, idx are host pointers; no
+ * device and no solver handle are touched.  It reduces 16-byte records only -- it is not a CPU path of the solve. */
+int admpc_argmin_pairs_host(const double* pairs, int W, double* val, int64_t* idx);
+
 /* The whole cross-GPU arg-min for a host that is not Python (one process per GPU): local admpc_argmin into a 16-byte
  * (cost, global index) record, ncclAllGather of the records over `nccl_comm` (an ncclComm_t of RCCL, passed as void*; 16 B per rank:
  * the only collective of the whole path), admpc_argmin_pairs over the gathered records -- three operations on `stream`, no host
- * synchronisation.  Every rank receives the winner in val / idx (device scalars).  RCCL is looked up at the first call (dlopen of
- * librccl.so); ADMPC_ENODEV when it is not installed. */
+ * synchronisation.  Every rank receives the winner in val / idx (device scalars).  RCCL is looked up at the first call: first among the
+ * libraries the process has already loaded (the communicator belongs to the copy that created it -- torch bundles its own librccl.so.1),
+ * then by dlopen of librccl.so.1 / librccl.so; ADMPC_ENODEV when it is not installed. */
 int admpc_argmin_global(AdmpcSolver* s, const double* cost, int B, int64_t index_offset, void* nccl_comm,
                         double* val, int64_t* idx, void* stream);
 

@@ -36,14 +36,15 @@ def _worker(rank, world, port, per_rank, seed, q):
         cfg = default_config()
         _, _, cost, st, _ = Oracle().solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
         cost_t = torch.from_numpy(cost)
-        # the device path's record flow: local arg-min -> 16-byte record -> all-gather -> second-level arg-min over the records
+        # the device path's record flow: local arg-min -> 16-byte record -> all-gather -> second-level arg-min over the records,
+        # reduced by libadmpc's admpc_argmin_pairs_host: the source the device kernel is compiled from (csrc/argmin_rule.h)
         v, i = adist.local_argmin_torch(cost_t, index_offset=lo)
-        win = adist.global_argmin_records(adist.pack_pair(v, i), adist.pairs_min_torch)
+        win = adist.global_argmin_records(adist.pack_pair(v, i), adist.pairs_min_host)
         gv, gi = adist.unpack_pair(win)
         # ties across ranks: the same value from both -> the lowest GLOBAL index wins; a NaN record never wins
-        tie = adist.global_argmin_records(adist.pack_pair(torch.tensor([1.5], dtype=torch.float64), torch.tensor([lo + 5], dtype=torch.int64)), adist.pairs_min_torch)
+        tie = adist.global_argmin_records(adist.pack_pair(torch.tensor([1.5], dtype=torch.float64), torch.tensor([lo + 5], dtype=torch.int64)), adist.pairs_min_host)
         nanr = adist.global_argmin_records(adist.pack_pair(torch.tensor([float("nan") if rank == 0 else 2.5], dtype=torch.float64),
-                                                           torch.tensor([lo], dtype=torch.int64)), adist.pairs_min_torch)
+                                                           torch.tensor([lo], dtype=torch.int64)), adist.pairs_min_host)
         # and the older (value, index) interface gives the same winner
         ov, oi = adist.global_argmin(v, i)
         q.put((rank, gv, gi, adist.unpack_pair(tie), adist.unpack_pair(nanr), cost.tolist(), lo, float(ov), int(oi)))
@@ -73,3 +74,59 @@ def test_two_rank_record_path_matches_single_process_scan():
         assert r[3] == (1.5, los[0] + 5)                                  # tie -> lowest global index (rank 0's shard)
         assert r[4] == (2.5, los[1])                                      # NaN never wins
         assert (r[7], r[8]) == expect
+
+
+def _records(recs):
+    t = torch.empty((len(recs), 2), dtype=torch.float64)
+    for k, (c, i) in enumerate(recs):
+        t[k, 0] = c
+        t[k, 1:2].view(torch.int64)[0] = i
+    return t
+
+
+def test_argmin_rules_table_on_the_host_reducers():
+    """tests/argmin_spec.py: one table for every implementation of the arg-min rules.  Here: the library's host reducer
+    (admpc_argmin_pairs_host -- csrc/argmin_rule.h, the source of the device kernels) and the torch restatement; the device
+    kernels run the same table in tests/test_gpu_parity.py."""
+    sys.path.insert(0, ROOT)
+    from ad_mpc_amd import dist as adist
+    from tests import argmin_spec as spec
+    assert len(spec.CASES) >= 20
+    for name, recs, want in spec.CASES:
+        assert spec.reference(recs) == want, name
+        for impl in (adist.pairs_min_host, adist.pairs_min_torch):
+            got = adist.unpack_pair(impl(_records(recs)))
+            assert got[1] == want[1] and (got[0] == want[0]), (name, impl.__name__, got, want)
+    for name, costs, off, want in spec.ARRAY_CASES:
+        v, i = adist.local_argmin_torch(torch.tensor(costs, dtype=torch.float64), index_offset=off)
+        assert (float(v), int(i)) == want, (name, float(v), int(i), want)
+        # the first level followed by a one-record second level is the identity
+        assert adist.unpack_pair(adist.pairs_min_host(adist.pack_pair(v, i).reshape(1, 2))) == want, name
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks_and_never_reports_fewer():
+    """`python bench.py --gpus 2` with no torch.distributed environment must start two ranks itself (it used to
+    run one rank and print n_gpus 1).  --dry-collective gloo runs that launcher, the rendezvous, the shard offsets and the record
+    path of the arg-min on CPU ranks; the winner must be the single-process arg-min and sit in rank 1's shard.  Without the dry
+    switch and without GPUs the bench refuses instead of reporting a smaller job."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-collective", "gloo", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1                                               # ONE JSON line, relayed from rank 0
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["ranks_seen"] == 2 and js["dry"] is True and js["value"] is None and js["steps"] == 3
+    assert js["argmin"] == js["argmin_single_process"] and js["argmin"]["index"] == 10945 >= 8192
+    # a world size that contradicts --gpus is refused by every rank
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), bench, "--gpus", "4", "--dry-collective", "gloo"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=280)
+    assert r.returncode != 0 and b"n_gpus" not in r.stdout
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+        assert r.returncode == 3 and r.stdout.strip() == b"" and b"refusing" in r.stderr

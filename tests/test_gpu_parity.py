@@ -785,6 +785,33 @@ def test_argmin_kernel(gpu_engine_factory):
     assert math.isinf(v.item()) and i.item() == 7
 
 
+def test_argmin_rules_table_on_the_device_reducers(gpu_engine_factory):
+    """tests/argmin_spec.py -- the table tests/test_dist_gloo.py runs against the host reducer of the world-size-2 gloo path --
+    against the device kernels: admpc_argmin_pairs on every case, admpc_argmin on the cost-array cases and on every case whose
+    records carry consecutive indices, and the library's host twin once more in this process (same answers, bit for bit)."""
+    import torch
+    from ad_mpc_amd import dist as adist
+    from tests import argmin_spec as spec
+    eng = gpu_engine_factory(default_config())
+
+    def records(recs):
+        a = np.empty((len(recs), 2)); a[:, 0] = [c for c, _ in recs]
+        a[:, 1] = np.array([i for _, i in recs], dtype=np.int64).view(np.float64)
+        return a
+    for name, recs, want in spec.CASES:
+        rec = records(recs)
+        dev = adist.unpack_pair(eng.argmin_pairs(eng.to_device(rec)))
+        host = adist.unpack_pair(adist.pairs_min_host(torch.from_numpy(rec)))
+        assert dev == want and host == want, (name, dev, host, want)
+        if spec.consecutive((name, recs, want)):
+            v, i = eng.argmin(eng.to_device(rec[:, 0].copy()), index_offset=recs[0][1])
+            assert (v.item(), i.item()) == want, name
+    for name, costs, off, want in spec.ARRAY_CASES:
+        v, i = eng.argmin(eng.to_device(np.array(costs)), index_offset=off)
+        assert (v.item(), i.item()) == want, (name, v.item(), i.item(), want)
+        assert adist.unpack_pair(eng.argmin_pair(eng.to_device(np.array(costs)), index_offset=off)) == want, name
+
+
 def test_epilogue_kernel_matches_host_logic(gpu_engine_factory):
     import torch
     from ad_mpc_amd import host

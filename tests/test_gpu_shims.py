@@ -135,6 +135,32 @@ def test_shift_iterate_option_of_the_seam(oracle):
         sol.solve()
 
 
+def test_seam_adopts_the_iterate_at_the_sqp_limit(oracle):
+    """acados keeps the last SQP iterate on status 2 (nlp_solver_max_iter reached); only a QP failure (status 4) leaves it
+    untouched.  With sqp_iters = 2 and a tolerance the random scenario cannot reach in two steps the seam must return status 2
+    AND hand back the new iterate (get / store_iterate), equal to two oracle steps."""
+    from ad_mpc_amd.ocp_solver import AdmpcOcpSolver
+    from ad_mpc_amd.scenarios import random_scenarios
+    cfg = default_config(N=20)
+    cfg.sqp_iters = 2; cfg.sqp_tol = 1e-12
+    s = random_scenarios(1, N=20, seed=33)
+    sol = AdmpcOcpSolver(cfg)
+    for k in range(20):
+        sol.set(k, "yref", s["yref"][0, k])
+    sol.set(20, "yref", s["yref_e"][0])
+    sol.set(0, "lbx", s["x0"][0]); sol.set(0, "ubx", s["x0"][0])
+    for k in range(21):
+        sol.set(k, "p", np.array([s["p"][0]])); sol.set(k, "x", s["xbar"][0, k])
+    before = np.array([sol.get(k, "u") for k in range(20)])
+    assert sol.solve() == 2
+    after = np.array([sol.get(k, "u") for k in range(20)])
+    xo, uo, co, so, io = oracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+    assert so[0] == 2
+    assert np.abs(after - before).max() > 1e-3                      # the iterate moved
+    assert np.abs(after - uo[0]).max() < 1e-8                       # ... to the oracle's second SQP iterate
+    assert sol.get_cost() == pytest.approx(co[0], rel=1e-9)        # cost and iterate belong together
+
+
 def test_store_iterate_carries_the_acados_multipliers(golden_kat, tmp_path):
     """AdmpcOcpSolver.store_iterate writes pi / lam / t / sl / su in the layout of the reference's sim_car_iterate.json
     (stage 0: 22 multipliers, later stages 10, terminal stage none): solve one RTI step from the reference's converged
