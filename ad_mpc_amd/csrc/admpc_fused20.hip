@@ -1,0 +1,854 @@
+// admpc_fused20.hip -- the N = 20 fp64 SQP-RTI step (BASELINE configs[1..3]) as ONE persistent kernel for gfx950.
+//
+// One wavefront (= one workgroup of 64 lanes) owns one MPC instance from its inputs to its outputs and then draws the next one
+// from a ticket counter.  Nothing but the algorithmic inputs and outputs of SURVEY 8a crosses HBM: the packed linearisation
+// (7.8 KB), the condensed Hessian (6.6 KB), its factor (6.6 KB) and every intermediate live in the wave's 25.6 KB of LDS or in
+// registers -- six instances per CU.  Phases of an instance (reference = data_driven_mpc/ros_gp_mpc/src/ad_mpc/...):
+//   A  H0/H1  ERK4 + forward sensitivities of all 20 stages           ad_3d_optimizer.py:280-310, acados ERK
+//             (A1: lanes (stage, third) integrate the state and table      (acados_solver_sim_car.c:655-665)
+//              the Jacobian entries of the four RK stages in LDS; A2: the same lanes integrate their 2-3 sensitivity columns
+//              from the tables -- the split keeps the phase inside the 256-register budget of two waves per SIMD)
+//   C  H2-H4  Gauss-Newton cost, bounds, full condensing                ad_3d_optimizer.py:146-199; acados_solver_sim_car.c:145
+//   D  H5     unconstrained trial, Mehrotra predictor-corrector on the dense 40-input QP (reference: HPIPM, :688-692)
+//   E  H6     state expansion, full step, cost, status                  acados_solver_sim_car.c:647-648,677
+// The phase bodies are the ones of the four-kernel pipeline in admpc_kernels.hip (kernels A, C, D, E), which
+// stays as the A/B reference (ADMPC_N20=split); what changes is where the data lives and that no instance waits for a kernel
+// boundary: the slowest instance of a batch starts at once instead of after everybody's linearisation and condensing.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/admpc.h"
+
+#define NX ADMPC_NX
+#define NU ADMPC_NU
+#define NY ADMPC_NY
+#define WAVE 64
+#define IPM_FLOOR 1e-40
+#define GTS 42           // values per stage of the packed linearisation (see kernel A in admpc_kernels.hip)
+
+namespace {
+
+// ---- optional per-phase wave-time accounting (build with -DADMPC_PHASE_TIMERS: `make timers`): s_memtime ticks (100 MHz) summed
+//      over all waves: 0 ticket draw, 1 A1 (state RK4 + model), 2 A2 (sensitivity columns), 3 C (condensing), 4 D trial,
+//      5 D interior-point iterations, 6 E (expansion + outputs); [8] wave-time from kernel start to the wave's exit
+#ifdef ADMPC_PHASE_TIMERS
+__device__ unsigned long long g_f20_ticks[16];
+__device__ __forceinline__ unsigned long long f20_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
+#define F20_DECL() unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = f20_now(); unsigned long long ph_last = ph_t0
+#define F20_STAMP(k) do { const unsigned long long t_ = f20_now(); ph_acc[k] += t_ - ph_last; ph_last = t_; } while (0)
+#define F20_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_f20_ticks[q_], ph_acc[q_]); atomicAdd(&g_f20_ticks[8], f20_now() - ph_t0); atomicMax(&g_f20_ticks[9], f20_now() - ph_t0); } } while (0)
+#else
+#define F20_DECL() do { } while (0)
+#define F20_STAMP(k) do { } while (0)
+#define F20_FLUSH() do { } while (0)
+#endif
+
+#include "model_dev.h"
+#include "dense40.h"
+#include "cond_common.h"
+
+// LDS map of one instance (doubles): what the interior point needs and nothing else -- 17.7 KB, eight instances per CU (two waves per
+// SIMD).  The exchange buffers keep the relative layout dense40.h's col_head assumes (sb = cb + 128).  The other phases alias it:
+//   A   JT [0, 1920) Jacobian tables of the RK stages, bl [1920, 2060) defects; then GT [0, 840) (written when the tables are dead)
+//   C   reads GT, bl; dq [860, 1008), gam [1008, 1456); leaves H in [0, 820) (row store after the last read of GT)
+//   E   GT [820, 1660), bl [1660, 1800) read back from the wave's slot buffer; dq [0, 148), du [148, 212)
+// The packed linearisation (GT, bl: 7.8 KB) has to survive the interior point for the expansion: it is parked in a slot buffer in
+// global memory that belongs to the WAVE, not to the instance (grid x 980 doubles = 16 MB at most, reused for every instance the wave
+// draws: L2-resident), written behind phase A and read back in front of phase E.
+struct FusedLds {
+    static constexpr int N = 20, NTRI = 820;
+    static constexpr int oH = 0, oL = oH + NTRI, oPark = oL + NTRI, oCb = oPark + 5 * 64;
+    static constexpr int total = oCb + 4 * 64;                          // 2216 doubles = 17 728 B
+    static constexpr int JTS = 24;                                      // Jacobian entries per (stage, RK stage)
+    static constexpr int oJT = 0, oBlA = N * 4 * JTS, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
+    static constexpr int oGTE = NTRI, oBlE = oGTE + N * GTS, oDqE = 0, oDuE = 148;
+    static constexpr int SLOT = N * GTS + N * NX;                       // doubles per wave in the slot buffer
+    static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + NX * 64 <= oPark && oBlE + N * NX <= total, "LDS aliases");
+};
+
+// ---- work order.  A wave owns an instance for 40 us (the trial solves it) up to 200 us (13 interior-point iterations), and a batch
+// of 4096 is two rounds of the 2048 resident waves: an expensive instance that is drawn late IS the kernel's run time.  A pre-pass
+// (one thread per instance, a few loads) bins the instances by a kinematic estimate of how far the longitudinal input has to leave
+// its box: the constant acceleration that carries the vehicle from x0 to the along-track position of the terminal reference,
+// a = 2 (s_ref - v_x T) / T^2, against [lbu_0, ubu_0].  On the config-2 scenarios every instance that needs 8 or more iterations
+// is in the first round with it, and 1837 of the 1841 that need the interior point at all (correlation with the iteration count
+// 0.80).  A heuristic: it orders work and nothing else -- results do not depend on the draw order.
+//   sched: [0] ticket counter, [1] exit counter, [F20_BINS0 + q] instances in bin q, [F20_HDR + q * cap + j] j-th instance of bin q
+#define F20_NB 64
+#define F20_BINS0 64
+#define F20_HDR 128
+__global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig* __restrict__ cfg, int B, const double* __restrict__ x0g,
+                                                               const double* __restrict__ yrefeg, int* __restrict__ sched, int cap)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* x0 = x0g + (size_t)b * NX;
+    const double* ye = yrefeg + (size_t)b * NX;
+    const double T = cfg->Ts * (double)cfg->N;
+    double sn, cs;
+    sincos(x0[2], &sn, &cs);
+    const double along = cs * (ye[0] - x0[0]) + sn * (ye[1] - x0[1]);
+    const double areq = 2.0 * (along - x0[3] * T) / (T * T);
+    const double lb = cfg->lbu[0], ub = cfg->ubu[0];
+    const double ov = fmax(areq - ub, lb - areq) / (ub - lb);          // < 0: that far inside the box
+    int q = 0;
+    if (ov == ov && ov > -0.125) q = 1 + (int)fmin(fmax((ov + 0.125) * 32.0, 0.0), (double)(F20_NB - 2));
+    const int pos = atomicAdd(sched + F20_BINS0 + q, 1);
+    sched[F20_HDR + (size_t)q * cap + pos] = b;
+}
+
+// next instance for a persistent wave (wave-uniform), -1 when the batch is drained: tickets walk the bins from the most expensive
+// down.  First ticket = block index (2048 simultaneous atomics on one word queue up for ~20 us), later ones from the counter.
+__device__ __forceinline__ int f20_next(int* __restrict__ sched, int cap, bool first, int lane) {
+    int t = blockIdx.x;
+    if (!first) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(sched, 1);
+        t = (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
+    }
+    const int c = sched[F20_BINS0 + F20_NB - 1 - lane];
+    const int incl = wave_scan_incl_int(c);
+    const unsigned long long m = __ballot(incl > t);
+    if (m == 0ull) return -1;
+    const int l = __ffsll((long long)m) - 1;
+    const int base = __builtin_amdgcn_readlane(incl - c, l);
+    return __builtin_amdgcn_readfirstlane(sched[F20_HDR + (size_t)(F20_NB - 1 - l) * cap + (t - base)]);
+}
+
+template <int QMASK>
+__global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                                const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                                const double* __restrict__ yrefeg, const double* __restrict__ pg,
+                                                                double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                                double* __restrict__ costg, int32_t* __restrict__ statusg,
+                                                                int32_t* __restrict__ itersg, int first_pass, int* __restrict__ sched, int cap,
+                                                                double* __restrict__ slotbuf)
+{
+    constexpr int N = 20, n = 40;
+    extern __shared__ double lds_raw[];
+    double* const Hp = lds_raw + FusedLds::oH;          // packed lower-triangular rows of H
+    double* const Lp = lds_raw + FusedLds::oL;          // packed strictly-lower rows of the unit factor L (M = L D L')
+    double* const park = lds_raw + FusedLds::oPark;     // [5][64] per-lane constants (registers are the scarce resource)
+    double* const cb = lds_raw + FusedLds::oCb;         // [64] step broadcast buffer
+    double* const invd = cb + 64;                       // [64] 1 / D_jj
+    double* const sb = invd + 64;                       // [64] per-stage exchange
+    double* const sb2 = sb + 64;                        // [64]
+    double* const JT = lds_raw + FusedLds::oJT;         // phase A: [N][4][24] Jacobian entries of the RK stages
+    double* const GT = lds_raw + FusedLds::oGTC;        // phases A (end), C: packed linearisation of the instance
+    double* const bl = lds_raw + FusedLds::oBlA;        // phases A, C: defects b_k
+    double* const dqC = lds_raw + FusedLds::oDqC;       // phase C: xbar_k - xref_k
+    double* const gam = lds_raw + FusedLds::oGam;       // phase C: [NX][64] Gamma components of the current stage
+    double* const GTe = lds_raw + FusedLds::oGTE;       // phase E: the linearisation again (from the slot buffer)
+    double* const ble = lds_raw + FusedLds::oBlE;
+    double* const dqE = lds_raw + FusedLds::oDqE;       // phase E: xbar_k - xref_k, overwritten by dx_k
+    double* const dus = lds_raw + FusedLds::oDuE;       // phase E: [64] du per input
+    double* const slot = slotbuf + (size_t)blockIdx.x * FusedLds::SLOT;
+#define PK_DL   park[0 * 64 + lane]
+#define PK_DUU  park[1 * 64 + lane]
+#define PK_G0   park[2 * 64 + lane]
+#define PK_DDL  park[3 * 64 + lane]
+#define PK_DDU  park[4 * 64 + lane]
+
+    // Every phase derives its per-lane quantities from a freshly laundered lane id and reads its constants through a freshly
+    // laundered config pointer: what is loop-invariant across instances must be recomputed in place -- hoisted out of the persistent
+    // loop it was parked in scratch (257 SGPR lanes and 89 VGPRs in the first build) and reloaded inside the stage loops.
+// lane id from v_mbcnt (a workgroup is one wave), never from threadIdx.x: v0 would stay live (and be spilled) across the whole kernel
+#define LAUNDER_LANE(v) int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(v))
+// an opaque zero offset, not an opaque pointer: the compiler keeps knowing that the config is uniform, read-only global memory (s_load)
+#define LAUNDER_CFG(c) int c##_z = 0; asm volatile("" : "+s"(c##_z)); const AdmpcConfig* __restrict__ c = cfg + c##_z
+
+    // Factorisation of the Newton matrix M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) into L D L' (LDS: Lp, invd);
+    // text of kernel D (admpc_kernels.hip), see there and dense40.h for the look-ahead scheme.
+    auto factorise = [&](const double dbar_, const double sodd_, const int lz_) __attribute__((always_inline)) {
+        const int trz_ = lz_ * (lz_ + 1) / 2;
+        const bool uz_ = lz_ < n;
+        double a[n];
+        newton_row_40(a, lds_byte_addr(Hp + (uz_ ? trz_ : 0)), dbar_, sodd_);
+        const unsigned lrow = lds_byte_addr(Lp + (uz_ ? trz_ : 0));
+        const unsigned pub_wr = lds_byte_addr(cb + lz_), pub_rd = lds_byte_addr(cb + (lz_ & 15));
+        auto chain = [&](auto jc, double& nln) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const double dj = rdlane(a[j], j);
+            const double dinv = rcp_nr(dj);                             // 1 / D_jj
+            const double lu = a[j] * dinv;                              // L_ij for the lanes below the diagonal
+            invd[j] = dinv;                                             // uniform value, same address
+            if constexpr (j + 1 < n) {
+                asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
+                             : : "v"(lrow), "v"(lu), "n"(n - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
+                nln = -lu;
+            }
+        };
+        double Rb[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, nlb[2] = {0.0, 0.0};
+        cb[lz_] = a[0];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) Rb[0][m] = cb[16 * m + (lz_ & 15)];
+        chain(std::integral_constant<int, 0>{}, nlb[0]);
+        static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr bool own = (j + 1) / 16 == 2;                     // column j: DPP sources are the lanes' own registers (VALU-written)
+            constexpr bool pub = j + 2 < n && (j + 2) / 16 < 2;         // column j + 1 still needs its blocks in other rows
+            double (&R)[3] = Rb[j & 1];
+            double (&Rn)[3] = Rb[(j + 1) & 1];
+            double& nl = nlb[j & 1];
+            double& nln = nlb[(j + 1) & 1];
+            col_head<j + 1, (j + 2) / 16, pub, own>(a[j + 1], R, nl, Rn, pub_wr, pub_rd);
+            if constexpr (!pub) Rn[2] = a[j + 1];                       // only lanes 32..39 are still involved: own row
+            chain(std::integral_constant<int, j + 1>{}, nln);
+            constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;        // first 4-aligned column >= j + 2
+            static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
+                constexpr int jj = decltype(c)::value;
+                if constexpr (own) fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
+                else fmac_rowbc_ld<jj % 16>(a[jj], R[jj / 16], nl);
+            });
+            static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
+                constexpr int jj = 4 * decltype(c)::value;
+                if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+                else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+            });
+        });
+        WSYNC();
+    };
+    // M x = y through the factor: L z = y, z *= D^-1, L' x = z (assembly, see gen_subst_asm.py)
+    auto ldl_solve = [&](double y, const int lz_) __attribute__((always_inline)) -> double {
+        const bool uz_ = lz_ < n;
+        const unsigned pub = lds_byte_addr(cb + (lz_ & 15));                              // cb is free while a system is being solved
+        fwd_subst_40(y, lds_byte_addr(Lp + (uz_ ? lz_ * (lz_ + 1) / 2 : 0)), pub);      // idle lanes never take part (EXEC masks)
+        double x = y * invd[uz_ ? lz_ : 0];
+        bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)), pub);
+        return x;
+    };
+
+    // ---------------- persistent loop: first ticket = block index, later ones from one global counter ----------------
+    F20_DECL();
+    bool first_ticket = true;
+    for (;;) {
+        LAUNDER_LANE(lane0);
+        const int inst = f20_next(sched, cap, first_ticket, lane0);
+        first_ticket = false;
+        if (inst < 0) break;
+        if (!first_pass && statusg[inst] != 0) continue;    // failed / converged in an earlier SQP iteration of this call
+        double* const xbg = xbarg + (size_t)inst * (N + 1) * NX;
+        double* const ubg = ubarg + (size_t)inst * N * NU;
+        const double* yrg = yrefg + (size_t)inst * N * NY;
+
+        // =================================================================================================================
+        // phase A (H0/H1): ERK4 + forward sensitivities.  Lane 3k + g <-> (stage k, column group g) as in kernel A:
+        // g = 0: x-columns 2,3,4; g = 1: x-columns 5,6; g = 2: u-columns 0,1.  Lanes 60..63 shadow task 59 and store nothing.
+        // =================================================================================================================
+#ifndef F20_NO_A
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const double h = cf->Ts;
+            const int tsk = lane < 3 * N ? lane : 3 * N - 1;
+            const int k = (int)(((unsigned)tsk * 21846u) >> 16), g = tsk - 3 * k;      // tsk / 3, tsk % 3 without a narrow udivrem
+            const bool live = lane < 3 * N;
+        F20_STAMP(0);
+            // ---- A1: the state through the four RK stages (all three lanes of a stage, redundantly: they share the GP sums);
+            //      lane g == 0 tables the Jacobian entries of every RK stage and writes the defect
+            {
+                const double pin = pg[inst];
+                double x[NX], u[NU], xn1[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { x[i] = xbg[k * NX + i]; xn1[i] = xbg[(k + 1) * NX + i]; }
+                u[0] = ubg[k * NU]; u[1] = ubg[k * NU + 1];
+                double kx[NX], accx[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { kx[i] = 0.0; accx[i] = 0.0; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double cs = (s == 0) ? 0.0 : (s == 3 ? 1.0 : 0.5);
+                    const double ws = (s == 0 || s == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
+                    double X[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) X[i] = x[i] + cs * h * kx[i];
+                    ModelEvalT<double> e;
+                    model_eval<double>(cf, X, u, pin, e);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { kx[i] = e.f[i]; accx[i] += ws * e.f[i]; }
+                    if (live && g == 0) {
+                        double2* jt = reinterpret_cast<double2*>(JT + (k * 4 + s) * FusedLds::JTS);
+                        jt[0] = make_double2(e.j0[0], e.j0[1]); jt[1] = make_double2(e.j0[2], e.j1[0]); jt[2] = make_double2(e.j1[1], e.j1[2]);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { jt[3 + 2 * r] = make_double2(e.a[r][0], e.a[r][1]); jt[4 + 2 * r] = make_double2(e.a[r][2], e.a[r][3]); }
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) jt[9 + r] = make_double2(e.bu[r][0], e.bu[r][1]);
+                    }
+                }
+                if (live && g == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) bl[k * NX + i] = (x[i] + h * accx[i]) - xn1[i];
+                }
+            }
+            WSYNC();
+        F20_STAMP(1);
+            // ---- A2: the sensitivity columns of the lane's group from the tabled Jacobians (text of rk4_group / sens_rhs)
+            {
+                const int xcol0 = g == 0 ? 2 : 5;
+                double kS[3][NX], accS[3][NX];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { kS[cc][i] = 0.0; accS[cc][i] = 0.0; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double cs = (s == 0) ? 0.0 : (s == 3 ? 1.0 : 0.5);
+                    const double ws = (s == 0 || s == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
+                    double S[3][NX];
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) {
+                            const double id = (g < 2 && i == xcol0 + cc) ? 1.0 : 0.0;
+                            S[cc][i] = id + cs * h * kS[cc][i];
+                        }
+                    ModelEvalT<double> e;
+                    {
+                        const double2* jt = reinterpret_cast<const double2*>(JT + (k * 4 + s) * FusedLds::JTS);
+                        double2 q;
+                        q = jt[0]; e.j0[0] = q.x; e.j0[1] = q.y; q = jt[1]; e.j0[2] = q.x; e.j1[0] = q.y; q = jt[2]; e.j1[1] = q.x; e.j1[2] = q.y;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { q = jt[3 + 2 * r]; e.a[r][0] = q.x; e.a[r][1] = q.y; q = jt[4 + 2 * r]; e.a[r][2] = q.x; e.a[r][3] = q.y; }
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { q = jt[9 + r]; e.bu[r][0] = q.x; e.bu[r][1] = q.y; }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        sens_rhs<double>(e, S[cc], g == 2 ? cc : -1, kS[cc]);
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) accS[cc][i] += ws * kS[cc][i];
+                    }
+                }
+                // packed stage record: stored columns c = 0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each
+                const int c0 = g == 0 ? 0 : (g == 1 ? 3 : 5);
+                const int nc = g == 0 ? 3 : 2;
+                WSYNC();                                   // every lane has read its tables: GT does not alias them, but keep the phases apart
+                double* Gk = GT + k * GTS;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    if (live && cc < nc)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const double id = (g < 2 && i == xcol0 + cc) ? 1.0 : 0.0;
+                            Gk[(c0 + cc) * 6 + i] = id + h * accS[cc][i];
+                        }
+            }
+            WSYNC();
+            // park the linearisation in the wave's slot buffer (read back in front of phase E); the stores retire under phase C
+            stage_in<N * GTS>(slot, GT, lane);
+            stage_in<N * NX>(slot + N * GTS, bl, lane);
+        }
+#endif
+
+        // =================================================================================================================
+        // phase C (H2-H4): condensing, lane i <-> input i = 2k + j (text of admpc_condense_kernel).  Leaves the packed
+        // Hessian rows in Hp and, in registers, g0 (reduced gradient at du = 0) and xhat6 of the lane's stage.
+        // =================================================================================================================
+        F20_STAMP(2);
+        double g0, xh6_own = 0.0;
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ki = lane >> 1, ji = lane & 1;
+            const bool uact = lane < n;
+            const int sc = uact ? lane : 0;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            stage_dq<N>(dqC, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
+            const double ubar_i = ubg[sc];
+            const double r_i = Rj * (ubar_i - yrg[(sc >> 1) * 9 + 7 + (sc & 1)]);
+            double Qd[NX], Qe[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cf->W[i]; Qe[i] = cf->We[i]; }
+            double xh[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) xh[c] = x0g[(size_t)inst * NX + c] - xbg[c];      // uniform
+            WSYNC();
+            double g[NX], hrow[n];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) g[c] = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) hrow[i] = 0.0;
+            g0 = r_i;
+            static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int lim = 2 * k < n ? 2 * k : n;        // inputs of stages < k (even)
+                constexpr int nblk = (lim + 15) / 16;             // 16-lane blocks of Gamma that are non-zero at this stage
+                // One stage = one basic block (an always-true test the compiler cannot see through): merged into one 21-stage block,
+                // hipcc hoists every LDS load of the whole instance and spills ~1600 registers.
+                int tok = B; asm volatile("" : "+s"(tok));
+                if (tok > 0) {
+                double wg[NX], Rb[NX][3];
+                if constexpr (k >= 1) {
+                    if (lane == k) xh6_own = xh[6];
+                    static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr ((QMASK >> c) & 1) {
+                            const double w = k < N ? Qd[c] : Qe[c];
+                            wg[c] = w * g[c];
+                            g0 += wg[c] * (xh[c] + dqC[k * 7 + c]);
+                            gam[c * 64 + lane] = g[c];
+                        }
+                    });
+                    static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr ((QMASK >> c) & 1) {
+#pragma unroll
+                            for (int m = 0; m < nblk; ++m) Rb[c][m] = gam[c * 64 + 16 * m + (lane & 15)];
+                        }
+                    });
+                }
+                double xn[NX], gn[NX];
+                if constexpr (k < N) {
+                    const double* Gk = GT + k * GTS;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) { xn[r] = bl[k * 7 + r] + (r < 2 ? xh[r] : 0.0); gn[r] = r < 2 ? g[r] : 0.0; }
+                    xn[6] = bl[k * 7 + 6] + xh[6]; gn[6] = g[6];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+#pragma unroll
+                        for (int r = 0; r < 6; r += 2) {
+                            const double2 a = *reinterpret_cast<const double2*>(Gk + c * 6 + r);
+                            xn[r] += a.x * xh[c + 2]; xn[r + 1] += a.y * xh[c + 2];
+                            gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
+                        }
+                    }
+                    const bool mine = ki == k;
+                    double bb[12];
+#pragma unroll
+                    for (int r = 0; r < 12; r += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(Gk + 5 * 6 + r);
+                        bb[r] = v.x; bb[r + 1] = v.y;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) asm volatile("" : "+v"(bb[r]));
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) gn[r] = mine ? (ji ? bb[6 + r] : bb[r]) : gn[r];
+                    gn[6] = mine ? (ji ? h : 0.0) : gn[6];
+                }
+                if constexpr (k >= 1) {
+                    static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr ((QMASK >> c) & 1) {
+                            static_for<0, lim / 4>([&](auto q) __attribute__((always_inline)) {
+                                constexpr int i2 = 4 * decltype(q)::value;
+                                fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[c][i2 / 16], wg[c]);
+                            });
+                            if constexpr (lim % 4 == 2) {
+                                fmac_rowbc_ld<(lim - 2) % 16>(hrow[lim - 2], Rb[c][(lim - 2) / 16], wg[c]);
+                                fmac_rowbc_ld<(lim - 1) % 16>(hrow[lim - 1], Rb[c][(lim - 1) / 16], wg[c]);
+                            }
+                        }
+                    });
+                }
+                if constexpr (k < N) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; }
+                }
+                }
+            });
+            store_row_40(hrow, lds_byte_addr(Hp + (uact ? (lane * (lane + 1)) / 2 : 0)));
+            // diagonal slots of the packed factor: 0.0 (the factorisation stores the strictly-lower part only; the substitution
+            // assembly lets the source lane of a step take part with this multiplier).  Phase C used L's space: rewrite them.
+            WSYNC();
+            if (uact) Lp[(lane * (lane + 1)) / 2 + lane] = 0.0;
+            WSYNC();
+        }
+
+        // =================================================================================================================
+        // phase D (H5): unconstrained trial + interior point on the condensed QP (text of admpc_qp_dense_kernel)
+        // =================================================================================================================
+        F20_STAMP(3);
+        double du = 0.0;
+        bool failed = false;
+        int it = 0;
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ki = lane >> 1, ji = lane & 1;
+            const bool uact = lane < n;
+            const bool dact = lane >= 1 && lane < N;
+            const int sc = uact ? lane : 0;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            const double rho_l = Ts * cf->zl, rho_u = Ts * cf->zu;
+            const double thr = cf->ipm_thr0, mu0 = cf->ipm_mu0;
+            const double tol_comp = cf->ipm_tol_comp, tol_res = cf->ipm_tol_res, tol_step = cf->ipm_tol_step;
+            const int itmax = cf->ipm_iter_max;
+            const bool try_unc = cf->ipm_try_unconstrained != 0.0;
+            const double thw = cf->ipm_warm_thr, wrest = cf->ipm_warm_restart;
+            const int fbit = (int)cf->ipm_fallback_iter;
+            const double inv_nineq = 1.0 / (double)(8 * N + 2 * (N - 1));
+            const double ubar_i = ubg[sc];
+            const double dl_i = cf->lbu[ji] - ubar_i, duu_i = cf->ubu[ji] - ubar_i;
+            double t[4], lam[4], sl = thr, su = thr;
+            {
+                const double r0[4] = { thr - dl_i, thr + duu_i, thr, thr };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
+            }
+            double Dt[2] = {1.0, 1.0}, Dlam[2] = {0.0, 0.0}, Ddl = 0.0, Ddu = 0.0, dx6 = 0.0;
+            if (dact) {
+                const double x6 = xbg[lane * 7 + 6];
+                Ddl = cf->lbx_delta - x6; Ddu = cf->ubx_delta - x6;
+                dx6 = xh6_own;
+                const double r0[2] = { dx6 - Ddl, Ddu - dx6 };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
+            }
+            PK_DL = dl_i; PK_DUU = duu_i; PK_G0 = g0; PK_DDL = Ddl; PK_DDU = Ddu;      // parked in LDS: registers are the scarce resource
+            WSYNC();
+
+            double rmax_prev = 0.0, step = 1e300, stp_local = 1e300, alpha_prev = 1.0;
+            bool solved = false, warmed = false, cons = false;
+            if (try_unc) {
+                int lt = lane; asm volatile("" : "+v"(lt));
+                factorise(uact ? Rj : 1.0, 0.0, lt);
+                const double xt = ldl_solve(uact ? -g0 : 0.0, lt);
+                const double duc = uact ? xt : 0.0;
+                cb[lane] = duc;
+                WSYNC();
+                const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
+                const double pre = wave_scan_incl<OpSum>(du1_stage);
+                const double dx6c = xh6_own + h * (pre - du1_stage);
+                const bool ok = (!uact || (duc >= dl_i && duc <= duu_i)) && (!dact || (dx6c >= Ddl && dx6c <= Ddu));
+                WSYNC();
+                if (__all(ok)) { du = duc; solved = true; }
+                else if (thw > 0.0) {
+                    warmed = true;
+                    du = duc;
+                    sl = fmax(dl_i - duc, 0.0) + thw; su = fmax(duc - duu_i, 0.0) + thw;
+                    const double r0[4] = { duc + sl - dl_i, su + duu_i - duc, sl, su };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thw ? r0[i] : thw; lam[i] = mu0 * rcp_nr(t[i]); }
+                    if (dact) {
+                        dx6 = dx6c;
+                        const double q0[2] = { dx6 - Ddl, Ddu - dx6 };
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { Dt[i] = q0[i] > thw ? q0[i] : thw; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
+                    }
+                }
+            }
+            auto cold_start = [&]() __attribute__((always_inline)) {
+                const double dlc = PK_DL, duc2 = PK_DUU;
+                du = 0.0; sl = thr; su = thr;
+                const double r0[4] = { thr - dlc, thr + duc2, thr, thr };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
+                dx6 = dact ? xh6_own : 0.0;
+                const double q0[2] = { dx6 - PK_DDL, PK_DDU - dx6 };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { Dt[i] = dact ? (q0[i] > thr ? q0[i] : thr) : 1.0; Dlam[i] = dact ? mu0 * rcp_nr(Dt[i]) : 0.0; }
+                alpha_prev = 1.0; stp_local = 1e300;
+            };
+        F20_STAMP(4);
+            if (!solved)
+            for (; it < itmax + (cons ? fbit : 0); ++it) {
+                int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
+                asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops
+                const int trz = lz * (lz + 1) / 2;
+                const bool uz = lz < n;
+                double ru, mu, Dbar, S_i;
+                {
+                    double musum = 0.0, cmax = 0.0, rmax = 0.0;
+                    double G0, G1, G2, G3;
+                    {
+                        const double i0 = rcp_nr(t[0]), i1 = rcp_nr(t[1]), i2_ = rcp_nr(t[2]), i3 = rcp_nr(t[3]);
+                        G0 = lam[0] * i0; G1 = lam[1] * i1; G2 = lam[2] * i2_; G3 = lam[3] * i3;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const double rci = t[i] * lam[i]; musum += uact ? rci : 0.0; cmax = fmax(cmax, uact ? rci : 0.0); }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { const double rci = Dt[i] * Dlam[i]; musum += dact ? rci : 0.0; cmax = fmax(cmax, dact ? rci : 0.0); }
+                    const double G56 = Dlam[0] * rcp_nr(Dt[0]) + Dlam[1] * rcp_nr(Dt[1]);
+                    Dbar = uact ? Rj + G0 * G2 * rcp_nr(G0 + G2) + G1 * G3 * rcp_nr(G1 + G3) : 1.0;       // idle lanes: identity rows
+                    cb[lane] = uact ? du : 0.0;
+                    const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
+                    sb[lane] = rdlane(dlam_pref, 63) - dlam_pref;           // suffix over stages > lane
+                    const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? G56 : 0.0);
+                    sb2[lane] = rdlane(Ssuf_incl, 63) - Ssuf_incl;          // lane = stage: sum over stages > lane
+                    WSYNC();
+                    double hdu = 0.0;
+                    {
+                        double Rd3[3];
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) Rd3[m] = cb[16 * m + (lane & 15)];
+                        double hv[n];
+                        sym_row_40(hv, lds_byte_addr(Hp + (uz ? trz : 0)), lds_byte_addr(Hp + (uz ? lz : 0)));
+                        static_for<0, n>([&](auto cc) __attribute__((always_inline)) {
+                            constexpr int c = decltype(cc)::value;
+                            fmac_rowbc_ld<c % 16>(hdu, Rd3[c / 16], hv[c]);
+                        });
+                    }
+                    ru = hdu + Rj * du + PK_G0 - lam[0] + lam[1] + (ji ? h * sb[uact ? ki : 0] : 0.0);
+                    S_i = h * h * sb2[uact ? ki : 0];                        // lane = input: S_{k_i}
+                    {
+                        const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+                        const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
+                        const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
+                        double ra = OpMaxNan::f(fabs(ru), fabs(rsl)); ra = OpMaxNan::f(ra, fabs(rsu));
+                        ra = OpMaxNan::f(ra, fabs(rd0)); ra = OpMaxNan::f(ra, fabs(rd1)); ra = OpMaxNan::f(ra, fabs(rd2)); ra = OpMaxNan::f(ra, fabs(rd3));
+                        const double rb = OpMaxNan::f(fabs(Drd0), fabs(Drd1));
+                        rmax = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
+                    }
+                    mu = wave_reduce<OpSum>(musum) * inv_nineq;
+                    cmax = wave_reduce<OpMax>(cmax);
+                    rmax = wave_reduce<OpMaxNan>(rmax);
+                    step = wave_reduce<OpMax>(stp_local);
+                    if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
+                    if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
+                    rmax_prev = rmax;
+                }
+                if (fbit > 0 && !cons && it >= fbit) {
+                    cons = true; warmed = false;
+                    cold_start();
+                    rmax_prev = 0.0;
+                    --it;
+                    continue;
+                }
+                factorise(Dbar, (uz && ji) ? S_i : 0.0, lz);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(t[i]), "+v"(lam[i]));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(Dt[i]), "+v"(Dlam[i]));
+                double it_[4], il_[4], rc[4], Dit[2], Dil[2], Drc[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { it_[i] = rcp_nr(t[i]); il_[i] = rcp_nr(lam[i]); rc[i] = t[i] * lam[i]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { Dit[i] = rcp_nr(Dt[i]); Dil[i] = rcp_nr(Dlam[i]); Drc[i] = Dt[i] * Dlam[i]; }
+                const double G0 = lam[0] * it_[0], G1 = lam[1] * it_[1], G2 = lam[2] * it_[2], G3 = lam[3] * it_[3];
+                const double iG02 = rcp_nr(G0 + G2), iG13 = rcp_nr(G1 + G3);
+                const double G5 = Dlam[0] * Dit[0], G6 = Dlam[1] * Dit[1];
+                const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+                const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
+                const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
+
+                double mu_aff = 0.0, dsl = 0.0, dsu = 0.0, ddu = 0.0, dt[4], dlam[4], Ddt[2], Ddlam[2];
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {
+                    const double c0 = rc[0] * it_[0], c1 = rc[1] * it_[1], c2 = rc[2] * it_[2], c3 = rc[3] * it_[3];
+                    const double e1 = rsl + c0 + c2 + G0 * rd0 + G2 * rd2;
+                    const double e2 = rsu + c1 + c3 + G1 * rd1 + G3 * rd3;
+                    const double etal = c0 + G0 * rd0 - G0 * e1 * iG02;
+                    const double etau = -c1 - G1 * rd1 + G1 * e2 * iG13;
+                    const double ek = dact ? (Drc[0] * Dit[0] + G5 * Drd0) - (Drc[1] * Dit[1] + G6 * Drd1) : 0.0;
+                    const double epref = wave_scan_incl<OpSum>(ek);
+                    sb[lane] = rdlane(epref, 63) - epref;
+                    WSYNC();
+                    double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : 0.0;
+                    const double x = ldl_solve(y, lz);
+                    ddu = uact ? x : 0.0;
+                    cb[lane] = ddu;
+                    WSYNC();
+                    const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
+                    const double pre = wave_scan_incl<OpSum>(du1_stage);
+                    const double ddx6 = h * (pre - du1_stage);
+                    dsl = -(e1 + G0 * ddu) * iG02;
+                    dsu = -(e2 - G1 * ddu) * iG13;
+                    dt[0] = ddu + dsl + rd0; dt[1] = -ddu + dsu + rd1; dt[2] = dsl + rd2; dt[3] = dsu + rd3;
+                    const double Gs[4] = { G0, G1, G2, G3 };
+                    double rr = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dlam[i] = -rc[i] * it_[i] - Gs[i] * dt[i];
+                        rr = fmax(rr, uact ? fmax(-dt[i] * it_[i], -dlam[i] * il_[i]) : 0.0);
+                    }
+                    Ddt[0] = ddx6 + Drd0;  Ddlam[0] = -Drc[0] * Dit[0] - G5 * Ddt[0];
+                    Ddt[1] = -ddx6 + Drd1; Ddlam[1] = -Drc[1] * Dit[1] - G6 * Ddt[1];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) rr = fmax(rr, dact ? fmax(-Ddt[i] * Dit[i], -Ddlam[i] * Dil[i]) : 0.0);
+                    rr = wave_reduce<OpMax>(rr);
+                    const double amax = rr > 1.0 ? rcp_nr(rr) : 1.0;
+                    if (pass == 0) {
+                        double s_aff = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s_aff += uact ? (t[i] + amax * dt[i]) * (lam[i] + amax * dlam[i]) : 0.0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) s_aff += dact ? (Dt[i] + amax * Ddt[i]) * (Dlam[i] + amax * Ddlam[i]) : 0.0;
+                        mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
+                        double sigma = mu_aff * rcp_nr(mu); sigma = sigma * sigma * sigma;
+                        if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;      // centring safeguard (admpc.h)
+                        const double smu = sigma * mu;
+                        if (!cons) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] + Ddt[i] * Ddlam[i] - smu;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] - smu;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] - smu;
+                        }
+                    } else {
+                        double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+                        const double alpha = fmin(tau * amax, 1.0);
+                        if (it == 0 && warmed && alpha < wrest) {
+                            warmed = false;
+                            cold_start();
+                        } else {
+                        alpha_prev = alpha;
+                        stp_local = uact ? fabs(alpha * ddu) : 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { t[i] = fmax(t[i] + alpha * dt[i], IPM_FLOOR); lam[i] = fmax(lam[i] + alpha * dlam[i], IPM_FLOOR); }
+                        du += alpha * ddu; sl += alpha * dsl; su += alpha * dsu;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            Dt[i] = dact ? fmax(Dt[i] + alpha * Ddt[i], IPM_FLOOR) : 1.0;
+                            Dlam[i] = dact ? fmax(Dlam[i] + alpha * Ddlam[i], IPM_FLOOR) : 1.0;
+                        }
+                        dx6 += dact ? alpha * ddx6 : 0.0;
+                        }
+                    }
+                    WSYNC();
+                }
+            }
+        }
+        F20_STAMP(5);
+        { LAUNDER_LANE(lw); if (lw == 0 && itersg) itersg[inst] = it; }
+        if (failed) {
+            // non-finite QP data: acados returns before the update -- the iterate stays as it is, status 4, cost +inf
+            { LAUNDER_LANE(lw); if (lw == 0) { statusg[inst] = ADMPC_STATUS_QP_FAILURE; if (costg) costg[inst] = INFINITY; } }
+            WSYNC();
+            continue;
+        }
+
+        // =================================================================================================================
+        // phase E (H6): expand the states through the linearised dynamics, full step, cost, status (text of admpc_expand_kernel)
+        // =================================================================================================================
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ji = lane & 1;
+            const bool uact = lane < n;
+            const int sc = uact ? lane : 0;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            const double rho_l = Ts * cf->zl, rho_u = Ts * cf->zu;
+            const double sqp_tol = (cf->sqp_iters > 1 && cf->sqp_tol > 0.0) ? cf->sqp_tol : 0.0;
+            const int r6 = lane < 6 ? lane : 0;                     // row of the packed linearisation this lane reads
+            const int r7 = lane < NX ? lane : 0;
+            const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
+            WSYNC();
+            // the slot buffer again: the wave's own stores of phase A have long retired, but the CU's vector L1 may still hold the
+            // lines the PREVIOUS instance of this wave read here (the L1 does not follow the wave's stores): drop them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            stage_in<N * GTS>(GTe, slot, lane);
+            stage_in<N * NX>(ble, slot + N * GTS, lane);
+            stage_dq<N>(dqE, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
+            du = uact ? du : 0.0;
+            dus[lane] = du;
+            const double ubar_i = ubg[sc];
+            const double uref_i = yrg[(sc >> 1) * 9 + 7 + (sc & 1)];
+            double dx = lane < NX ? x0g[(size_t)inst * NX + r7] - xbg[r7] : 0.0;      // dx_0 (lanes 0..6)
+            WSYNC();
+            bool bad = false;
+            double J = 0.0, snorm = 0.0;                       // snorm: max |full step| and |shooting defect| of this SQP step (cfg.sqp_tol)
+            static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const double e = dx + dqE[k * 7 + r7];
+                J += 0.5 * (k < N ? wq : wqe) * e * e;
+                if (!(fabs(dx) <= 1e300)) bad = true;
+                if (lane < NX) { snorm = OpMaxNan::f(snorm, fabs(dx)); if constexpr (k < N) snorm = OpMaxNan::f(snorm, fabs(ble[k * 7 + r7])); }
+                if (lane < NX) dqE[k * 7 + lane] = dx;            // slot k now holds dx_k
+                if constexpr (k < N) {
+                    const double* Gk = GTe + k * GTS;
+                    const double u0 = dus[2 * k], u1 = dus[2 * k + 1];
+                    double acc = ble[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                    double gg[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) gg[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
+                    const double b0 = lane < 6 ? Gk[5 * 6 + r6] : 0.0, b1 = lane < 6 ? Gk[6 * 6 + r6] : (lane == 6 ? h : 0.0);
+                    acc += b0 * u0 + b1 * u1;
+                    fmac_rowbc<2>(acc, dx, gg[0]); fmac_rowbc<3>(acc, dx, gg[1]); fmac_rowbc<4>(acc, dx, gg[2]);
+                    fmac_rowbc<5>(acc, dx, gg[3]); fmac_rowbc<6>(acc, dx, gg[4]);
+                    dx = lane < NX ? acc : 0.0;
+                }
+            });
+            const double unew = ubar_i + du;
+            if (uact && !(fabs(unew) <= 1e300)) bad = true;
+            if (uact) snorm = OpMaxNan::f(snorm, fabs(du));
+            const bool conv = sqp_tol > 0.0 && wave_reduce<OpMaxNan>(snorm) <= sqp_tol;
+            const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : (conv ? -1 : ADMPC_STATUS_SUCCESS);     // -1: converged, see admpc_solve_batch
+            double Ju = 0.0;
+            WSYNC();
+            if (status <= 0) {
+#pragma unroll
+                for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i < (N + 1) * NX) xbg[i] = xbg[i] + dqE[i]; }
+                if (uact) {
+                    const double e = unew - uref_i;
+                    Ju = 0.5 * Rj * e * e;
+                    if (unew < cf->lbu[ji]) Ju += rho_l * (cf->lbu[ji] - unew);
+                    if (unew > cf->ubu[ji]) Ju += rho_u * (unew - cf->ubu[ji]);
+                    ubg[lane] = unew;
+                }
+            }
+            const double Jt = wave_reduce<OpSum>(J + Ju);
+            if (lane == 0) {
+                if (costg) costg[inst] = status <= 0 ? Jt : INFINITY;
+                statusg[inst] = status;
+            }
+            WSYNC();
+            F20_STAMP(6);
+        }
+    }
+    F20_FLUSH();
+    // ---- every wave has drawn exactly one ticket beyond the batch; the last one to leave clears tickets and bins for the next launch
+    {
+        LAUNDER_LANE(lane0);
+        int gone = 0;
+        if (lane0 == 0) gone = atomicAdd(sched + 1, 1);
+        gone = __builtin_amdgcn_readfirstlane(gone);
+        if (gone == (int)gridDim.x - 1) { sched[lane0] = 0; sched[64 + lane0] = 0; __threadfence(); }
+    }
+#undef PK_DL
+#undef PK_DUU
+#undef PK_G0
+#undef PK_DDL
+#undef PK_DDU
+}
+
+}  // namespace
+
+// ---- host side (called by admpc_solve_batch_ex in admpc_kernels.hip)
+extern "C" {
+
+__attribute__((visibility("hidden"))) int admpc_fused20_lds_bytes(void) { return FusedLds::total * (int)sizeof(double); }
+__attribute__((visibility("hidden"))) size_t admpc_fused20_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * FusedLds::SLOT; }
+
+// debug builds only: read and clear the phase counters (all zero in the shipped build)
+int admpc_debug_f20_ticks(unsigned long long* out16)
+{
+#ifdef ADMPC_PHASE_TIMERS
+    unsigned long long z[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_f20_ticks), sizeof z) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_f20_ticks), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+#else
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    return 1;
+#endif
+}
+
+__attribute__((visibility("hidden"))) void admpc_fused20_prepare(void)
+{
+    // 25.6 KB per workgroup: below the 64 KB default, no opt-in needed; kept for symmetry with the other units
+}
+
+// sched ints of a handle that solves up to `cap` instances per call (zeroed once at allocation; the kernel re-arms the header)
+__attribute__((visibility("hidden"))) size_t admpc_fused20_sched_ints(int cap) { return (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap; }
+
+// grid: persistent, eight one-wave workgroups per CU (two waves per SIMD); slotbuf: admpc_fused20_slot_doubles(num_cu) doubles
+__attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
+        const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* slotbuf)
+{
+    const int lds = FusedLds::total * (int)sizeof(double);
+    int grid = num_cu * 8; if (grid > B) grid = B;
+    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref_e, sched, cap);
+    if (qmask == 7)
+        hipLaunchKernelGGL((admpc_fused20_kernel<7>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);
+    else
+        hipLaunchKernelGGL((admpc_fused20_kernel<127>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);
+}
+
+}

@@ -31,249 +31,7 @@
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------
-// model: f and the non-zero pattern of its Jacobians (ad_3d_optimizer.py:280-310)
-// ---------------------------------------------------------------------------------------------
-template <class T>
-struct ModelEvalT {
-    T f[NX];
-    T j0[3], j1[3];           // rows 0,1 of Jx over (psi, vx, vy)
-    T a[3][4];                // rows 3,4,5 of Jx over (vx, vy, psi_dot, delta)
-    T bu[3][2];               // rows 3,4,5 of Ju
-};
-
-// sin and cos of a moderate argument (|x| < ~1e4: yaw angles, steering angles) in ~35 fp64 instructions: Cody-Waite reduction by
-// pi/2 in two parts and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4] (error < 1 ulp there).  ocml's
-// sincos spends ~100 instructions, most of them on a reduction for huge arguments that cannot occur here; the model is
-// evaluated 4 times per stage and thread, each with two sincos.  Non-finite input gives NaN (as libm).
-__device__ __forceinline__ void sincos_small(const double x, double* sn, double* cs) {
-    const double n = rint(x * 6.36619772367581382433e-01);                 // 2 / pi
-    double y = fma(-n, 1.57079632673412561417e+00, x);                    // pi/2, first 33 bits
-    y = fma(-n, 6.07710050650619224932e-11, y);                           // pi/2 - first part
-    const double z = y * y;
-    double rs = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    rs = fma(z, rs, 2.75573137070700676789e-06); rs = fma(z, rs, -1.98412698298579493134e-04); rs = fma(z, rs, 8.33333333332248946124e-03);
-    const double s0 = fma(y * z, fma(z, rs, -1.66666666666666324348e-01), y);
-    double rc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    rc = fma(z, rc, -2.75573143513906633035e-07); rc = fma(z, rc, 2.48015872894767294178e-05); rc = fma(z, rc, -1.38888888888741095749e-03);
-    rc = fma(z, rc, 4.16666666666666019037e-02);
-    const double hz = 0.5 * z, w = 1.0 - hz;
-    const double c0 = w + (((1.0 - w) - hz) + z * z * rc);
-    const int q = (int)n & 3;
-    const double sq = (q & 1) ? c0 : s0, cq = (q & 1) ? s0 : c0;
-    *sn = (q & 2) ? -sq : sq;
-    *cs = ((q + 1) & 2) ? -cq : cq;
-}
-// fp32: the library routine (1-2 ulp over the whole range)
-__device__ __forceinline__ void sincos_small(const float x, float* sn, float* cs) { sincosf(x, sn, cs); }
-
-// exp(x) for x <= 0 (the squared-exponential kernel): x = k ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (remainder
-// < 4e-18), v_ldexp_f64.  ~20 instructions; underflows to 0 like libm.
-__device__ __forceinline__ double exp_nonpos(const double x) {
-    const double k = rint(x * 1.44269504088896338700e+00);
-    double r = fma(-k, 6.93147180369123816490e-01, x);
-    r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                                      // 1 / 13!
-    p = fma(p, r, 2.08767569878681e-09);  p = fma(p, r, 2.505210838544172e-08); p = fma(p, r, 2.755731922398589e-07);
-    p = fma(p, r, 2.7557319223985893e-06); p = fma(p, r, 2.48015873015873e-05);  p = fma(p, r, 1.984126984126984e-04);
-    p = fma(p, r, 1.3888888888888889e-03); p = fma(p, r, 8.333333333333333e-03); p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01); p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
-    return ldexp(p, (int)fmax(k, -1100.0));
-}
-__device__ __forceinline__ float exp_nonpos(const float x) { return expf(x); }
-
-// Mean and gradient of one squared-exponential GP over 1..3 features (anisotropic length scale, gp.py:81-138).  The three
-// threads of a stage (adjacent lanes 3m, 3m+1, 3m+2: the kernel maps 63 tasks to a wave) integrate the same state, so they evaluate the same GP: each takes every third training
-// point and the partial sums are combined by lane shuffles, in the same order on all three lanes (identical results).
-template <class T>
-__device__ __forceinline__ void gp_eval(const AdmpcGp& g, const T (&z)[ADMPC_GP_MAX_FEAT], T& mu, T (&dmu)[ADMPC_GP_MAX_FEAT]) {
-    T m = 0, d0 = 0, d1 = 0, d2 = 0;
-    const int n = g.n_points, nf = g.n_feat;
-    const int lane = threadIdx.x & 63, sub = lane - 3 * (int)(((unsigned)lane * 21846u) >> 16), base = lane - sub;   // lane % 3 without a narrow urem (see div7)
-    const T sf = (T)g.sigma_f;
-    const T il0 = (T)g.inv_l2[0];
-    if (nf == 1) {                          // wave-uniform: the one-feature regressors of config 3 keep their short loop
-        for (int i = sub; i < n; i += 3) {
-            const T e0 = z[0] - (T)g.Z[0][i];
-            const T ka = sf * exp_nonpos((T)-0.5 * e0 * e0 * il0) * (T)g.alpha[i];
-            m += ka;
-            d0 -= ka * e0 * il0;
-        }
-    } else {
-        const T il1 = (T)g.inv_l2[1], il2 = nf > 2 ? (T)g.inv_l2[2] : (T)0;   // unused feature: weight 0
-        for (int i = sub; i < n; i += 3) {
-            const T e0 = z[0] - (T)g.Z[0][i], e1 = z[1] - (T)g.Z[1][i], e2 = z[2] - (T)g.Z[2][i];
-            const T ka = sf * exp_nonpos((T)-0.5 * (e0 * e0 * il0 + e1 * e1 * il1 + e2 * e2 * il2)) * (T)g.alpha[i];
-            m += ka;
-            d0 -= ka * e0 * il0; d1 -= ka * e1 * il1; d2 -= ka * e2 * il2;
-        }
-    }
-    auto tri = [&](T v) { const T a = __shfl(v, base), b = __shfl(v, base + 1), c = __shfl(v, base + 2); return (a + b) + c; };
-    mu = tri(m) + (T)g.ymean; dmu[0] = tri(d0); dmu[1] = (T)0; dmu[2] = (T)0;
-    if (nf > 1) { dmu[1] = tri(d1); dmu[2] = tri(d2); }
-}
-
-// T = float: the reference's "+ 1e-99" in the slip-angle denominators (ad_3d_optimizer.py:290,296-297) is 0 in fp32, and with
-// v_x = 0 the dynamic branch would be inf * 0 = NaN even when the blend parameter p switches it off.  The fp32 instantiation
-// therefore drops the dynamic branch altogether when p == 0 (the shipped blend speeds: pure kinematic model) and keeps the
-// blended value for 0 < p <= 1 (hard parts).
-template <class T>
-__device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, const T* x, const T* u, T p, ModelEvalT<T>& e)
-{
-    const T psi = x[2], vx = x[3], vy = x[4], r = x[5], dl = x[6];
-    const T m = (T)c->mass, LF = (T)c->L_F, LR = (T)c->L_R, Iz = (T)c->Iz, Cf = (T)c->Cf, Cr = (T)c->Cr;
-    const T L = LR + LF;
-    T sp, cp, sd, cd;
-    sincos_small(psi, &sp, &cp);
-    sincos_small(dl, &sd, &cd);
-    e.f[0] = vx * cp - vy * sp;
-    e.f[1] = vx * sp + vy * cp;
-    e.f[2] = r;
-    e.j0[0] = -vx * sp - vy * cp; e.j0[1] = cp; e.j0[2] = -sp;
-    e.j1[0] = vx * cp - vy * sp;  e.j1[1] = sp; e.j1[2] = cp;
-    const T v = vx + (T)1e-99;
-    T iv = (T)1 / v;
-    if constexpr (sizeof(T) == 4) iv = p == (T)0 ? (T)0 : iv;
-    const T Ffy = 2 * Cf * (dl - (vy + LF * r) * iv);
-    const T Fry = 2 * Cr * (LR * r - vy) * iv;
-    const T im = (T)1 / m, iIz = (T)1 / Iz;
-    const T kk = u[1] * vx + dl * u[0];
-    const T dyn3 = u[0] - im * Ffy * sd + vy * r;
-    const T dyn4 = im * (Fry + Ffy * cd) - vx * r;
-    const T dyn5 = iIz * (LF * Ffy * cd - LR * Fry);
-    const T q = (T)1 - p;
-    e.f[3] = p * dyn3 + q * u[0];
-    e.f[4] = p * dyn4 + q * (kk * LR / L);
-    e.f[5] = p * dyn5 + q * (kk / L);
-    e.f[6] = u[1];
-    const T gF[4] = { 2 * Cf * (vy + LF * r) * iv * iv, -2 * Cf * iv, -2 * Cf * LF * iv, 2 * Cf };
-    const T gR[4] = { -Fry * iv, -2 * Cr * iv, 2 * Cr * LR * iv, (T)0 };
-    T d3[4], d4[4], d5[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        d3[i] = -gF[i] * sd * im;
-        d4[i] = (gR[i] + gF[i] * cd) * im;
-        d5[i] = (LF * gF[i] * cd - LR * gR[i]) * iIz;
-    }
-    d3[1] += r;  d3[2] += vy;  d3[3] += -Ffy * cd * im;
-    d4[0] += -r; d4[2] += -vx; d4[3] += -Ffy * sd * im;
-    d5[3] += -LF * Ffy * sd * iIz;
-    const T k4[4] = { u[1] * LR / L, (T)0, (T)0, u[0] * LR / L };
-    const T k5[4] = { u[1] / L, (T)0, (T)0, u[0] / L };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        e.a[0][i] = p * d3[i];
-        e.a[1][i] = p * d4[i] + q * k4[i];
-        e.a[2][i] = p * d5[i] + q * k5[i];
-    }
-    e.bu[0][0] = (T)1;              e.bu[0][1] = (T)0;
-    e.bu[1][0] = q * dl * LR / L;  e.bu[1][1] = q * vx * LR / L;
-    e.bu[2][0] = q * dl / L;       e.bu[2][1] = q * vx / L;
-    const int ngp = c->n_gp;
-    for (int g = 0; g < ngp; ++g) {          // residual GPs: out in {3,4,5}, feat in {3..8} (validated on the host)
-        const AdmpcGp& gp = c->gp[g];
-        const int out = gp.out - 3, nf = gp.n_feat;
-        // static indexing only: runtime-indexed private arrays would live in scratch memory
-        int fd[ADMPC_GP_MAX_FEAT];
-        T z[ADMPC_GP_MAX_FEAT], dmu[ADMPC_GP_MAX_FEAT], mu;
-#pragma unroll
-        for (int d = 0; d < ADMPC_GP_MAX_FEAT; ++d) {
-            fd[d] = d < nf ? gp.feat[d] - 3 : -1;                // 0..3 -> (vx,vy,r,delta), 4..5 -> (u0,u1); -1: unused
-            z[d] = fd[d] == 0 ? vx : fd[d] == 1 ? vy : fd[d] == 2 ? r : fd[d] == 3 ? dl : fd[d] == 4 ? u[0] : fd[d] == 5 ? u[1] : (T)0;
-        }
-        gp_eval<T>(gp, z, mu, dmu);
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const bool so = out == o;
-            e.f[3 + o] += so ? mu : (T)0;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && fd[0] == cc) ? dmu[0] : (T)0;
-            e.bu[o][0] += (so && fd[0] == 4) ? dmu[0] : (T)0;
-            e.bu[o][1] += (so && fd[0] == 5) ? dmu[0] : (T)0;
-        }
-        if (nf > 1) {                        // wave-uniform: one-feature regressors skip the selects of the other two features
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const bool so = out == o;
-#pragma unroll
-                for (int d = 1; d < ADMPC_GP_MAX_FEAT; ++d) {
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) e.a[o][cc] += (so && fd[d] == cc) ? dmu[d] : (T)0;
-                    e.bu[o][0] += (so && fd[d] == 4) ? dmu[d] : (T)0;
-                    e.bu[o][1] += (so && fd[d] == 5) ? dmu[d] : (T)0;
-                }
-            }
-        }
-    }
-}
-
-// d(column)/dt = Jx * s (+ Ju column for an input column)
-template <class T>
-__device__ __forceinline__ void sens_rhs(const ModelEvalT<T>& e, const T* s, int ucol, T* d)
-{
-    d[0] = e.j0[0] * s[2] + e.j0[1] * s[3] + e.j0[2] * s[4];
-    d[1] = e.j1[0] * s[2] + e.j1[1] * s[3] + e.j1[2] * s[4];
-    d[2] = s[5];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        T a = e.a[r][0] * s[3] + e.a[r][1] * s[4] + e.a[r][2] * s[5] + e.a[r][3] * s[6];
-        a += ucol == 0 ? e.bu[r][0] : (ucol == 1 ? e.bu[r][1] : (T)0);
-        d[3 + r] = a;
-    }
-    d[6] = ucol == 1 ? (T)1 : (T)0;
-}
-
-// One ERK4 step of length h for the state and for the NC sensitivity columns of group g:
-//   g=0: x-columns 2,3,4   g=1: x-columns 5,6   g=2: u-columns 0,1
-// Results: phi[7] (all groups), col[c][7] = column c of the group of A (g<2) or B (g=2).
-template <class T>
-__device__ __forceinline__ void rk4_group(const AdmpcConfig* __restrict__ c, const T* x, const T* u, T p, T h,
-                                          int g, T* phi, T col[3][NX])
-{
-    const int xcol0 = g == 0 ? 2 : 5;
-    T kx[NX], accx[NX];
-    T kS[3][NX], accS[3][NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { kx[i] = (T)0; accx[i] = (T)0; }
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { kS[cc][i] = (T)0; accS[cc][i] = (T)0; }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const T cs = (s == 0) ? (T)0 : (s == 3 ? (T)1 : (T)0.5);
-        const T ws = (s == 0 || s == 3) ? (T)(1.0 / 6.0) : (T)(2.0 / 6.0);
-        T X[NX], S[3][NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) X[i] = x[i] + cs * h * kx[i];
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                T id = (g < 2 && i == xcol0 + cc) ? (T)1 : (T)0;
-                S[cc][i] = id + cs * h * kS[cc][i];
-            }
-        ModelEvalT<T> e;
-        model_eval<T>(c, X, u, p, e);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { kx[i] = e.f[i]; accx[i] += ws * e.f[i]; }
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            sens_rhs<T>(e, S[cc], g == 2 ? cc : -1, kS[cc]);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) accS[cc][i] += ws * kS[cc][i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) phi[i] = x[i] + h * accx[i];
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            T id = (g < 2 && i == xcol0 + cc) ? (T)1 : (T)0;
-            col[cc][i] = id + h * accS[cc][i];
-        }
-}
+#include "model_dev.h"
 
 // ---------------------------------------------------------------------------------------------
 // kernel A: shooting + linearisation, one thread per (instance, stage, column group), T = double or float
@@ -332,11 +90,8 @@ __global__ __launch_bounds__(LIN_BLOCK) void admpc_linearize_kernel(const AdmpcC
 // wave-level primitives
 // ---------------------------------------------------------------------------------------------
 #include "dense40.h"      // rdlane, WSYNC, lds_byte_addr, the 40 x 40 factorisation / substitution helpers, rcp_nr
+#include "cond_common.h"  // div7, lane scans, stage_in / stage_dq, DenseLds
 
-
-// x / 7 for 0 <= x < 13107 as a 32-bit multiply-shift: hipcc 7.2 narrows small non-negative ints to 16 bits and its backend
-// cannot select the 16-bit udivrem by 7 at -Oz ("Cannot select: i16 udivrem"); there is no `/ 7` or `% 7` on the device.
-__device__ __forceinline__ int div7(int x) { return (int)(((unsigned)x * 9363u) >> 16); }
 
 // ---------------------------------------------------------------------------------------------
 // kernel B' : condensed QP, dense Cholesky -- the reference's own QP strategy (FULL_CONDENSING_HPIPM,
@@ -349,37 +104,6 @@ __device__ __forceinline__ int div7(int x) { return (int)(((unsigned)x * 9363u) 
 //   g0  = r + sum_k Gamma_k' Q_k (xhat_k + xbar_k - xref_k)
 //   delta row of stage k:  dx6_k = xhat_k[6] + h * sum_{k'<k} du_{(k',1)}   (structural: delta' = u1)
 // ---------------------------------------------------------------------------------------------
-template <class Op>
-__device__ __forceinline__ double wave_scan_incl(double v) {      // inclusive prefix over lanes 0..lane
-    v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));
-    return v;
-}
-
-// 1/sqrt(d) for well-scaled positive d: hardware estimate + two Newton steps (full double accuracy for the pivots seen here,
-// 1e-3 .. 1e15; ocml's rsqrt adds range scaling that the pivot chain does not need)
-__device__ __forceinline__ double rsqrt_nr(double d) {
-    double r = __builtin_amdgcn_rsq(d);
-    double e = fma(-d * r, r, 1.0);
-    r = fma(0.5 * r, e, r);
-    e = fma(-d * r, r, 1.0);
-    return fma(0.5 * r, e, r);
-}
-
-__device__ __forceinline__ int wave_scan_incl_int(int v) {        // inclusive prefix sum over lanes 0..lane
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
 // next instance for a persistent wave (wave-uniform), -1 when the step is drained.  Instances were binned by predicted
 // interior-point effort; tickets walk the bins from the most expensive down (longest-processing-time-first), so the
 // stragglers start early instead of last.  Lane l looks at bin SCHED_NB-1-l.
@@ -406,36 +130,6 @@ __device__ __forceinline__ int sched_next(int* __restrict__ sched, int cap, bool
     return sched[SCHED_HDR + (size_t)(SCHED_NB - 1 - l) * cap + (t - base)];
 }
 
-// ---- staging of one instance between HBM and LDS.  All loads of a block are issued before the first use, so a wave pays
-//      one memory round trip per block instead of one per 64 elements (the plain copy loop serialises load -> ds_write).
-//      CNT doubles, CNT even, both sides 16-byte aligned; the clamped tail re-copies the last element pair (same value).
-template <int CNT>
-__device__ __forceinline__ void stage_in(double* __restrict__ dst, const double* __restrict__ src, const int lane) {
-    static_assert(CNT % 2 == 0, "stage_in copies double2");
-    constexpr int C2 = CNT / 2, IT = (C2 + WAVE - 1) / WAVE;
-    double2 tmp[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < C2 ? i : C2 - 1; tmp[it] = reinterpret_cast<const double2*>(src)[i]; }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < C2 ? i : C2 - 1; reinterpret_cast<double2*>(dst)[i] = tmp[it]; }
-}
-// dq[k][c] = xbar[k][c] - (k < N ? yref[k][c] : yref_e[c]), k = 0..N: the same, for the tracking-error block
-template <int NN>
-__device__ __forceinline__ void stage_dq(double* __restrict__ dq, const double* __restrict__ xb, const double* __restrict__ yr,
-                                         const double* __restrict__ yre, const int lane) {
-    constexpr int CNT = (NN + 1) * NX, IT = (CNT + WAVE - 1) / WAVE;
-    double xv[IT], yv[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1;
-        const int k = div7(i), c = i - 7 * k;
-        xv[it] = xb[i];
-        yv[it] = k < NN ? yr[k * 9 + c] : yre[c];
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
-}
-
 // ---- optional in-kernel phase timers of the interior-point kernel (build with -DADMPC_PHASE_TIMERS; totals are printed by
 //      admpc_destroy).  s_memtime ticks, summed over all waves: 0 staging, 1 phase A, 2 factorisation, 3 phase C,
 //      4 substitutions, 5 expand/step, 6 final roll-out + outputs, 7 scheduler draw
@@ -452,15 +146,6 @@ __device__ __forceinline__ unsigned long long phase_now() {
 #define PHASE_STAMP(k) do { } while (0)
 #define PHASE_FLUSH() do { } while (0)
 #endif
-
-template <int NT>
-struct DenseLds {
-    static constexpr int N = NT, n = 2 * NT, NTRI = n * (n + 1) / 2;
-    static constexpr int LSZ = NTRI > N * GTS ? NTRI : N * GTS;
-    static constexpr int BLS = (N * 7 + 1) & ~1, DQS = ((N + 1) * 7 + 1) & ~1;     // keep every sub-array 16-byte aligned
-    static constexpr int total = 2 * (NTRI + (NTRI & 1)) + 5 * 64 + 4 * 64;     // interior-point kernel: H, L, parked constants, exchange buffers
-    static constexpr int expand_total = N * GTS + BLS + DQS + 64;                 // expand kernel: linearisation, defects, tracking error, du
-};
 
 // kernel C (N = 20 path): condensing.  One instance per wavefront, lane i <-> input i.  Writes, per instance, the packed
 // lower-triangular Hessian rows H[NTRI] and aux[128] = { g0[64] (reduced gradient at du = 0, per input), xhat6[64] (free
@@ -1497,18 +1182,27 @@ struct AdmpcSolver {
     int num_cu;
     int use_dense;           // condensed dense-Cholesky QP kernel available for this horizon (N == 20) and not disabled
     int dense_lds_bytes;
-    // workspace of the linearisation (kernel A -> kernel B), grown on demand by admpc_reserve
-    int cap;                 // instances
-    double* d_GT;            // [cap][N][42]
-    double* d_bl;            // [cap][N][7]
+    int n20_fused;           // N = 20 fp64 steps run the fused persistent kernel (admpc_fused20.hip); 0: the four-kernel pipeline (ADMPC_N20=split)
+    int* d_tick;             // [128 + 64 cap_fused] tickets, exit counter and work-order bins of the fused kernel (zeroed at allocation; the kernel re-arms them)
+    int cap_fused;
+    double* d_slot;          // per-wave slot buffers of the fused kernel (the linearisation across the interior point), allocated at its first launch
+    // Workspaces, each grown on demand by the path that needs it (admpc_reserve sizes the handle's default path up front):
+    int cap;                 // instances: d_status
     int32_t* d_status;       // [cap] used when the caller passes status == NULL
-    double* d_H;             // [cap][NTRI] condensed Hessians (dense path)
-    double* d_aux;           // [cap][128]
-    int* d_sched;            // [SCHED_HDR + SCHED_NB * cap] work scheduler of the persistent interior-point waves
+    int cap_lin;             // kernel A's output: every path but the fused one
+    double* d_GT;            // [cap_lin][N][42]
+    double* d_bl;            // [cap_lin][N][7]
+    int cap_dense;           // four-kernel N = 20 pipeline
+    double* d_H;             // [cap_dense][NTRI] condensed Hessians
+    double* d_aux;           // [cap_dense][128]
+    int* d_sched;            // [SCHED_HDR (+ SCHED_NB * cap_dense)] ticket counter of kernel R / work scheduler of the four-kernel pipeline
+    int sched_cap;           // instances the scheduler lists of d_sched were sized for (0: header only)
     int qmask;               // 7 when only x, y, psi carry tracking weights (specialised condensing kernel), else 127
-    double* d_ws;            // [cap][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
-    int32_t* d_split;        // [2 cap + 1] keys, order and count of the row kernel's second phase (split batches)
-    double* d_dump;          // [cap][16 + 31 N] LDS regions of the deferred instances between the two phases
+    int cap_row;             // kernel R: every fp32 solve, fp64 for N != 20, every solve that asks for multipliers
+    int row_elem;            // element width (8 / 4) the row workspace was sized for
+    double* d_ws;            // [cap_row][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
+    int32_t* d_split;        // [2 cap_row + 1] keys, order and count of the row kernel's second phase (split batches)
+    double* d_dump;          // [cap_row][16 + 31 N] LDS regions of the deferred instances between the two phases
     int split_mode;          // -1: split batches of more than one round of waves (default), 0: never, 1: always (ADMPC_ROWQP_SPLIT)
     double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
 };
@@ -1538,6 +1232,13 @@ extern "C" void admpc_rowqp_launch_f64(int grid, int lds_bytes, hipStream_t st, 
 extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, const AdmpcConfig* d_cfg, int B, int rows, int inst_stride,
         const float* x0, const float* yref, const float* yref_e, const float* GT, const float* bl,
         float* xbar, float* ubar, float* cost, int32_t* stat, int32_t* iters, float* pi, float* ineq, float* ws, int first, int* ticket, int32_t* split, float* dump);
+
+// fused N = 20 step (admpc_fused20.hip)
+extern "C" void admpc_fused20_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
+        const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* slotbuf);
+extern "C" size_t admpc_fused20_slot_doubles(int num_cu);
+extern "C" size_t admpc_fused20_sched_ints(int cap);
 
 extern "C" {
 
@@ -1603,7 +1304,8 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         int r_, st_, lb_, g_;
         if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     }
-    s->cap = 0; s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr; s->d_dump = nullptr;
+    s->cap = s->cap_lin = s->cap_dense = s->cap_row = 0; s->row_elem = 8; s->sched_cap = 0; s->d_tick = nullptr; s->d_slot = nullptr; s->cap_fused = 0;
+    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr; s->d_dump = nullptr;
     {   // ADMPC_ROWQP_SPLIT=0 / 1: never / always run the row kernel in two phases (A/B tests); default: by batch size
         const char* e = getenv("ADMPC_ROWQP_SPLIT");
         s->split_mode = e && e[0] == '0' ? 0 : (e && e[0] == '1' ? 1 : -1);
@@ -1612,6 +1314,9 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         const char* e = getenv("ADMPC_QP");
         s->use_dense = (cfg->N == 20) && !(e && strcmp(e, "riccati") == 0);
         s->dense_lds_bytes = DenseLds<20>::total * (int)sizeof(double);
+        // ADMPC_N20=split keeps the four-kernel pipeline (linearise, condense, interior point, expand) for A/B runs and tests
+        const char* m = getenv("ADMPC_N20");
+        s->n20_fused = !(m && strcmp(m, "split") == 0);
     }
     hipError_t e = hipMalloc((void**)&s->d_cfg, sizeof(AdmpcConfig));
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -1645,6 +1350,8 @@ void admpc_destroy(AdmpcSolver* s)
     }
 #endif
     (void)hipFree(s->d_cfg);
+    if (s->d_tick) (void)hipFree(s->d_tick);
+    if (s->d_slot) (void)hipFree(s->d_slot);
     if (s->d_sched) (void)hipFree(s->d_sched);
     if (s->d_GT) (void)hipFree(s->d_GT);
     if (s->d_bl) (void)hipFree(s->d_bl);
@@ -1658,40 +1365,90 @@ void admpc_destroy(AdmpcSolver* s)
     delete s;
 }
 
+// ---- workspaces: grown on demand, each by the path that uses it.  Growing synchronises the device (nothing may still be using
+//      the old block) and allocates; admpc_reserve does it up front for the handle's default path.
+#define GROW(ptr, type, count) do { if (ptr) (void)hipFree(ptr); ptr = nullptr; HIPCHK(hipMalloc((void**)&(ptr), (size_t)(count) * sizeof(type))); } while (0)
+static int ensure_status(AdmpcSolver* s, int B)
+{
+    if (B <= s->cap) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    s->cap = 0;
+    GROW(s->d_status, int32_t, B);
+    s->cap = B;
+    return ADMPC_OK;
+}
+static int ensure_sched(AdmpcSolver* s, int lists_for)          // header (ticket counter, bucket counts) + optional scheduler lists
+{
+    if (s->d_sched && lists_for <= s->sched_cap) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    s->sched_cap = 0;
+    GROW(s->d_sched, int, (size_t)SCHED_HDR + (size_t)SCHED_NB * (size_t)lists_for);
+    s->sched_cap = lists_for;
+    return ADMPC_OK;
+}
+static int ensure_lin(AdmpcSolver* s, int B)                    // kernel A's output
+{
+    int rc = ensure_sched(s, s->sched_cap); if (rc) return rc;
+    if (B <= s->cap_lin) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t N = (size_t)s->cfg.N;
+    s->cap_lin = 0;
+    GROW(s->d_GT, double, (size_t)B * N * GTS);
+    GROW(s->d_bl, double, (size_t)B * N * NX);
+    s->cap_lin = B;
+    return ADMPC_OK;
+}
+static int ensure_dense(AdmpcSolver* s, int B)                  // four-kernel N = 20 pipeline
+{
+    int rc = ensure_lin(s, B); if (rc) return rc;
+    if (B <= s->cap_dense) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    s->cap_dense = 0;
+    GROW(s->d_H, double, (size_t)B * DenseLds<20>::NTRI);
+    GROW(s->d_aux, double, (size_t)B * 128);
+    rc = ensure_sched(s, B); if (rc) return rc;
+    s->cap_dense = B;
+    return ADMPC_OK;
+}
+static int ensure_fused(AdmpcSolver* s, int B)                  // fused N = 20 step: one slot buffer per resident wave, the work-order lists
+{
+    if (!s->d_slot) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
+    if (B <= s->cap_fused) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    s->cap_fused = 0;
+    GROW(s->d_tick, int, admpc_fused20_sched_ints(B));
+    HIPCHK(hipMemset(s->d_tick, 0, admpc_fused20_sched_ints(B) * sizeof(int)));
+    HIPCHK(hipDeviceSynchronize());                 // the memset runs on the null stream: the caller's (non-blocking) stream must not overtake it
+    s->cap_fused = B;
+    return ADMPC_OK;
+}
+static int ensure_row(AdmpcSolver* s, int B, int elem)          // kernel R; sized by the element width of the solve
+{
+    int rc = ensure_lin(s, B); if (rc) return rc;
+    if (B <= s->cap_row && elem <= s->row_elem) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t N = (size_t)s->cfg.N;
+    const int nb = B > s->cap_row ? B : s->cap_row;
+    const int ne = (s->cap_row > 0 && s->row_elem > elem) ? s->row_elem : elem;
+    s->cap_row = 0;
+    if (s->d_ws) (void)hipFree(s->d_ws); s->d_ws = nullptr;
+    if (s->d_dump) (void)hipFree(s->d_dump); s->d_dump = nullptr;
+    HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)nb * (N + 1) * 38 * (size_t)ne));          // RQ_RW = 38 values per record
+    HIPCHK(hipMalloc((void**)&s->d_dump, (size_t)nb * (16 + 31 * N) * (size_t)ne));
+    GROW(s->d_split, int32_t, (size_t)2 * nb + 1);
+    s->cap_row = nb; s->row_elem = ne;
+    return ADMPC_OK;
+}
+
 int admpc_reserve(AdmpcSolver* s, int B)
 {
     if (!s || B < 0) return fail(ADMPC_EINVAL, "admpc_reserve: bad argument");
-    if (B <= s->cap) return ADMPC_OK;
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
-    HIPCHK(hipDeviceSynchronize());                  // nothing may still be using the old workspace
-    if (s->d_GT) (void)hipFree(s->d_GT);
-    if (s->d_bl) (void)hipFree(s->d_bl);
-    if (s->d_status) (void)hipFree(s->d_status);
-    if (s->d_H) (void)hipFree(s->d_H);
-    if (s->d_aux) (void)hipFree(s->d_aux);
-    if (s->d_sched) (void)hipFree(s->d_sched);
-    if (s->d_ws) (void)hipFree(s->d_ws);
-    if (s->d_split) (void)hipFree(s->d_split);
-    if (s->d_dump) (void)hipFree(s->d_dump);
-    s->d_ws = nullptr; s->d_split = nullptr; s->d_dump = nullptr;
-    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_sched = nullptr; s->cap = 0;
-    const size_t N = (size_t)s->cfg.N;
-    HIPCHK(hipMalloc((void**)&s->d_GT, (size_t)B * N * GTS * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&s->d_bl, (size_t)B * N * NX * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&s->d_status, (size_t)B * sizeof(int32_t)));
-    if (s->use_dense) {
-        HIPCHK(hipMalloc((void**)&s->d_H, (size_t)B * DenseLds<20>::NTRI * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&s->d_aux, (size_t)B * 128 * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&s->d_sched, ((size_t)SCHED_HDR + (size_t)SCHED_NB * B) * sizeof(int)));
-    } else {
-        HIPCHK(hipMalloc((void**)&s->d_sched, (size_t)SCHED_HDR * sizeof(int)));       // [0]: ticket counter of the row kernel
-    }
-    HIPCHK(hipMalloc((void**)&s->d_ws, (size_t)B * (N + 1) * 38 * sizeof(double)));       // row kernel's workspace, RQ_RW = 38 values per record (every fp32 solve, fp64 for N != 20)
-    HIPCHK(hipMalloc((void**)&s->d_split, ((size_t)2 * B + 1) * sizeof(int32_t)));
-    HIPCHK(hipMalloc((void**)&s->d_dump, (size_t)B * (16 + 31 * N) * sizeof(double)));
-    s->cap = B;
-    return ADMPC_OK;
+    int rc = ensure_status(s, B); if (rc) return rc;
+    if (s->use_dense && s->n20_fused) return ensure_fused(s, B);      // no per-instance workspace
+    if (s->use_dense) return ensure_dense(s, B);
+    return ensure_row(s, B, 8);
 }
 
 // Two phases for the row kernel (admpc_rowqp.hip)?  Only with the unconstrained trial on; by default when the batch is more than one
@@ -1734,8 +1491,13 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
     if (!x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
-    if (B > s->cap) { int rc = admpc_reserve(s, B); if (rc) return rc; }   // allocates: call admpc_reserve up front to keep this call allocation-free
     const int N = s->cfg.N;
+    const bool dense = s->use_dense && !snap, fused = dense && s->n20_fused;
+    {   // workspaces of the path this call takes (no-ops once sized: admpc_reserve up front keeps the default path allocation-free)
+        int rc = ensure_status(s, B); if (rc) return rc;
+        if (fused) { rc = ensure_fused(s, B); if (rc) return rc; }
+        else { rc = dense ? ensure_dense(s, B) : ensure_row(s, B, 8); if (rc) return rc; }
+    }
     hipStream_t st = (hipStream_t)stream;
     int32_t* stat = status ? status : s->d_status;
     const long totalA = (long)B * N * 3;
@@ -1744,24 +1506,29 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     for (int sq = 0; sq < nsqp; ++sq) {
         const int first = sq == 0 ? 1 : 0;
+        if (fused) {
+            // shooting, condensing, interior point and expansion of an instance in one persistent kernel: no workspace, no kernel boundary
+            admpc_fused20_launch(s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, s->d_tick, s->cap_fused, s->d_slot);
+            continue;
+        }
         hipLaunchKernelGGL(admpc_linearize_kernel<double>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->d_sched);
-        if (s->use_dense && !snap) {
+        if (dense) {
             constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + NX * 64) * (int)sizeof(double);
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
             if (s->qmask == 7)
                 hipLaunchKernelGGL((admpc_condense_kernel<20, 7>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                    (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
-                                   (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
+                                   (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->sched_cap);
             else
                 hipLaunchKernelGGL((admpc_condense_kernel<20, 127>), dim3(gridC), dim3(WAVE), cond_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                    (const double*)s->d_GT, (const double*)s->d_bl, (const double*)xbar, (const double*)ubar,
-                                   (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->cap);
+                                   (const int32_t*)stat, first, s->d_H, s->d_aux, s->d_sched, s->sched_cap);
             int gridD = s->num_cu * ((160 * 1024) / s->dense_lds_bytes < 8 ? (160 * 1024) / s->dense_lds_bytes : 8);   // two waves per SIMD
             if (gridD > B) gridD = B;
             hipLaunchKernelGGL((admpc_qp_dense_kernel<20>), dim3(gridD), dim3(WAVE), s->dense_lds_bytes, st, s->d_cfg, B,
                                (const double*)xbar, (const double*)ubar, cost, stat, iters,
-                               (const double*)s->d_H, s->d_aux, s->d_sched, s->cap);
+                               (const double*)s->d_H, s->d_aux, s->d_sched, s->sched_cap);
             constexpr int exp_lds = DenseLds<20>::expand_total * (int)sizeof(double);
             int gridE = s->num_cu * 16; if (gridE > B) gridE = B;
             hipLaunchKernelGGL((admpc_expand_kernel<20>), dim3(gridE), dim3(WAVE), exp_lds, st, s->d_cfg, B, x0, yref, yref_e,
@@ -1791,7 +1558,7 @@ int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* y
     if (!x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
-    if (B > s->cap) { int rc = admpc_reserve(s, B); if (rc) return rc; }
+    { int rc = ensure_status(s, B); if (rc) return rc; rc = ensure_row(s, B, 4); if (rc) return rc; }
     const int N = s->cfg.N;
     if (!rowqp_fits(B, N, 4)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
     hipStream_t st = (hipStream_t)stream;
