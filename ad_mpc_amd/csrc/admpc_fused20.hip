@@ -26,12 +26,29 @@
 #define WAVE 64
 #define IPM_FLOOR 1e-40
 #define GTS 42           // values per stage of the packed linearisation (see kernel A in admpc_kernels.hip)
+#ifndef F20_PARK
+#define F20_PARK 0
+#endif
+#ifndef F20_NT
+#define F20_NT 0
+#endif
 
 namespace {
 
 // ---- optional per-phase wave-time accounting (build with -DADMPC_PHASE_TIMERS: `make timers`): s_memtime ticks (100 MHz) summed
 //      over all waves: 0 ticket draw, 1 A1 (state RK4 + model), 2 A2 (sensitivity columns), 3 C (condensing), 4 D trial,
 //      5 D interior-point iterations, 6 E (expansion + outputs); [8] wave-time from kernel start to the wave's exit
+#if defined(ADMPC_PHASE_TIMERS) || defined(ADMPC_F20_TRACE)
+__device__ unsigned long long g_f20_trace[4 * 8192];      // per instance (first 8192): start, end (s_memrealtime, 100 MHz), block, IPM start
+__device__ __forceinline__ unsigned long long f20_real() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
+#define F20_TRACE_BEGIN() const unsigned long long tr_t0 = f20_real(); unsigned long long tr_t1 = 0
+#define F20_TRACE_MID() tr_t1 = f20_real()
+#define F20_TRACE_END(inst) do { if (threadIdx.x == 0 && (inst) < 8192) { g_f20_trace[4 * (inst)] = tr_t0; g_f20_trace[4 * (inst) + 1] = f20_real(); g_f20_trace[4 * (inst) + 2] = blockIdx.x; g_f20_trace[4 * (inst) + 3] = tr_t1; } } while (0)
+#else
+#define F20_TRACE_BEGIN() do { } while (0)
+#define F20_TRACE_MID() do { } while (0)
+#define F20_TRACE_END(inst) do { } while (0)
+#endif
 #ifdef ADMPC_PHASE_TIMERS
 __device__ unsigned long long g_f20_ticks[16];
 __device__ __forceinline__ unsigned long long f20_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
@@ -48,6 +65,32 @@ __device__ __forceinline__ unsigned long long f20_now() { unsigned long long t; 
 #include "dense40.h"
 #include "cond_common.h"
 
+// Inputs and outputs of an instance are touched once (xbar three times, minutes of L2 time apart): marked non-temporal so that
+// they do not push the waves' slot buffers (F20_PARK) out of the L2
+#if F20_NT
+#define LDG(p) __builtin_nontemporal_load(p)
+#define STG(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define LDG(p) (*(p))
+#define STG(p, v) (*(p) = (v))
+#endif
+// stage_dq of cond_common.h with the loads above
+template <int NN>
+__device__ __forceinline__ void stage_dq_nt(double* __restrict__ dq, const double* __restrict__ xb, const double* __restrict__ yr,
+                                            const double* __restrict__ yre, const int lane) {
+    constexpr int CNT = (NN + 1) * NX, IT = (CNT + WAVE - 1) / WAVE;
+    double xv[IT], yv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1;
+        const int k = div7(i), c = i - 7 * k;
+        xv[it] = LDG(xb + i);
+        yv[it] = k < NN ? LDG(yr + k * 9 + c) : LDG(yre + c);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
+}
+
 // LDS map of one instance (doubles): what the interior point needs and nothing else -- 17.7 KB, eight instances per CU (two waves per
 // SIMD).  The exchange buffers keep the relative layout dense40.h's col_head assumes (sb = cb + 128).  The other phases alias it:
 //   A   JT [0, 1920) Jacobian tables of the RK stages, bl [1920, 2060) defects; then GT [0, 840) (written when the tables are dead)
@@ -62,7 +105,7 @@ struct FusedLds {
     static constexpr int total = oCb + 4 * 64;                          // 2216 doubles = 17 728 B
     static constexpr int JTS = 24;                                      // Jacobian entries per (stage, RK stage)
     static constexpr int oJT = 0, oBlA = N * 4 * JTS, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
-    static constexpr int oGTE = NTRI, oBlE = oGTE + N * GTS, oDqE = 0, oDuE = 148;
+    [[maybe_unused]] static constexpr int oGTE = NTRI, oBlE = oGTE + N * GTS, oDqE = 0, oDuE = 148;        // F20_PARK = 1 only
     static constexpr int SLOT = N * GTS + N * NX;                       // doubles per wave in the slot buffer
     static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + NX * 64 <= oPark && oBlE + N * NX <= total, "LDS aliases");
 };
@@ -75,27 +118,43 @@ struct FusedLds {
 // is in the first round with it, and 1837 of the 1841 that need the interior point at all (correlation with the iteration count
 // 0.80).  A heuristic: it orders work and nothing else -- results do not depend on the draw order.
 //   sched: [0] ticket counter, [1] exit counter, [F20_BINS0 + q] instances in bin q, [F20_HDR + q * cap + j] j-th instance of bin q
+// wave priority by interior-point iteration (measured: 0/2/4 -> 0.250 ms per step, 1/3/6 0.254, 3/6 only 0.255, none 0.269)
+#ifndef F20_PRIO_IT1
+#define F20_PRIO_IT0 0
+#define F20_PRIO_IT1 2
+#define F20_PRIO_IT2 4
+#endif
 #define F20_NB 64
 #define F20_BINS0 64
 #define F20_HDR 128
 __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig* __restrict__ cfg, int B, const double* __restrict__ x0g,
                                                                const double* __restrict__ yrefeg, int* __restrict__ sched, int cap)
 {
+    // Bin counts are aggregated per block in LDS and reach the global counters as ONE atomic per (block, bin): 2000 of 4096 config-2
+    // instances share bin 0, and one global atomic each on that word took 22 us -- a tenth of the step.
+    __shared__ int cnt[F20_NB], base[F20_NB];
+    if (threadIdx.x < F20_NB) cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double* x0 = x0g + (size_t)b * NX;
-    const double* ye = yrefeg + (size_t)b * NX;
-    const double T = cfg->Ts * (double)cfg->N;
-    double sn, cs;
-    sincos(x0[2], &sn, &cs);
-    const double along = cs * (ye[0] - x0[0]) + sn * (ye[1] - x0[1]);
-    const double areq = 2.0 * (along - x0[3] * T) / (T * T);
-    const double lb = cfg->lbu[0], ub = cfg->ubu[0];
-    const double ov = fmax(areq - ub, lb - areq) / (ub - lb);          // < 0: that far inside the box
-    int q = 0;
-    if (ov == ov && ov > -0.125) q = 1 + (int)fmin(fmax((ov + 0.125) * 32.0, 0.0), (double)(F20_NB - 2));
-    const int pos = atomicAdd(sched + F20_BINS0 + q, 1);
-    sched[F20_HDR + (size_t)q * cap + pos] = b;
+    int q = -1, rank = 0;
+    if (b < B) {
+        const double* x0 = x0g + (size_t)b * NX;
+        const double* ye = yrefeg + (size_t)b * NX;
+        const double T = cfg->Ts * (double)cfg->N;
+        double sn, cs;
+        sincos(x0[2], &sn, &cs);
+        const double along = cs * (ye[0] - x0[0]) + sn * (ye[1] - x0[1]);
+        const double areq = 2.0 * (along - x0[3] * T) / (T * T);
+        const double lb = cfg->lbu[0], ub = cfg->ubu[0];
+        const double ov = fmax(areq - ub, lb - areq) / (ub - lb);          // < 0: that far inside the box
+        q = 0;
+        if (ov == ov && ov > -0.125) q = 1 + (int)fmin(fmax((ov + 0.125) * 32.0, 0.0), (double)(F20_NB - 2));
+        rank = atomicAdd(&cnt[q], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < F20_NB) base[threadIdx.x] = cnt[threadIdx.x] > 0 ? atomicAdd(sched + F20_BINS0 + threadIdx.x, cnt[threadIdx.x]) : 0;
+    __syncthreads();
+    if (q >= 0) sched[F20_HDR + (size_t)q * cap + base[q] + rank] = b;
 }
 
 // next instance for a persistent wave (wave-uniform), -1 when the batch is drained: tickets walk the bins from the most expensive
@@ -139,11 +198,22 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
     double* const bl = lds_raw + FusedLds::oBlA;        // phases A, C: defects b_k
     double* const dqC = lds_raw + FusedLds::oDqC;       // phase C: xbar_k - xref_k
     double* const gam = lds_raw + FusedLds::oGam;       // phase C: [NX][64] Gamma components of the current stage
+#if F20_PARK
     double* const GTe = lds_raw + FusedLds::oGTE;       // phase E: the linearisation again (from the slot buffer)
     double* const ble = lds_raw + FusedLds::oBlE;
     double* const dqE = lds_raw + FusedLds::oDqE;       // phase E: xbar_k - xref_k, overwritten by dx_k
     double* const dus = lds_raw + FusedLds::oDuE;       // phase E: [64] du per input
+#else
+    double* const GTe = GT;                             // phase E: the linearisation again (phase A, second run: same places)
+    double* const ble = bl;
+    double* const dqE = lds_raw + FusedLds::oDqC;       // phase E: xbar_k - xref_k, overwritten by dx_k
+    double* const dus = lds_raw + FusedLds::oGam;       // phase E: [64] du per input
+#endif
+#if F20_PARK
     double* const slot = slotbuf + (size_t)blockIdx.x * FusedLds::SLOT;
+#else
+    (void)slotbuf;
+#endif
 #define PK_DL   park[0 * 64 + lane]
 #define PK_DUU  park[1 * 64 + lane]
 #define PK_G0   park[2 * 64 + lane]
@@ -227,6 +297,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         const int inst = f20_next(sched, cap, first_ticket, lane0);
         first_ticket = false;
         if (inst < 0) break;
+        F20_TRACE_BEGIN();
         if (!first_pass && statusg[inst] != 0) continue;    // failed / converged in an earlier SQP iteration of this call
         double* const xbg = xbarg + (size_t)inst * (N + 1) * NX;
         double* const ubg = ubarg + (size_t)inst * N * NU;
@@ -236,7 +307,14 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         // phase A (H0/H1): ERK4 + forward sensitivities.  Lane 3k + g <-> (stage k, column group g) as in kernel A:
         // g = 0: x-columns 2,3,4; g = 1: x-columns 5,6; g = 2: u-columns 0,1.  Lanes 60..63 shadow task 59 and store nothing.
         // =================================================================================================================
-#ifndef F20_NO_A
+        double du = 0.0;
+        bool failed = false;
+        int it = 0;
+        // F20_PARK = 0: the linearisation is not kept across the interior point at all -- phase A runs a second time in front of phase E
+        // (pass 1 of this loop, one copy of the code); F20_PARK = 1: it is parked in the wave's slot buffer in global memory instead.
+        int npass = F20_PARK ? 1 : 2; asm volatile("" : "+s"(npass));
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) {
         {
             LAUNDER_LANE(lane); LAUNDER_CFG(cf);
             const double h = cf->Ts;
@@ -250,8 +328,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 const double pin = pg[inst];
                 double x[NX], u[NU], xn1[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { x[i] = xbg[k * NX + i]; xn1[i] = xbg[(k + 1) * NX + i]; }
-                u[0] = ubg[k * NU]; u[1] = ubg[k * NU + 1];
+                for (int i = 0; i < NX; ++i) { x[i] = LDG(xbg + k * NX + i); xn1[i] = LDG(xbg + (k + 1) * NX + i); }
+                u[0] = LDG(ubg + k * NU); u[1] = LDG(ubg + k * NU + 1);
                 double kx[NX], accx[NX];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { kx[i] = 0.0; accx[i] = 0.0; }
@@ -334,11 +412,13 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                         }
             }
             WSYNC();
+#if F20_PARK
             // park the linearisation in the wave's slot buffer (read back in front of phase E); the stores retire under phase C
             stage_in<N * GTS>(slot, GT, lane);
             stage_in<N * NX>(slot + N * GTS, bl, lane);
-        }
 #endif
+        }
+        if (pass != 0) break;
 
         // =================================================================================================================
         // phase C (H2-H4): condensing, lane i <-> input i = 2k + j (text of admpc_condense_kernel).  Leaves the packed
@@ -353,7 +433,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             const int sc = uact ? lane : 0;
             const double Ts = cf->Ts, h = cf->Ts;
             const double Rj = Ts * cf->W[NX + ji];
-            stage_dq<N>(dqC, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
+            stage_dq_nt<N>(dqC, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
             const double ubar_i = ubg[sc];
             const double r_i = Rj * (ubar_i - yrg[(sc >> 1) * 9 + 7 + (sc & 1)]);
             double Qd[NX], Qe[NX];
@@ -458,9 +538,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         // phase D (H5): unconstrained trial + interior point on the condensed QP (text of admpc_qp_dense_kernel)
         // =================================================================================================================
         F20_STAMP(3);
-        double du = 0.0;
-        bool failed = false;
-        int it = 0;
         {
             LAUNDER_LANE(lane); LAUNDER_CFG(cf);
             const int ki = lane >> 1, ji = lane & 1;
@@ -540,8 +617,16 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 alpha_prev = 1.0; stp_local = 1e300;
             };
         F20_STAMP(4);
+            F20_TRACE_MID();
             if (!solved)
             for (; it < itmax + (cons ? fbit : 0); ++it) {
+                // An instance that is still iterating is on its way to becoming the batch's straggler: give its wave the issue slots of the
+                // SIMD it shares (the partner is a fresh instance of the second round, which is not on anybody's critical path)
+#ifndef F20_NO_PRIO
+                if (it == F20_PRIO_IT0) __builtin_amdgcn_s_setprio(1);
+                if (it == F20_PRIO_IT1) __builtin_amdgcn_s_setprio(2);
+                if (it == F20_PRIO_IT2) __builtin_amdgcn_s_setprio(3);
+#endif
                 int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
                 asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops
                 const int trz = lz * (lz + 1) / 2;
@@ -703,11 +788,14 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             }
         }
         F20_STAMP(5);
+        if (failed) break;
+        }   // pass
         { LAUNDER_LANE(lw); if (lw == 0 && itersg) itersg[inst] = it; }
         if (failed) {
             // non-finite QP data: acados returns before the update -- the iterate stays as it is, status 4, cost +inf
             { LAUNDER_LANE(lw); if (lw == 0) { statusg[inst] = ADMPC_STATUS_QP_FAILURE; if (costg) costg[inst] = INFINITY; } }
             WSYNC();
+            __builtin_amdgcn_s_setprio(0);
             continue;
         }
 
@@ -727,13 +815,15 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             const int r7 = lane < NX ? lane : 0;
             const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
             WSYNC();
+#if F20_PARK
             // the slot buffer again: the wave's own stores of phase A have long retired, but the CU's vector L1 may still hold the
             // lines the PREVIOUS instance of this wave read here (the L1 does not follow the wave's stores): drop them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             stage_in<N * GTS>(GTe, slot, lane);
             stage_in<N * NX>(ble, slot + N * GTS, lane);
-            stage_dq<N>(dqE, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
+#endif
+            stage_dq_nt<N>(dqE, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
             du = uact ? du : 0.0;
             dus[lane] = du;
             const double ubar_i = ubg[sc];
@@ -772,13 +862,13 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             WSYNC();
             if (status <= 0) {
 #pragma unroll
-                for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i < (N + 1) * NX) xbg[i] = xbg[i] + dqE[i]; }
+                for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i < (N + 1) * NX) STG(xbg + i, LDG(xbg + i) + dqE[i]); }
                 if (uact) {
                     const double e = unew - uref_i;
                     Ju = 0.5 * Rj * e * e;
                     if (unew < cf->lbu[ji]) Ju += rho_l * (cf->lbu[ji] - unew);
                     if (unew > cf->ubu[ji]) Ju += rho_u * (unew - cf->ubu[ji]);
-                    ubg[lane] = unew;
+                    STG(ubg + lane, unew);
                 }
             }
             const double Jt = wave_reduce<OpSum>(J + Ju);
@@ -788,7 +878,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             }
             WSYNC();
             F20_STAMP(6);
+            F20_TRACE_END(inst);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     F20_FLUSH();
     // ---- every wave has drawn exactly one ticket beyond the batch; the last one to leave clears tickets and bins for the next launch
@@ -812,7 +904,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
 extern "C" {
 
 __attribute__((visibility("hidden"))) int admpc_fused20_lds_bytes(void) { return FusedLds::total * (int)sizeof(double); }
-__attribute__((visibility("hidden"))) size_t admpc_fused20_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * FusedLds::SLOT; }
+// doubles of the per-wave slot buffers (0: this build recomputes the linearisation in front of phase E instead of parking it)
+__attribute__((visibility("hidden"))) size_t admpc_fused20_slot_doubles(int num_cu) { return F20_PARK ? (size_t)num_cu * 8 * FusedLds::SLOT : (size_t)0; }
 
 // debug builds only: read and clear the phase counters (all zero in the shipped build)
 int admpc_debug_f20_ticks(unsigned long long* out16)
@@ -825,6 +918,19 @@ int admpc_debug_f20_ticks(unsigned long long* out16)
     return 0;
 #else
     for (int i = 0; i < 16; ++i) out16[i] = 0;
+    return 1;
+#endif
+}
+
+int admpc_debug_f20_trace(unsigned long long* out, int n_inst)
+{
+#if defined(ADMPC_PHASE_TIMERS) || defined(ADMPC_F20_TRACE)
+    if (n_inst > 8192) n_inst = 8192;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f20_trace), (size_t)n_inst * 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return 0;
+#else
+    (void)out; (void)n_inst;
     return 1;
 #endif
 }

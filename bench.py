@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (admpc_solve_batch: shooting + QP + full step for every
-instance; at N = 20 fp64 four kernel launches, otherwise two) over one batch of synthetic scenarios that is already resident
+instance; at N = 20 fp64 one fused persistent kernel behind a work-order pre-pass, otherwise two launches) over one batch of synthetic scenarios that is already resident
 in HBM.  Every step starts from the same initial iterate (pre-staged copies), so all steps do identical work.
 Workloads (BASELINE.json):
   --gpus 1 (default)                                   configs[1]: batch 4096 random (x0, curved reference) scenarios, N = 20, fp64
@@ -345,6 +345,7 @@ def main():
         else:
             wl = "BASELINE configs[1]: batch %d random (x0, curved ref) scenarios, N=%d, %s" % (B, N, args.dtype)
         dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
+        fused = dense and os.environ.get("ADMPC_N20") != "split"
         out = {
             "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
@@ -355,7 +356,8 @@ def main():
             "roofline": {"bound": "fp32-valu" if f32 else "fp64-valu", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": ach_tf / peak_tf, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
-                         "kernel": ("one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
+                         "kernel": ("one step = admpc_f20_order_kernel (work-order pre-pass, ~3 us) + admpc_fused20_kernel (dominant, > 97 %: shooting, condensing, dense interior point and expansion of an instance in one persistent wave)"
+                                    if fused else "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
                                     if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than one round of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
                          "kernel_ms": kern_ms,
                          "note": "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt); roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)" % ("fp32" if f32 else "fp64", peak_tf)},
