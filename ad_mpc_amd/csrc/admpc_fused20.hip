@@ -26,9 +26,6 @@
 #define WAVE 64
 #define IPM_FLOOR 1e-40
 #define GTS 42           // values per stage of the packed linearisation (see kernel A in admpc_kernels.hip)
-#ifndef F20_PARK
-#define F20_PARK 0
-#endif
 #ifndef F20_NT
 #define F20_NT 0
 #endif
@@ -66,7 +63,7 @@ __device__ __forceinline__ unsigned long long f20_now() { unsigned long long t; 
 #include "cond_common.h"
 
 // Inputs and outputs of an instance are touched once (xbar three times, minutes of L2 time apart): marked non-temporal so that
-// they do not push the waves' slot buffers (F20_PARK) out of the L2
+// they do not push the waves' slot buffers out of the L2 (measured: no effect on traffic, 0.5 % slower: off)
 #if F20_NT
 #define LDG(p) __builtin_nontemporal_load(p)
 #define STG(p, v) __builtin_nontemporal_store(v, p)
@@ -95,19 +92,17 @@ __device__ __forceinline__ void stage_dq_nt(double* __restrict__ dq, const doubl
 // SIMD).  The exchange buffers keep the relative layout dense40.h's col_head assumes (sb = cb + 128).  The other phases alias it:
 //   A   JT [0, 1920) Jacobian tables of the RK stages, bl [1920, 2060) defects; then GT [0, 840) (written when the tables are dead)
 //   C   reads GT, bl; dq [860, 1008), gam [1008, 1456); leaves H in [0, 820) (row store after the last read of GT)
-//   E   GT [820, 1660), bl [1660, 1800) read back from the wave's slot buffer; dq [0, 148), du [148, 212)
-// The packed linearisation (GT, bl: 7.8 KB) has to survive the interior point for the expansion: it is parked in a slot buffer in
-// global memory that belongs to the WAVE, not to the instance (grid x 980 doubles = 16 MB at most, reused for every instance the wave
-// draws: L2-resident), written behind phase A and read back in front of phase E.
+//   E   GT, bl once more in the places of phase A (second run of phase A, or read back from the slot buffer); dq, du in C's places
+// The packed linearisation (GT, bl: 7.8 KB) is needed again behind the interior point, by the expansion, and LDS cannot keep it at this
+// occupancy: see `park_gt` in the kernel for the two ways across.
 struct FusedLds {
     static constexpr int N = 20, NTRI = 820;
     static constexpr int oH = 0, oL = oH + NTRI, oPark = oL + NTRI, oCb = oPark + 5 * 64;
     static constexpr int total = oCb + 4 * 64;                          // 2216 doubles = 17 728 B
     static constexpr int JTS = 24;                                      // Jacobian entries per (stage, RK stage)
     static constexpr int oJT = 0, oBlA = N * 4 * JTS, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
-    [[maybe_unused]] static constexpr int oGTE = NTRI, oBlE = oGTE + N * GTS, oDqE = 0, oDuE = 148;        // F20_PARK = 1 only
     static constexpr int SLOT = N * GTS + N * NX;                       // doubles per wave in the slot buffer
-    static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + NX * 64 <= oPark && oBlE + N * NX <= total, "LDS aliases");
+    static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + NX * 64 <= oPark, "LDS aliases");
 };
 
 // ---- work order.  A wave owns an instance for 40 us (the trial solves it) up to 200 us (13 interior-point iterations), and a batch
@@ -198,22 +193,18 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
     double* const bl = lds_raw + FusedLds::oBlA;        // phases A, C: defects b_k
     double* const dqC = lds_raw + FusedLds::oDqC;       // phase C: xbar_k - xref_k
     double* const gam = lds_raw + FusedLds::oGam;       // phase C: [NX][64] Gamma components of the current stage
-#if F20_PARK
-    double* const GTe = lds_raw + FusedLds::oGTE;       // phase E: the linearisation again (from the slot buffer)
-    double* const ble = lds_raw + FusedLds::oBlE;
-    double* const dqE = lds_raw + FusedLds::oDqE;       // phase E: xbar_k - xref_k, overwritten by dx_k
-    double* const dus = lds_raw + FusedLds::oDuE;       // phase E: [64] du per input
-#else
-    double* const GTe = GT;                             // phase E: the linearisation again (phase A, second run: same places)
-    double* const ble = bl;
+    double* const GTe = GT;                             // phase E: the linearisation again, in the same places (second run of phase A,
+    double* const ble = bl;                             //          or read back from the wave's slot buffer)
     double* const dqE = lds_raw + FusedLds::oDqC;       // phase E: xbar_k - xref_k, overwritten by dx_k
     double* const dus = lds_raw + FusedLds::oGam;       // phase E: [64] du per input
-#endif
-#if F20_PARK
+    // How the linearisation gets across the interior point (LDS cannot keep it at eight instances per CU):
+    //   slotbuf == NULL  phase A runs a second time in front of phase E: nothing but the instance's inputs and outputs crosses HBM
+    //                    (24 MB per 4096-instance step, 1.3 x the algorithmic bytes; + 2 % time);
+    //   slotbuf != NULL  it is parked in a slot buffer that belongs to the WAVE (grid x 980 doubles, reused for every instance the wave
+    //                    draws, written behind phase A and read back in front of phase E: 71 MB per step).  The host chooses this when
+    //                    GP residuals are configured: their kernel sums make phase A several times as expensive.
+    const bool park_gt = slotbuf != nullptr;
     double* const slot = slotbuf + (size_t)blockIdx.x * FusedLds::SLOT;
-#else
-    (void)slotbuf;
-#endif
 #define PK_DL   park[0 * 64 + lane]
 #define PK_DUU  park[1 * 64 + lane]
 #define PK_G0   park[2 * 64 + lane]
@@ -310,9 +301,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         double du = 0.0;
         bool failed = false;
         int it = 0;
-        // F20_PARK = 0: the linearisation is not kept across the interior point at all -- phase A runs a second time in front of phase E
-        // (pass 1 of this loop, one copy of the code); F20_PARK = 1: it is parked in the wave's slot buffer in global memory instead.
-        int npass = F20_PARK ? 1 : 2; asm volatile("" : "+s"(npass));
+        // without a slot buffer phase A runs a second time in front of phase E: pass 1 of this loop (one copy of the code)
+        int npass = park_gt ? 1 : 2; asm volatile("" : "+s"(npass));
 #pragma unroll 1
         for (int pass = 0; pass < npass; ++pass) {
         {
@@ -412,11 +402,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                         }
             }
             WSYNC();
-#if F20_PARK
-            // park the linearisation in the wave's slot buffer (read back in front of phase E); the stores retire under phase C
-            stage_in<N * GTS>(slot, GT, lane);
-            stage_in<N * NX>(slot + N * GTS, bl, lane);
-#endif
+            if (park_gt) {      // park the linearisation in the wave's slot buffer (read back in front of phase E); the stores retire under phase C
+                stage_in<N * GTS>(slot, GT, lane);
+                stage_in<N * NX>(slot + N * GTS, bl, lane);
+            }
         }
         if (pass != 0) break;
 
@@ -815,14 +804,15 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             const int r7 = lane < NX ? lane : 0;
             const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
             WSYNC();
-#if F20_PARK
-            // the slot buffer again: the wave's own stores of phase A have long retired, but the CU's vector L1 may still hold the
-            // lines the PREVIOUS instance of this wave read here (the L1 does not follow the wave's stores): drop them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            stage_in<N * GTS>(GTe, slot, lane);
-            stage_in<N * NX>(ble, slot + N * GTS, lane);
-#endif
+            if (park_gt) {
+                // the slot buffer again: the wave's own stores of phase A have long retired, but the CU's vector L1 may still hold the
+                // lines the PREVIOUS instance of this wave read here (the L1 does not follow the wave's stores): drop them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                stage_in<N * GTS>(GTe, slot, lane);
+                stage_in<N * NX>(ble, slot + N * GTS, lane);
+                WSYNC();
+            }
             stage_dq_nt<N>(dqE, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
             du = uact ? du : 0.0;
             dus[lane] = du;
@@ -904,8 +894,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
 extern "C" {
 
 __attribute__((visibility("hidden"))) int admpc_fused20_lds_bytes(void) { return FusedLds::total * (int)sizeof(double); }
-// doubles of the per-wave slot buffers (0: this build recomputes the linearisation in front of phase E instead of parking it)
-__attribute__((visibility("hidden"))) size_t admpc_fused20_slot_doubles(int num_cu) { return F20_PARK ? (size_t)num_cu * 8 * FusedLds::SLOT : (size_t)0; }
+// doubles of the per-wave slot buffers (only allocated and passed when the handle's model carries GP residuals)
+__attribute__((visibility("hidden"))) size_t admpc_fused20_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * FusedLds::SLOT; }
 
 // debug builds only: read and clear the phase counters (all zero in the shipped build)
 int admpc_debug_f20_ticks(unsigned long long* out16)

@@ -1412,7 +1412,8 @@ static int ensure_dense(AdmpcSolver* s, int B)                  // four-kernel N
 }
 static int ensure_fused(AdmpcSolver* s, int B)                  // fused N = 20 step: one slot buffer per resident wave, the work-order lists
 {
-    if (!s->d_slot && admpc_fused20_slot_doubles(s->num_cu) > 0) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
+    // slot buffers only where parking the linearisation beats recomputing it: with GP residuals in the model (see admpc_fused20.hip)
+    if (!s->d_slot && s->cfg.n_gp > 0) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
     if (B <= s->cap_fused) return ADMPC_OK;
     HIPCHK(hipDeviceSynchronize());
     s->cap_fused = 0;

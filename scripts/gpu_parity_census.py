@@ -5,17 +5,19 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle
-from ad_mpc_amd.config import default_config
+from ad_mpc_amd.config import default_config, set_gp
 from ad_mpc_amd.engine import BatchSolver
-from ad_mpc_amd.scenarios import random_scenarios
+from ad_mpc_amd.scenarios import random_scenarios, grid_gp
 
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 o = Oracle(omp=True)
 nth = min(64, os.cpu_count() or 8)
 total = 0
-for N, B, dt in ((20, 4096, np.float64), (20, 8192, np.float64), (40, 4096, np.float64), (40, 8192, np.float64), (80, 2048, np.float64),
-                 (80, 8192, np.float64), (128, 1024, np.float64), (80, 16384, np.float32)):
+for N, B, dt, gp in ((20, 4096, np.float64, False), (20, 4096, np.float64, True), (20, 8192, np.float64, False), (40, 4096, np.float64, False), (40, 4096, np.float64, True),
+                     (40, 8192, np.float64, False), (80, 2048, np.float64, False), (80, 8192, np.float64, False), (128, 1024, np.float64, False), (80, 16384, np.float32, False)):
     cfg = default_config(N=N)
+    if gp:
+        set_gp(cfg, grid_gp())              # BASELINE configs[2]: GP residual-dynamics correction active
     eng = BatchSolver(cfg, device=0)
     for kw in ({}, {"blend": (3.0, 5.0)}):
         n = 0; bad_status = 0; it_off = 0; it_off2 = 0; du = 0.0; dx = 0.0; du_off = 0.0; mx = 0; t0 = time.time()
@@ -31,7 +33,7 @@ for N, B, dt in ((20, 4096, np.float64), (20, 8192, np.float64), (40, 4096, np.f
             du_off = max(du_off, float(np.abs(g[1][off] - r[1][off]).max(initial=0)))
             mx = max(mx, int(g[4].max()))
         total += n
-        fam = "dynamic " if kw else "kinematic"
+        fam = ("dynamic " if kw else "kinematic") + (" + GP residual" if gp else "")
         if dt == np.float64:
             print(f"N {N:3d} B {B:5d} f64 {fam}: {n:6d} instances, status mismatches {bad_status}, iteration counts differing {it_off} (by more than one: {it_off2}; "
                   f"their max |du| {du_off:.1e}), max |du| {du:.2e}, max |dx| {dx:.2e}, max iterations {mx}  [{time.time() - t0:.0f} s]", flush=True)

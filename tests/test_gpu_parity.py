@@ -467,6 +467,20 @@ def test_gp_residual_config3(gpu_engine_factory, oracle):
     assert np.abs(base[1] - o[1]).max() > 1e-3       # the GP really changes the answer
 
 
+def test_gp_residual_config3_full_size(gpu_engine_factory, oracle_omp):
+    """BASELINE configs[2] at its full size: batch 4096 with the GP residual-dynamics correction active (grid_gp: three 1-D
+    regressors on v_x, v_y, psi_dot), every instance against the oracle on OpenMP threads -- identical status and interior-point
+    iteration counts, solutions within 1e-8 -- for the shipped blend speeds (kinematic branch) and for the 3 / 5 m/s blend that
+    switches the dynamic bicycle branch on."""
+    cfg = default_config(N=20); set_gp(cfg, grid_gp())
+    eng = gpu_engine_factory(cfg)
+    for kw in ({}, {"blend": (3.0, 5.0)}):
+        s = random_scenarios(4096, N=20, seed=1234, **kw)
+        g, o = _solve_both(eng, oracle_omp, cfg, s, nthreads=16)
+        assert (o[3] == 0).all()
+        _assert_parity(g, o)
+
+
 def _multi_feature_gps(seed=8):
     """Three regressors with 3, 2 and 1 features (states and inputs mixed, one length scale per feature)."""
     rng = np.random.default_rng(seed)
