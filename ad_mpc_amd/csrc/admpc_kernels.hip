@@ -585,7 +585,8 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                 rmax = wave_reduce<OpMaxNan>(rmax);
                 step = wave_reduce<OpMax>(stp_local);
                 if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
-                if (cmax <= tol_comp && step <= tol_step && (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev))) break;
+                if (cmax <= tol_comp && step <= tol_step &&
+                        (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev && rmax <= ADMPC_IPM_FLOOR_CAP * tol_res))) break;      // admpc.h: stopping test
                 rmax_prev = rmax;
             }
             if (fbit > 0 && !cons && it >= fbit) {
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_qp_dense_kernel(const AdmpcConf
                     mu_aff = wave_reduce<OpSum>(s_aff) * inv_nineq;
                     double sigma = mu_aff * rcp_nr(mu); sigma = sigma * sigma * sigma;
                     if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;      // centring safeguard (admpc.h)
-                    const double smu = sigma * mu;
+                    const double smu = fmax(sigma * mu, ADMPC_IPM_MU_FLOOR * tol_comp);      // admpc.h: centring target floor
                     if (!cons) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;

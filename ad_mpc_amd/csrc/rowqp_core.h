@@ -74,6 +74,7 @@ struct RqParams {              // wave-uniform scalars
     T inv_nineq;               // 1 / (8N + 2(N-1))
     T big;                     // |value| above this (or NaN) = failed step
     T floor_;                  // lower clamp of t, lam
+    T mu_floor;                // lower bound of the centring target sigma * mu (ADMPC_IPM_MU_FLOOR, admpc.h)
     T sqp_tol;                 // > 0 in SQP mode with a tolerance: finish() reports convergence of the outer iteration
     T blocked;                 // centring safeguard: step length below which the next iteration centres (ADMPC_IPM_BLOCKED_STEP)
     T wrest;                   // a warm start whose first step is shorter than this is abandoned for the cold start (0: never)
@@ -861,7 +862,7 @@ struct RowQp {
             failed = failed | (active & nan);
             active = active & !nan;
             const M conv = active & (R.cmax <= splat(q.tol_comp)) & (step <= splat(q.tol_step)) &
-                           ((rmax <= splat(q.tol_res)) | (X::mfrom(guard > 0) & (rmax > splat((T)0.1) * rmax_prev)));
+                           ((rmax <= splat(q.tol_res)) | (X::mfrom(guard > 0) & (rmax > splat((T)0.1) * rmax_prev) & (rmax <= splat((T)ADMPC_IPM_FLOOR_CAP * q.tol_res))));      // admpc.h: stopping test
             rmax_last = X::sel(active, rmax, rmax_last);
             rmax_prev = rmax;
             active = active & !conv & (iters < X::isel(cons, X::isplat(q.itmax + q.fbit), X::isplat(q.itmax)));
@@ -895,7 +896,7 @@ struct RowQp {
             const V mu_aff = ((one - a_aff) * munq + a_aff * a_aff * s2) * splat(q.inv_nineq);
             V sigma = mu_aff * X::rcp(mu); sigma = sigma * sigma * sigma;
             sigma = X::sel(alpha_prev < splat(q.blocked), one, sigma);   // after a blocked step: centre
-            const V smu = sigma * mu;
+            const V smu = X::vmax(sigma * mu, splat(q.mu_floor));      // admpc.h: centring target floor
             RQ_DBG("[emu] it mu=%.6e cmax=%.3e rmax=%.3e a_aff=%.6e mu_aff=%.6e sigma=%.6e\n", X::first(mu), X::first(R.cmax), X::first(rmax), X::first(a_aff), X::first(mu_aff), X::first(sigma));
             // ---- corrector
             sweep_backward(smu);
@@ -1017,6 +1018,10 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     q.inv_nineq = (T)(1.0 / (double)(8 * c.N + 2 * (c.N - 1)));
     q.big = f32 ? (T)1e30 : (T)1e300;
     q.floor_ = f32 ? (T)1e-8 : (T)1e-40;
+    // fp64: MU_FLOOR * tol_comp (admpc.h).  fp32: none -- its tol_comp (1e-3) is a stop level, not an accuracy target (the accuracy of
+    // the float path comes from the steps that overshoot it), and slacks / multipliers are clamped at 1e-8 already.  (A floor of 1e-8
+    // was tried: one of 49 152 census instances then ends 2.6e-2 off the fp64 minimiser instead of 1.8e-3.)
+    q.mu_floor = f32 ? (T)0 : (T)(ADMPC_IPM_MU_FLOOR * c.ipm_tol_comp);
     q.blocked = (T)ADMPC_IPM_BLOCKED_STEP;
     q.wrest = (T)c.ipm_warm_restart;
     q.fbit = (int)c.ipm_fallback_iter;

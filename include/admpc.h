@@ -56,6 +56,21 @@ extern "C" {
  * badly centred iterate (seen on one of 16384 config-5 scenarios: mu cycling with period 4 until iter_max). */
 #define ADMPC_IPM_BLOCKED_STEP 0.05
 
+/* Two more safeguards (round 3; oracle and every device path of the car model), both against the same failure: once the
+ * complementarity products are below their tolerance while the last step was not yet below its own, the method takes another
+ * iteration, and Mehrotra's heuristic (sigma = (mu_aff / mu)^3 ~ 1e-15 by then) sends mu from 1e-11 to 1e-17 .. 1e-27.  The Newton
+ * matrix of that iteration has barrier ratios lam / t beyond 1e16, and the linear algebra loses every digit: on one of 36 864 GP
+ * scenarios the condensed factorisation produced a garbage direction (a blocked step that moved the inputs by 1.3e-2, accepted by
+ * the rounding-floor clause of the stopping test); on a long-horizon fallback instance the Riccati form's residual grew from 1e-9
+ * to 1e10 until the iteration limit.
+ *   ADMPC_IPM_MU_FLOOR   the centring target sigma * mu is never below MU_FLOOR * ipm_tol_comp: the method does not drive the
+ *                        complementarity further below its tolerance than three orders of magnitude;
+ *   ADMPC_IPM_FLOOR_CAP  stopping test:  max lam*t <= ipm_tol_comp  and  last input step <= ipm_tol_step  and
+ *                        (residual <= ipm_tol_res  or  the residual sits on its rounding floor -- no longer falling by 10x per
+ *                        iteration -- AND is not above FLOOR_CAP * ipm_tol_res): the floor clause never accepts a large residual. */
+#define ADMPC_IPM_MU_FLOOR 1e-3
+#define ADMPC_IPM_FLOOR_CAP 1e3
+
 /* status per instance (acados enum values used by the reference) */
 #define ADMPC_STATUS_SUCCESS     0
 #define ADMPC_STATUS_MAXITER     2   /* SQP mode with sqp_tol > 0: not converged within sqp_iters steps (iterate and cost are valid) */

@@ -310,24 +310,28 @@ typedef struct {
     real dt[MAXN][NU][4], dlam[MAXN][NU][4], dtd[MAXN][2], dlamd[MAXN][2];
 } IpmWork;
 
-/* all linear residuals at the current iterate; returns their max-norm */
-static real ipm_residuals(const StageQP* qp, const IpmState* s, IpmWork* w)
+/* all linear residuals at the current iterate; returns their max-norm.  *m_ineq (may be NULL): max-norm over the inequality rows the
+ * stopping test re-evaluates (bound pairs, slack-penalty rows, steering rows); *m_stat: over the stationarity rows (ru, rx). */
+static real ipm_residuals(const StageQP* qp, const IpmState* s, IpmWork* w, real* m_ineq, real* m_stat)
 {
     const int N = qp->N;
-    real m = 0;
-#define UPD(v) do { real a_ = R_FABS(v); if (a_ > m || !(a_ == a_)) m = a_; } while (0)
+    real m = 0, mi = 0, ms = 0;
+#define UPD1(acc, v) do { real a_ = R_FABS(v); if (a_ > acc || !(a_ == a_)) acc = a_; } while (0)
+#define UPD(v) UPD1(m, v)
+#define UPDI(v) do { UPD1(m, v); UPD1(mi, v); } while (0)
+#define UPDS(v) do { UPD1(m, v); UPD1(ms, v); } while (0)
     for (int k = 0; k < N; ++k) {
         for (int j = 0; j < NU; ++j) {
             real a = qp->Rd[j] * s->du[k][j] + qp->r[k][j] - s->lam[k][j][0] + s->lam[k][j][1];
             for (int l = 0; l < NX; ++l) a += qp->B[k][l][j] * s->pi[k][l];
-            w->ru[k][j] = a; UPD(a);
-            w->rsl[k][j] = qp->rho_l - s->lam[k][j][0] - s->lam[k][j][2]; UPD(w->rsl[k][j]);
-            w->rsu[k][j] = qp->rho_u - s->lam[k][j][1] - s->lam[k][j][3]; UPD(w->rsu[k][j]);
+            w->ru[k][j] = a; UPDS(a);
+            w->rsl[k][j] = qp->rho_l - s->lam[k][j][0] - s->lam[k][j][2]; UPDI(w->rsl[k][j]);
+            w->rsu[k][j] = qp->rho_u - s->lam[k][j][1] - s->lam[k][j][3]; UPDI(w->rsu[k][j]);
             w->rd[k][j][0] = s->du[k][j] + s->sl[k][j] - qp->dlu[k][j] - s->t[k][j][0];
             w->rd[k][j][1] = -s->du[k][j] + s->su[k][j] + qp->duu[k][j] - s->t[k][j][1];
             w->rd[k][j][2] = s->sl[k][j] - s->t[k][j][2];
             w->rd[k][j][3] = s->su[k][j] - s->t[k][j][3];
-            for (int i = 0; i < 4; ++i) UPD(w->rd[k][j][i]);
+            UPDI(w->rd[k][j][0]); UPDI(w->rd[k][j][1]); UPD(w->rd[k][j][2]); UPD(w->rd[k][j][3]);
         }
         for (int i = 0; i < NX; ++i) {
             real a = qp->b[k][i] - s->dx[k + 1][i];
@@ -342,15 +346,20 @@ static real ipm_residuals(const StageQP* qp, const IpmState* s, IpmWork* w)
                 w->rx[k][i] = a;
             }
             w->rx[k][6] += -s->lamd[k][0] + s->lamd[k][1];
-            for (int i = 0; i < NX; ++i) UPD(w->rx[k][i]);
-            w->rdd[k][0] = s->dx[k][6] - qp->dld[k] - s->td[k][0]; UPD(w->rdd[k][0]);
-            w->rdd[k][1] = qp->dud[k] - s->dx[k][6] - s->td[k][1]; UPD(w->rdd[k][1]);
+            for (int i = 0; i < NX; ++i) UPDS(w->rx[k][i]);
+            w->rdd[k][0] = s->dx[k][6] - qp->dld[k] - s->td[k][0]; UPDI(w->rdd[k][0]);
+            w->rdd[k][1] = qp->dud[k] - s->dx[k][6] - s->td[k][1]; UPDI(w->rdd[k][1]);
         } else {
             for (int i = 0; i < NX; ++i) w->rx[0][i] = 0;
         }
     }
-    for (int i = 0; i < NX; ++i) { w->rx[N][i] = qp->Qe[i] * s->dx[N][i] + qp->q[N][i] - s->pi[N - 1][i]; UPD(w->rx[N][i]); }
+    for (int i = 0; i < NX; ++i) { w->rx[N][i] = qp->Qe[i] * s->dx[N][i] + qp->q[N][i] - s->pi[N - 1][i]; UPDS(w->rx[N][i]); }
 #undef UPD
+#undef UPDI
+#undef UPDS
+#undef UPD1
+    if (m_ineq) *m_ineq = mi;
+    if (m_stat) *m_stat = ms;
     return m;
 }
 
@@ -519,6 +528,14 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
     int it;
     real rmax_prev = 0, step = 1e300;   /* step: max-norm of the last applied input step */
     real alpha_prev = 1;                /* step length of the previous iteration (centring safeguard, admpc.h) */
+    /* Stopping test on the linear residuals: every linear residual of a Newton iteration in residual form shrinks by exactly
+     * (1 - alpha) per step.  The stationarity rows (ru, rx: they carry the dynamics multipliers) enter the test through that law --
+     * rstat starts at their max-norm at the start point and is multiplied by (1 - alpha) per step -- the inequality rows are
+     * re-evaluated.  Re-evaluating the stationarity rows as well puts their accumulated rounding (1e-10 .. 1e-9 at N >= 80) next to
+     * tol_res = 1e-9, and whether an instance on its rounding floor stops one iteration earlier or later then depends on the order
+     * of summation (the device kernels do not iterate the dynamics multipliers at all: rowqp_core.h).  The re-evaluated value is
+     * still formed every iteration: a non-finite entry anywhere is a QP failure. */
+    real rstat = -1;                    /* < 0: (re)start -- take the start point's value */
     for (it = 0; it < c->ipm_iter_max + (cons ? (int)c->ipm_fallback_iter : 0); ++it) {      /* the fallback gets a full budget of its own */
         real mu, cmax;
     residuals:
@@ -528,17 +545,20 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             if (k >= 1) for (int i = 0; i < 2; ++i) { real v = s->td[k][i] * s->lamd[k][i]; w->rcd[k][i] = v; mu += v; if (v > cmax) cmax = v; }
         }
         mu /= n_ineq;
-        real rmax = ipm_residuals(qp, s, w);
-        if (!(mu == mu) || !(rmax == rmax)) return -1;
+        real rineq, rstat_now;
+        real rall = ipm_residuals(qp, s, w, &rineq, &rstat_now);
+        if (!(mu == mu) || !(rall == rall)) return -1;
+        if (rstat < 0) rstat = rstat_now;
+        real rmax = rineq > rstat ? rineq : rstat;
         /* converged, or complementarity reached and the linear residuals sit on their rounding floor */
         if (cmax <= c->ipm_tol_comp && step <= c->ipm_tol_step &&
-            (rmax <= c->ipm_tol_res || (it > 0 && rmax > (real)0.1 * rmax_prev))) break;
+            (rmax <= c->ipm_tol_res || (it > 0 && rmax > (real)0.1 * rmax_prev && rmax <= (real)ADMPC_IPM_FLOOR_CAP * c->ipm_tol_res))) break;
         rmax_prev = rmax;
         if (!cons && c->ipm_fallback_iter > 0 && it >= (int)c->ipm_fallback_iter) {
             /* still iterating: most likely a limit cycle of the centring heuristic.  Start over, finish with plain predictor-centring steps */
             cons = 1; warmed = 0;
             ipm_cold_start(c, qp, s);
-            alpha_prev = 1; step = 1e300; rmax_prev = 0;
+            alpha_prev = 1; step = 1e300; rmax_prev = 0; rstat = -1;
             goto residuals;
         }
 
@@ -558,13 +578,15 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
         mu_aff /= n_ineq;
         real sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
         if (alpha_prev < (real)ADMPC_IPM_BLOCKED_STEP) sigma = 1;       /* blocked step: centre (breaks the method's limit cycles) */
+        real smu = sigma * mu;                                          /* centring target, never below MU_FLOOR * tol_comp (admpc.h) */
+        if (smu < (real)ADMPC_IPM_MU_FLOOR * (real)c->ipm_tol_comp) smu = (real)ADMPC_IPM_MU_FLOOR * (real)c->ipm_tol_comp;
         /* corrector: centring + second-order term (dropped in fallback mode) */
         const real w2 = cons ? 0 : 1;
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < NU; ++j) for (int i = 0; i < 4; ++i)
-                w->rc[k][j][i] = s->t[k][j][i] * s->lam[k][j][i] + w2 * (w->dt[k][j][i] * w->dlam[k][j][i]) - sigma * mu;
+                w->rc[k][j][i] = s->t[k][j][i] * s->lam[k][j][i] + w2 * (w->dt[k][j][i] * w->dlam[k][j][i]) - smu;
             if (k >= 1) for (int i = 0; i < 2; ++i)
-                w->rcd[k][i] = s->td[k][i] * s->lamd[k][i] + w2 * (w->dtd[k][i] * w->dlamd[k][i]) - sigma * mu;
+                w->rcd[k][i] = s->td[k][i] * s->lamd[k][i] + w2 * (w->dtd[k][i] * w->dlamd[k][i]) - smu;
         }
         ipm_reduce(qp, s, w, 0);
         riccati_solve(qp, F, (const real (*)[NX])w->gx, (const real (*)[NU])w->gu, (const real (*)[NX])w->req, w->ddu, w->ddx, w->dpi);
@@ -576,10 +598,11 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             /* the first step from the warm start is blocked (cfg.ipm_warm_restart): start over from the cold start; the iteration counts */
             warmed = 0;
             ipm_cold_start(c, qp, s);
-            alpha_prev = 1; step = 1e300; rmax_prev = 0;
+            alpha_prev = 1; step = 1e300; rmax_prev = 0; rstat = -1;
             continue;
         }
         alpha_prev = alpha;
+        rstat = (1 - alpha) * rstat;
         step = 0;
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < NU; ++j) {

@@ -106,6 +106,54 @@ def kat(ref):
                     terminal_xy_vs_last_row_padding=float(pad_err)))
 
 
+ITERATE2 = os.path.join(REF, "data_driven_mpc/ros_gp_mpc/src/ad_mpc/solve_iteration.json")
+
+
+def kat_mid_rti(ref):
+    """Second, weaker pin from the reference's other stored iterate (src/ad_mpc/solve_iteration.json): N = 40, v_x 10 -> 14 m/s, taken in
+    the middle of an RTI sequence with the DYNAMIC bicycle branch active (its shooting gaps are 8e-4 with p = 1, 0.077 with p = 0).
+    What can be recovered exactly and what cannot:
+      * x, y references: exactly.  Columns 0, 1 of every A_k are unit vectors whatever the linearisation point, so the x, y rows of the
+        stationarity condition read Ts q (x_k - xref_k) + pi_k - pi_{k-1} = 0 with the stored quantities alone (the terminal point
+        again equals the last row, to 7 digits, with the 1e-2 terminal scale -- the same consistency check as for the first fixture);
+      * psi references: only to ~1e-3 rad.  Their row carries d(phi_x, phi_y)/d(psi) of the linearisation the QP was built at, i.e. at
+        the PREVIOUS iterate, which the file does not hold; here they are evaluated at the stored iterate;
+      * the iterate is one RTI step short of convergence: one step of a consistent solver started at it moves it by O(1e-2).
+    Hence the test statement: started at the stored iterate with these references and p = 1, one RTI step stays within 2.5e-2 of it,
+    so does the converged SQP solution, and the set of inputs at their bound (acceleration = 5 on stages 0..7) is the stored one."""
+    d = json.load(open(ITERATE2))
+    N = 40
+    X = np.array([d["x_%d" % k] for k in range(N + 1)])
+    U = np.array([d["u_%d" % k] for k in range(N)])
+    PI = np.array([d["pi_%d" % k] for k in range(N)])
+    LAM = [np.array(d["lam_%d" % k]) for k in range(N)]
+    T = [np.array(d["t_%d" % k]) for k in range(N)]
+    q = np.array([10.0, 10.0, 100.0, 0, 0, 0, 0])
+    gap1 = gap0 = 0.0
+    A = np.zeros((N, NX, NX)); B = np.zeros((N, NX, NU))
+    for k in range(N):
+        phi, A[k], B[k] = ref.rk4_sens(X[k], U[k], 1.0, TS)
+        gap1 = max(gap1, np.abs(phi - X[k + 1]).max())
+        gap0 = max(gap0, np.abs(ref.rk4_sens(X[k], U[k], 0.0, TS)[0] - X[k + 1]).max())
+    yref = np.zeros((N, NX + NU))
+    yref[0, 0:3] = X[0, 0:3]
+    for k in range(1, N):
+        lam = LAM[k]
+        g = A[k].T @ PI[k] - PI[k - 1]
+        g[6] += -lam[2] + lam[5]
+        yref[k, 0:3] = X[k, 0:3] + g[0:3] / (TS * q[0:3])
+    we_scale = 1e-2
+    yref_e = np.zeros(NX)
+    yref_e[0:3] = X[N, 0:3] - PI[N - 1, 0:3] / (we_scale * q[0:3])
+    return dict(
+        source="data_driven_mpc/ros_gp_mpc/src/ad_mpc/solve_iteration.json (acados iterate in the middle of an RTI sequence, N=40, dynamic branch)",
+        N=N, Ts=TS, p=1.0, terminal_scale=we_scale, x0=X[0].tolist(), yref=yref.tolist(), yref_e=yref_e.tolist(),
+        X=X.tolist(), U=U.tolist(), LAM=[l.tolist() for l in LAM],
+        checks=dict(max_shooting_gap_p1=gap1, max_shooting_gap_p0=gap0,
+                    terminal_xy_vs_last_row_padding=float(np.abs(yref_e[0:2] - yref[N - 1, 0:2]).max()),
+                    max_lam_t=float(max((l * t).max() for l, t in zip(LAM, T)))))
+
+
 def ref_traj_golden():
     """Golden vectors of RefTrajectory.set_traj/get_waypoints produced by the reference module itself.  ref_traj.py imports
     rosbag and rospy at module level without using them in these two functions; empty placeholder modules let it import."""
@@ -148,9 +196,12 @@ def main():
     k = kat(ref)
     with open(os.path.join(OUT, "kat_sim_car_iterate.json"), "w") as f:
         json.dump(k, f)
+    k2 = kat_mid_rti(ref)
+    with open(os.path.join(OUT, "kat_solve_iteration.json"), "w") as f:
+        json.dump(k2, f)
     with open(os.path.join(OUT, "ref_traj.json"), "w") as f:
         json.dump(ref_traj_golden(), f)
-    print("shooting.json: 120 cases;  KAT checks:", k["checks"], "; ref_traj.json written")
+    print("shooting.json: 120 cases;  KAT checks:", k["checks"], "; mid-RTI fixture checks:", k2["checks"], "; ref_traj.json written")
 
 
 if __name__ == "__main__":

@@ -44,6 +44,14 @@ def golden_kat():
 
 
 @pytest.fixture(scope="session")
+def golden_kat_mid_rti():
+    """The reference's second stored iterate (solve_iteration.json: dynamic branch, in the middle of an RTI sequence); what it pins
+    and to which level: oracle/make_golden.py:kat_mid_rti."""
+    with open(os.path.join(GOLDEN, "kat_solve_iteration.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def gpu_engine_factory():
     """Returns a function cfg -> BatchSolver on cuda:0; imports the HIP path lazily so that the CPU
     suite never touches it."""

@@ -175,3 +175,30 @@ def test_fallback_mode_ends_the_limit_cycles(oracle):
         off = c.copy(); off.ipm_fallback_iter = 0.0
         r0 = oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
         assert r0[4][0] == c.ipm_iter_max and np.abs(r0[1] - r[1]).max() > 5e-3
+
+
+def _mid_rti_statement(solve, k):
+    """oracle/make_golden.py:kat_mid_rti -- the statement the reference's second stored iterate supports (dynamic branch, p = 1):
+    started at the stored iterate, one RTI step and the converged SQP solution both stay within 2.5e-2 of it (it is one RTI step
+    short of convergence and its heading references are recoverable to ~1e-3 only), and the inputs at their bound are the stored ones
+    (acceleration = 5 on stages 0..7, nothing else)."""
+    N = k["N"]
+    X, U = np.array(k["X"]), np.array(k["U"])
+    x0, yref, ye, p = np.array(k["x0"])[None], np.array(k["yref"])[None], np.array(k["yref_e"])[None], np.array([k["p"]])
+    assert k["checks"]["max_shooting_gap_p1"] < 1e-3 < 0.05 < k["checks"]["max_shooting_gap_p0"]       # the dynamic branch produced it
+    assert k["checks"]["terminal_xy_vs_last_row_padding"] < 1e-6 and k["checks"]["max_lam_t"] < 2e-9
+    at_bound = np.nonzero(U[:, 0] > 5.0 - 1e-6)[0].tolist()
+    assert at_bound == list(range(8)) and np.abs(U[:, 1]).max() < 3.0 - 1e-3 and U[:, 0].min() > -10.0 + 1e-3
+    for sqp in (1, 30):
+        cfg = default_config(N=N, Ts=k["Ts"], terminal_scale=k["terminal_scale"]); cfg.sqp_iters = sqp
+        x, u, cost, st, it = solve(cfg, x0, yref, ye, p, X[None].copy(), U[None].copy())
+        assert st[0] == 0
+        assert np.abs(u[0] - U).max() < 2.5e-2 and np.abs(x[0] - X).max() < 2.5e-2
+        assert np.nonzero(u[0][:, 0] > 5.0 - 1e-6)[0].tolist() == at_bound
+        assert np.abs(x[0][1:N, 6]).max() < 0.52
+    return x, u
+
+
+def test_second_stored_iterate_dynamic_branch(oracle, golden_kat_mid_rti):
+    """Second solver pin (weaker than the converged fixture): the oracle against the reference's mid-RTI acados iterate."""
+    _mid_rti_statement(lambda cfg, *a: oracle.solve_batch(cfg, *a), golden_kat_mid_rti)
