@@ -1204,6 +1204,7 @@ struct AdmpcSolver {
     double* d_ws;            // [cap_row][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
     int32_t* d_split;        // [2 cap_row + 1] keys, order and count of the row kernel's second phase (split batches)
     double* d_dump;          // [cap_row][16 + 31 N] LDS regions of the deferred instances between the two phases
+    int row_chunk;           // > 0: cap of the chunk size of kernel-R solves (ADMPC_ROWQP_CHUNK; tests)
     int split_mode;          // -1: split batches of more than one round of waves (default), 0: never, 1: always (ADMPC_ROWQP_SPLIT)
     double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
 };
@@ -1310,6 +1311,8 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     {   // ADMPC_ROWQP_SPLIT=0 / 1: never / always run the row kernel in two phases (A/B tests); default: by batch size
         const char* e = getenv("ADMPC_ROWQP_SPLIT");
         s->split_mode = e && e[0] == '0' ? 0 : (e && e[0] == '1' ? 1 : -1);
+        const char* c = getenv("ADMPC_ROWQP_CHUNK");
+        s->row_chunk = c ? atoi(c) : 0;
     }
     {   // ADMPC_QP=riccati forces the stage-wise Riccati kernel (A/B tests); default: condensed kernel where instantiated
         const char* e = getenv("ADMPC_QP");
@@ -1364,6 +1367,18 @@ void admpc_destroy(AdmpcSolver* s)
     if (s->d_dump) (void)hipFree(s->d_dump);
     if (s->d_pairs) (void)hipFree(s->d_pairs);
     delete s;
+}
+
+// Kernel R addresses its arrays with 32-bit byte offsets from the (64-bit) array bases: a batch whose largest array would pass 4 GB
+// is solved in consecutive chunks on the caller's stream (same results: instances are independent; the workspace is sized for one
+// chunk).  ADMPC_ROWQP_CHUNK=n caps the chunk (tests).
+static int rowqp_chunk(const AdmpcSolver* s, int N, int elem)
+{
+    const unsigned long long per = (unsigned long long)(N + 1) * 42ull * (unsigned long long)elem;
+    unsigned long long m = ((1ull << 32) - 1ull) / per;
+    if (m > 0x7fffffffull) m = 0x7fffffffull;
+    if (s->row_chunk > 0 && (unsigned long long)s->row_chunk < m) m = (unsigned long long)s->row_chunk;
+    return (int)m;
 }
 
 // ---- workspaces: grown on demand, each by the path that uses it.  Growing synchronises the device (nothing may still be using
@@ -1450,7 +1465,7 @@ int admpc_reserve(AdmpcSolver* s, int B)
     int rc = ensure_status(s, B); if (rc) return rc;
     if (s->use_dense && s->n20_fused) return ensure_fused(s, B);      // no per-instance workspace
     if (s->use_dense) return ensure_dense(s, B);
-    return ensure_row(s, B, 8);
+    { const int chunk = rowqp_chunk(s, s->cfg.N, 8); return ensure_row(s, B < chunk ? B : chunk, 8); }
 }
 
 // Two phases for the row kernel (admpc_rowqp.hip)?  Only with the unconstrained trial on; by default when the batch is more than one
@@ -1462,12 +1477,44 @@ static int32_t* rowqp_split(const AdmpcSolver* s, int B, int rows, int grid)
     return (s->split_mode == 1 || nquads > grid) ? s->d_split : nullptr;
 }
 
-// kernel R addresses its arrays with 32-bit byte offsets from the (64-bit) array bases
-static int rowqp_fits(int B, int N, int elem)
+}  // extern "C"
+
+// linearisation (kernel A) + row-mapped Riccati interior point (kernel R) for a batch of any size, T = double or float
+template <class T>
+static int solve_rows(AdmpcSolver* s, int B, const T* x0, const T* yref, const T* yref_e, const T* p, T* xbar, T* ubar,
+                      T* cost, int32_t* stat, int32_t* iters, T* pi, T* ineq, hipStream_t st)
 {
-    const unsigned long long worst = (unsigned long long)B * (unsigned long long)(N + 1) * 42ull * (unsigned long long)elem;
-    return worst < (1ull << 32);
+    const int N = s->cfg.N, elem = (int)sizeof(T);
+    const int chunk = rowqp_chunk(s, N, elem);
+    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
+    { int rc = ensure_row(s, B < chunk ? B : chunk, elem); if (rc) return rc; }
+    for (long off = 0; off < (long)B; off += chunk) {
+        const int nb = (long)B - off < (long)chunk ? (int)((long)B - off) : chunk;
+        int rows, stride, ldsb, gridR;
+        if (admpc_rowqp_plan(N, elem, nb, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
+        const long totalA = (long)nb * N * 3;
+        int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
+        if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
+        const T* cx0 = x0 + off * NX; const T* cyr = yref + off * N * NY; const T* cye = yref_e + off * NX; const T* cp = p + off;
+        T* cxb = xbar + off * (N + 1) * NX; T* cub = ubar + off * N * NU;
+        T* cco = cost ? cost + off : nullptr; int32_t* cst = stat + off; int32_t* cit = iters ? iters + off : nullptr;
+        T* cpi = pi ? pi + off * (N + 1) * NX : nullptr; T* ciq = ineq ? ineq + off * N * 20 : nullptr;
+        for (int sq = 0; sq < nsqp; ++sq) {
+            const int first = sq == 0 ? 1 : 0;
+            hipLaunchKernelGGL(admpc_linearize_kernel<T>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, nb, (const T*)cxb, (const T*)cub, cp,
+                               first ? (const int32_t*)nullptr : (const int32_t*)cst, (T*)s->d_GT, (T*)s->d_bl, s->d_sched);
+            if constexpr (sizeof(T) == 8)
+                admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, nb, rows, stride, cx0, cyr, cye, (const double*)s->d_GT, (const double*)s->d_bl,
+                                       cxb, cub, cco, cst, cit, cpi, ciq, s->d_ws, first, s->d_sched, rowqp_split(s, nb, rows, gridR), s->d_dump);
+            else
+                admpc_rowqp_launch_f32(gridR, ldsb, st, s->d_cfg, nb, rows, stride, cx0, cyr, cye, (const float*)s->d_GT, (const float*)s->d_bl,
+                                       cxb, cub, cco, cst, cit, cpi, ciq, (float*)s->d_ws, first, s->d_sched, rowqp_split(s, nb, rows, gridR), (float*)s->d_dump);
+        }
+    }
+    return ADMPC_OK;
 }
+
+extern "C" {
 
 int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
                          double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, double* pi, double* ineq, void* stream);
@@ -1498,14 +1545,21 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
     {   // workspaces of the path this call takes (no-ops once sized: admpc_reserve up front keeps the default path allocation-free)
         int rc = ensure_status(s, B); if (rc) return rc;
         if (fused) { rc = ensure_fused(s, B); if (rc) return rc; }
-        else { rc = dense ? ensure_dense(s, B) : ensure_row(s, B, 8); if (rc) return rc; }
+        else if (dense) { rc = ensure_dense(s, B); if (rc) return rc; }
     }
     hipStream_t st = (hipStream_t)stream;
     int32_t* stat = status ? status : s->d_status;
+    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
+    if (!dense) {      // every horizon but N = 20, and every solve that asks for multipliers: kernel A + kernel R, in chunks if need be
+        int rc = solve_rows<double>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, pi, ineq, st); if (rc) return rc;
+        if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
+            hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
+        HIPCHK(hipGetLastError());
+        return ADMPC_OK;
+    }
     const long totalA = (long)B * N * 3;
     int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
     if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
-    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     for (int sq = 0; sq < nsqp; ++sq) {
         const int first = sq == 0 ? 1 : 0;
         if (fused) {
@@ -1515,7 +1569,7 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
         }
         hipLaunchKernelGGL(admpc_linearize_kernel<double>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->d_sched);
-        if (dense) {
+        {
             constexpr int cond_lds = (DenseLds<20>::NTRI + (DenseLds<20>::NTRI & 1) + 20 * GTS + DenseLds<20>::BLS + DenseLds<20>::DQS + NX * 64) * (int)sizeof(double);
             int gridC = s->num_cu * 8; if (gridC > B) gridC = B;
             if (s->qmask == 7)
@@ -1536,13 +1590,6 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
             hipLaunchKernelGGL((admpc_expand_kernel<20>), dim3(gridE), dim3(WAVE), exp_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, (const double*)s->d_aux);
         }
-        else {
-            int rows, stride, ldsb, gridR;
-            if (admpc_rowqp_plan(N, 8, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
-            if (!rowqp_fits(B, N, 8)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
-            admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const double*)s->d_GT, (const double*)s->d_bl,
-                                   xbar, ubar, cost, stat, iters, pi, ineq, s->d_ws, first, s->d_sched, rowqp_split(s, B, rows, gridR), s->d_dump);
-        }
     }
     if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
         hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
@@ -1560,24 +1607,11 @@ int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* y
     if (!x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
-    { int rc = ensure_status(s, B); if (rc) return rc; rc = ensure_row(s, B, 4); if (rc) return rc; }
-    const int N = s->cfg.N;
-    if (!rowqp_fits(B, N, 4)) return fail(ADMPC_EINVAL, "batch too large for one launch (arrays beyond 4 GB): split it");
+    { int rc = ensure_status(s, B); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     int32_t* stat = status ? status : s->d_status;
-    const long totalA = (long)B * N * 3;
-    int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
-    if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
-    int rows, stride, ldsb, gridR;
-    if (admpc_rowqp_plan(N, 4, B, s->num_cu, &rows, &stride, &ldsb, &gridR) != 0) return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel");
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
-    for (int sq = 0; sq < nsqp; ++sq) {
-        const int first = sq == 0 ? 1 : 0;
-        hipLaunchKernelGGL(admpc_linearize_kernel<float>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, (const float*)xbar, (const float*)ubar, p,
-                           first ? (const int32_t*)nullptr : (const int32_t*)stat, (float*)s->d_GT, (float*)s->d_bl, s->d_sched);
-        admpc_rowqp_launch_f32(gridR, ldsb, st, s->d_cfg, B, rows, stride, x0, yref, yref_e, (const float*)s->d_GT, (const float*)s->d_bl,
-                               xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, (float*)s->d_ws, first, s->d_sched, rowqp_split(s, B, rows, gridR), (float*)s->d_dump);
-    }
+    { int rc = solve_rows<float>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, st); if (rc) return rc; }
     if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
         hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
     HIPCHK(hipGetLastError());

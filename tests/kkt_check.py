@@ -41,3 +41,50 @@ def kkt_residuals(cfg, x0, yref, yref_e, xbar, ubar, dbg):
     res["comp"] = max(np.abs(lam_u[:, :, 0] * t0).max(), np.abs(lam_u[:, :, 1] * t1).max(), np.abs(lam_u[:, :, 2] * sl).max(),
                       np.abs(lam_u[:, :, 3] * su).max(), np.abs(lam_d[1:N, 0] * t5).max(), np.abs(lam_d[1:N, 1] * t6).max())
     return res
+
+
+def kkt_residuals_from_multipliers(cfg, x0, yref, yref_e, xbar, ubar, A, B, phi, x_new, u_new, pi, ineq):
+    """KKT residuals of the QP of one RTI step evaluated with the multipliers the solver itself returns
+    (admpc_solve_batch_ex: pi [N+1,7], ineq [N,20], record order of include/admpc.h) -- nothing is reconstructed here, so the
+    stationarity rows test the returned multipliers, not an adjoint recursion of this file.  Linearisation (A, B, phi) at the
+    iterate the step started from (xbar, ubar)."""
+    N = cfg.N
+    Ts = cfg.Ts
+    W = np.array(cfg.W[:]); We = np.array(cfg.We[:])
+    Q = Ts * W[:NX]; R = Ts * W[NX:]
+    rho_l, rho_u = Ts * cfg.zl, Ts * cfg.zu
+    dx = x_new - xbar; du = u_new - ubar
+    b = phi - xbar[1:]
+    t, lam = ineq[:, :10], ineq[:, 10:]
+    q = Q * (xbar[:N] - yref[:, :NX]); r = R * (ubar - yref[:, NX:])
+    qN = We * (xbar[N] - yref_e)
+    res = {}
+    res["x0"] = np.abs(dx[0] - (x0 - xbar[0])).max()
+    res["dyn"] = np.abs(np.array([A[k] @ dx[k] + B[k] @ du[k] + b[k] - dx[k + 1] for k in range(N)])).max()
+    sx = [np.abs(We * dx[N] + qN - pi[N - 1]).max()]
+    for k in range(1, N):
+        g = Q * dx[k] + q[k] + A[k].T @ pi[k] - pi[k - 1]
+        g[6] += -lam[k, 4] + lam[k, 5]
+        sx.append(np.abs(g).max())
+    res["stat_x"] = max(sx)
+    res["stat_x0"] = np.abs(Q * dx[0] + q[0] + A[0].T @ pi[0] - pi[N]).max()        # pi[N]: multiplier of the initial-state equality
+    su_ = []
+    for k in range(N):
+        g = R * du[k] + r[k] + B[k].T @ pi[k]
+        g[0] += -lam[k, 0] + lam[k, 1]; g[1] += -lam[k, 2] + lam[k, 3]
+        su_.append(np.abs(g).max())
+    res["stat_u"] = max(su_)
+    res["stat_s"] = max(np.abs(rho_l - lam[:, 0] - lam[:, 6]).max(), np.abs(rho_u - lam[:, 1] - lam[:, 7]).max(),
+                        np.abs(rho_l - lam[:, 2] - lam[:, 8]).max(), np.abs(rho_u - lam[:, 3] - lam[:, 9]).max())
+    lbu = np.array(cfg.lbu[:]); ubu = np.array(cfg.ubu[:])
+    # slacks as the constraints define them, from the returned primal point and slack variables (t[6..9] are sl0, su0, sl1, su1)
+    sl = np.stack([t[:, 6], t[:, 8]], axis=1); su = np.stack([t[:, 7], t[:, 9]], axis=1)
+    tl = du + sl - (lbu - ubar); tu = -du + su + (ubu - ubar)
+    t5 = dx[1:N, 6] - (cfg.lbx_delta - xbar[1:N, 6]); t6 = (cfg.ubx_delta - xbar[1:N, 6]) - dx[1:N, 6]
+    res["slack_consistency"] = max(np.abs(tl[:, 0] - t[:, 0]).max(), np.abs(tu[:, 0] - t[:, 1]).max(), np.abs(tl[:, 1] - t[:, 2]).max(), np.abs(tu[:, 1] - t[:, 3]).max(),
+                                   np.abs(t5 - t[1:N, 4]).max(), np.abs(t6 - t[1:N, 5]).max())
+    res["prim"] = max(0.0, -min(tl.min(), tu.min(), sl.min(), su.min(), t5.min(), t6.min()))
+    res["dual"] = max(0.0, -lam.min())
+    res["comp"] = np.abs(lam * t)[1:].max(initial=0.0) if N > 1 else 0.0
+    res["comp"] = max(res["comp"], np.abs(lam[0, [0, 1, 2, 3, 6, 7, 8, 9]] * t[0, [0, 1, 2, 3, 6, 7, 8, 9]]).max())
+    return res

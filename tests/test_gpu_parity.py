@@ -465,6 +465,39 @@ def test_second_stored_iterate_dynamic_branch_on_gpu(gpu_engine_factory, oracle,
     assert np.abs(u - o[1]).max() <= 1e-7
 
 
+@pytest.mark.parametrize("N,B", [(20, 48), (40, 32), (80, 16)])
+def test_kkt_residuals_of_the_device_output(gpu_engine_factory, N, B):
+    """Optimality evidence on the DEVICE output, independent of any CPU solver: the step and the multipliers that
+    admpc_solve_batch_ex returns (pi, slacks, inequality multipliers) satisfy the KKT conditions of the QP of the RTI step --
+    linearised dynamics, stationarity in states / inputs / slack variables, primal and dual feasibility, complementarity --
+    evaluated in numpy (tests/kkt_check.py) with the linearisation the device's own shooting entry returns.  The QP is strictly
+    convex in the inputs, so a KKT point IS its minimiser."""
+    import torch
+    from kkt_check import kkt_residuals_from_multipliers
+    cfg = default_config(N=N)
+    s = random_scenarios(B, N=N, seed=77, blend=(3.0, 5.0))
+    eng = gpu_engine_factory(cfg)
+    d = eng.to_device
+    xb, ub = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+    phi, A, Bm = eng.shoot(d(s["xbar"]), d(s["ubar"]), d(s["p"]))
+    st = torch.empty(B, dtype=torch.int32, device=eng.device); it = torch.empty_like(st)
+    pi, ineq = eng.solve_with_multipliers(d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"]), xb, ub, None, st, it)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all() and (it.cpu().numpy() > 0).sum() >= B // 4          # the interior point really ran
+    phi, A, Bm, xn, un, pi, ineq = (t.cpu().numpy() for t in (phi, A, Bm, xb, ub, pi, ineq))
+    worst = {}
+    for i in range(B):
+        r = kkt_residuals_from_multipliers(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], s["xbar"][i], s["ubar"][i], A[i], Bm[i], phi[i],
+                                           xn[i], un[i], pi[i], ineq[i])
+        for k, v in r.items():
+            worst[k] = max(worst.get(k, 0.0), float(v))
+    tol = 1e-7 if N <= 40 else 1e-6
+    assert worst["dyn"] <= 1e-9 and worst["x0"] <= 1e-12, worst
+    for k in ("stat_x", "stat_x0", "stat_u", "stat_s", "slack_consistency", "prim", "dual"):
+        assert worst[k] <= tol, (k, worst)
+    assert worst["comp"] <= 1e-9, worst
+
+
 def test_gp_residual_config3(gpu_engine_factory, oracle):
     cfg = default_config(N=20); set_gp(cfg, grid_gp())
     s = random_scenarios(256, N=20, seed=1234, blend=(3.0, 5.0))
@@ -638,6 +671,54 @@ def test_two_handles_on_two_streams(gpu_engine_factory, N):
         got = (a[4].cpu().numpy(), a[5].cpu().numpy(), outs[i][0].cpu().numpy(), outs[i][1].cpu().numpy(), outs[i][2].cpu().numpy())
         for g, r in zip(got, ref[i]):
             np.testing.assert_array_equal(g, r)
+
+
+def test_batches_beyond_4_gb_are_solved_in_chunks(gpu_engine_factory, monkeypatch):
+    """Kernel R addresses its arrays with 32-bit offsets; the library used to refuse batches whose largest array passes 4 GB
+    ("split it").  Now it splits them itself.  (a) A forced chunk size (ADMPC_ROWQP_CHUNK) gives the bits of the one-launch solve, fp64
+    with multipliers and fp32, odd sizes, converged SQP; (b) a real N = 128 batch of 101 000 instances (4.4 GB of linearisation)
+    equals the solves of its two halves, bit for bit, and every instance converges."""
+    import torch
+    for N, B, chunk in ((40, 1000, 333), (24, 257, 64)):
+        cfg = default_config(N=N, sqp_iters=3, sqp_tol=1e-9)
+        s = random_scenarios(B, N=N, seed=61, blend=(3.0, 5.0))
+        ref = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        ref32 = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], dtype=np.float32)
+        monkeypatch.setenv("ADMPC_ROWQP_CHUNK", str(chunk))
+        eng = gpu_engine_factory(cfg)
+        got = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        got32 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], dtype=np.float32)
+        d = eng.to_device
+        xb, ub = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+        pi, ineq = eng.solve_with_multipliers(d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"]), xb, ub)
+        monkeypatch.delenv("ADMPC_ROWQP_CHUNK")
+        xb1, ub1 = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+        pi1, ineq1 = gpu_engine_factory(cfg).solve_with_multipliers(d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["p"]), xb1, ub1)
+        torch.cuda.synchronize()
+        for a, b in zip(got + got32, ref + ref32):
+            np.testing.assert_array_equal(a, b)
+        ok = torch.as_tensor(got[3] != 4, device=eng.device)          # a failed instance has no multipliers (its records stay unwritten)
+        assert int(ok.sum()) >= B - B // 50
+        assert torch.equal(pi[ok], pi1[ok]) and torch.equal(ineq[ok], ineq1[ok]) and torch.equal(xb, xb1)
+    N, B = 128, 101000
+    cfg = default_config(N=N)
+    eng = gpu_engine_factory(cfg)
+    assert B * (N + 1) * 42 * 8 > 2 ** 32
+    base = random_scenarios(1000, N=N, seed=62)
+    rep = lambda a: torch.as_tensor(a, device=eng.device).repeat((B // 1000,) + (1,) * (a.ndim - 1)).contiguous()
+    t = {k: rep(base[k]) for k in ("x0", "yref", "yref_e", "p", "xbar", "ubar")}
+    t["p"] = t["p"] * 0.0 + torch.linspace(0.0, 1.0, B, device=eng.device, dtype=torch.float64)        # every instance its own blend: no two alike
+    xb, ub = t["xbar"].clone(), t["ubar"].clone()
+    st = torch.empty(B, dtype=torch.int32, device=eng.device); it = torch.empty_like(st); cost = torch.empty(B, dtype=torch.float64, device=eng.device)
+    eng.solve(t["x0"], t["yref"], t["yref_e"], t["p"], xb, ub, cost, st, it)
+    h = B // 2
+    for lo, hi in ((0, h), (h, B)):
+        xh, uh = t["xbar"][lo:hi].clone(), t["ubar"][lo:hi].clone()
+        sh = torch.empty(hi - lo, dtype=torch.int32, device=eng.device); ih = torch.empty_like(sh); ch = torch.empty(hi - lo, dtype=torch.float64, device=eng.device)
+        eng.solve(t["x0"][lo:hi].contiguous(), t["yref"][lo:hi].contiguous(), t["yref_e"][lo:hi].contiguous(), t["p"][lo:hi].contiguous(), xh, uh, ch, sh, ih)
+        torch.cuda.synchronize()
+        assert torch.equal(xh, xb[lo:hi]) and torch.equal(uh, ub[lo:hi]) and torch.equal(sh, st[lo:hi]) and torch.equal(ih, it[lo:hi]) and torch.equal(ch, cost[lo:hi])
+    assert int((st != 0).sum()) == 0 and int(it.max()) < cfg.ipm_iter_max + 30          # nobody runs out of iterations (fallback budget included)
 
 
 def test_empty_batch_and_argument_errors(gpu_engine_factory):
