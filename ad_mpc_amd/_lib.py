@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libadmpc.so")
 
 EXPORTS = (
     "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_ex", "admpc_solve_batch_f32", "admpc_shoot_batch",
-    "admpc_argmin", "admpc_argmin_pairs", "admpc_argmin_pairs_host", "admpc_argmin_global", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_actuation_batch", "admpc_resample_vel_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
+    "admpc_argmin", "admpc_argmin_pairs", "admpc_argmin_pairs_host", "admpc_argmin_global", "admpc_select_cluster_batch", "admpc_solve_batch_routed", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_actuation_batch", "admpc_resample_vel_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
 )
 QUAD_EXPORTS = ("admpc_quad_default_config", "admpc_quad_create", "admpc_quad_destroy", "admpc_quad_solve_batch", "admpc_quad_shoot_batch")   # include/admpc_quad.h
 
@@ -51,6 +51,8 @@ def load():
     L.admpc_argmin_pairs.argtypes = [C.c_void_p, dp, C.c_int, dp, ip, vp]; L.admpc_argmin_pairs.restype = C.c_int
     L.admpc_argmin_pairs_host.argtypes = [dp, C.c_int, dp, ip]; L.admpc_argmin_pairs_host.restype = C.c_int
     L.admpc_argmin_global.argtypes = [C.c_void_p, dp, C.c_int, C.c_int64, C.c_void_p, dp, ip, vp]; L.admpc_argmin_global.restype = C.c_int
+    L.admpc_select_cluster_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, C.c_int, dp, ip, vp]; L.admpc_select_cluster_batch.restype = C.c_int
+    L.admpc_solve_batch_routed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]; L.admpc_solve_batch_routed.restype = C.c_int
     L.admpc_shift_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, C.c_int, vp]; L.admpc_shift_batch.restype = C.c_int
     L.admpc_epilogue_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, ip, vp]; L.admpc_epilogue_batch.restype = C.c_int
     L.admpc_actuation_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, ip, dp, ip, C.c_int, dp, dp, ip, ip, vp]; L.admpc_actuation_batch.restype = C.c_int

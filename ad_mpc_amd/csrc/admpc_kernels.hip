@@ -1482,7 +1482,7 @@ static int32_t* rowqp_split(const AdmpcSolver* s, int B, int rows, int grid)
 // linearisation (kernel A) + row-mapped Riccati interior point (kernel R) for a batch of any size, T = double or float
 template <class T>
 static int solve_rows(AdmpcSolver* s, int B, const T* x0, const T* yref, const T* yref_e, const T* p, T* xbar, T* ubar,
-                      T* cost, int32_t* stat, int32_t* iters, T* pi, T* ineq, hipStream_t st)
+                      T* cost, int32_t* stat, int32_t* iters, T* pi, T* ineq, hipStream_t st, int routed = 0)
 {
     const int N = s->cfg.N, elem = (int)sizeof(T);
     const int chunk = rowqp_chunk(s, N, elem);
@@ -1500,7 +1500,7 @@ static int solve_rows(AdmpcSolver* s, int B, const T* x0, const T* yref, const T
         T* cco = cost ? cost + off : nullptr; int32_t* cst = stat + off; int32_t* cit = iters ? iters + off : nullptr;
         T* cpi = pi ? pi + off * (N + 1) * NX : nullptr; T* ciq = ineq ? ineq + off * N * 20 : nullptr;
         for (int sq = 0; sq < nsqp; ++sq) {
-            const int first = sq == 0 ? 1 : 0;
+            const int first = (sq == 0 && !routed) ? 1 : 0;      // routed: the status array says which instances are this handle's (0) from the start
             hipLaunchKernelGGL(admpc_linearize_kernel<T>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, nb, (const T*)cxb, (const T*)cub, cp,
                                first ? (const int32_t*)nullptr : (const int32_t*)cst, (T*)s->d_GT, (T*)s->d_bl, s->d_sched);
             if constexpr (sizeof(T) == 8)
@@ -1527,10 +1527,11 @@ int admpc_solve_batch(AdmpcSolver* s, int B, const double* x0, const double* yre
 
 /* admpc_solve_batch plus the multipliers of the returned iterate (acados store_iterate contents).  With pi / ineq given the step
  * runs on the row kernel at every horizon (the condensed N = 20 pipeline eliminates the states and carries no multipliers of the
- * dynamics). */
-int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
-                         double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters,
-                         double* pi, double* ineq, void* stream)
+ * dynamics).  routed (admpc_solve_batch_routed): `status` arrives filled -- 0 for the instances this handle is to solve, non-zero for
+ * the others, which every kernel then leaves alone (the mechanism that skips failed / converged instances in later SQP passes). */
+static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
+                      double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters,
+                      double* pi, double* ineq, void* stream, int routed)
 {
     const bool snap = pi != nullptr || ineq != nullptr;
     if (snap && !(pi && ineq)) return fail(ADMPC_EINVAL, "pi and ineq must be given together");
@@ -1551,7 +1552,7 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
     int32_t* stat = status ? status : s->d_status;
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     if (!dense) {      // every horizon but N = 20, and every solve that asks for multipliers: kernel A + kernel R, in chunks if need be
-        int rc = solve_rows<double>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, pi, ineq, st); if (rc) return rc;
+        int rc = solve_rows<double>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, pi, ineq, st, routed); if (rc) return rc;
         if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
             hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
         HIPCHK(hipGetLastError());
@@ -1561,7 +1562,7 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
     int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
     if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
     for (int sq = 0; sq < nsqp; ++sq) {
-        const int first = sq == 0 ? 1 : 0;
+        const int first = (sq == 0 && !routed) ? 1 : 0;
         if (fused) {
             // shooting, condensing, interior point and expansion of an instance in one persistent kernel: no workspace, no kernel boundary
             admpc_fused20_launch(s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, s->d_tick, s->cap_fused, s->d_slot);
@@ -1593,6 +1594,97 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* 
     }
     if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
         hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_solve_batch_ex(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
+                         double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters,
+                         double* pi, double* ineq, void* stream)
+{
+    return solve_impl(s, B, x0, yref, yref_e, p, xbar, ubar, cost, status, iters, pi, ineq, stream, 0);
+}
+
+// ---- clustered GP ensembles (reference: one solver per cluster, chosen per solve by GPEnsemble.select_gp)
+namespace {
+#pragma clang fp contract(off)
+// nearest centroid of z = [x; u][feats] (Euclidean distance as numpy / the reference computes it, ties -> lowest index): gp.py:738-770
+__global__ void admpc_select_cluster_kernel(int B, int d, int f0, int f1, int f2, const double* __restrict__ xs, const double* __restrict__ us,
+                                            int K, const double* __restrict__ cent, int32_t* __restrict__ route)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int f[3] = { f0, f1, f2 };
+    double z[3];
+    for (int j = 0; j < d; ++j) z[j] = f[j] < NX ? xs[(size_t)b * NX + f[j]] : us[(size_t)b * NU + f[j] - NX];
+    double best = INFINITY; int bi = 0;
+    for (int c = 0; c < K; ++c) {
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) { const double e = z[j] - cent[c * d + j]; acc = acc + e * e; }
+        const double dist = __dsqrt_rn(acc);
+        if (dist < best) { best = dist; bi = c; }
+    }
+    route[b] = bi;
+}
+// status array of one cluster's solve: 0 = this handle's instance, ADMPC_STATUS_SKIP = somebody else's
+#define ADMPC_STATUS_SKIP (-2)
+__global__ void admpc_route_fill_kernel(int B, const int32_t* __restrict__ route, int c, int32_t* __restrict__ tmp)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) tmp[b] = route[b] == c ? 0 : ADMPC_STATUS_SKIP;
+}
+__global__ void admpc_route_merge_kernel(int B, const int32_t* __restrict__ route, int c, const int32_t* __restrict__ tmp, int32_t* __restrict__ status)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && route[b] == c) status[b] = tmp[b];
+}
+// an instance routed to no cluster at all is reported as failed instead of being passed over in silence
+__global__ void admpc_route_invalid_kernel(int B, const int32_t* __restrict__ route, int K, int32_t* __restrict__ status, double* __restrict__ cost, int32_t* __restrict__ iters)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && (route[b] < 0 || route[b] >= K)) { if (status) status[b] = ADMPC_STATUS_QP_FAILURE; if (cost) cost[b] = INFINITY; if (iters) iters[b] = 0; }
+}
+}
+
+int admpc_select_cluster_batch(int device, int B, int n_feat, const int32_t* feats, const double* x_sel, const double* u_sel,
+                               int K, const double* centroids, int32_t* route, void* stream)
+{
+    if (B < 0 || n_feat < 1 || n_feat > 3 || !feats || K < 1) return fail(ADMPC_EINVAL, "bad argument");
+    if (B == 0) return ADMPC_OK;
+    if (!x_sel || !u_sel || !centroids || !route) return fail(ADMPC_EINVAL, "null array argument");
+    for (int j = 0; j < n_feat; ++j) if (feats[j] < 0 || feats[j] >= NX + NU) return fail(ADMPC_EINVAL, "feature index outside [x; u]");
+    DeviceGuard guard(device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(admpc_select_cluster_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n_feat, feats[0], n_feat > 1 ? feats[1] : 0,
+                       n_feat > 2 ? feats[2] : 0, x_sel, u_sel, K, centroids, route);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_solve_batch_routed(AdmpcSolver* const* solvers, int K, int B, const int32_t* route,
+                             const double* x0, const double* yref, const double* yref_e, const double* p,
+                             double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
+{
+    if (!solvers || K < 1) return fail(ADMPC_EINVAL, "bad argument");
+    if (B < 0) return fail(ADMPC_EINVAL, "negative batch");
+    if (B == 0) return ADMPC_OK;
+    if (!route || !x0 || !yref || !yref_e || !p || !xbar || !ubar) return fail(ADMPC_EINVAL, "null array argument");
+    for (int c = 0; c < K; ++c) {
+        if (!solvers[c]) return fail(ADMPC_EINVAL, "null solver");
+        if (solvers[c]->device != solvers[0]->device || solvers[c]->cfg.N != solvers[0]->cfg.N) return fail(ADMPC_EINVAL, "the cluster solvers must share device and horizon");
+    }
+    DeviceGuard guard(solvers[0]->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((B + 255) / 256), blk(256);
+    hipLaunchKernelGGL(admpc_route_invalid_kernel, g, blk, 0, st, B, route, K, status, cost, iters);
+    for (int c = 0; c < K; ++c) {
+        AdmpcSolver* s = solvers[c];
+        int rc = ensure_status(s, B); if (rc) return rc;
+        hipLaunchKernelGGL(admpc_route_fill_kernel, g, blk, 0, st, B, route, c, s->d_status);
+        rc = solve_impl(s, B, x0, yref, yref_e, p, xbar, ubar, cost, s->d_status, iters, nullptr, nullptr, stream, 1); if (rc) return rc;
+        if (status) hipLaunchKernelGGL(admpc_route_merge_kernel, g, blk, 0, st, B, route, c, (const int32_t*)s->d_status, status);
+    }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

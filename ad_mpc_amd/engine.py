@@ -202,9 +202,9 @@ class BatchSolver:
 
 class EnsembleBatchSolver:
     """Clustered GP ensembles (reference: one AcadosOcpSolver per cluster, quad_3d_optimizer.py:207, chosen per
-    solve by GPEnsemble.select_gp, :452 / :491).  One engine handle per cluster; a batch is routed by cluster: the instances of
-    cluster c are gathered, solved by handle c and scattered back (torch index ops are the plumbing, every number comes from
-    the HIP kernels).  ``ensemble``: gp_loader.GPEnsemble."""
+    solve by GPEnsemble.select_gp, :452 / :491).  One engine handle per cluster; selection and routing are HIP kernels of the
+    library (admpc_select_cluster_batch, admpc_solve_batch_routed): no gather / scatter, no host synchronisation -- every
+    handle runs over the whole batch and leaves the instances of the other clusters alone.  ``ensemble``: gp_loader.GPEnsemble."""
 
     def __init__(self, cfg, ensemble, device=0):
         from .config import set_gp
@@ -214,39 +214,52 @@ class EnsembleBatchSolver:
             cc = cfg.copy()
             set_gp(cc, ensemble.clusters[c])
             self.solvers.append(BatchSolver(cc, device=device))
+        self.lib = self.solvers[0].lib
         self.device = self.solvers[0].device
+        self.device_index = self.solvers[0].device_index
         self.N = self.solvers[0].N
-        self._cent = torch.as_tensor(ensemble.centroids.copy(), dtype=torch.float64, device=self.device)       # K x d
+        self._cent = torch.as_tensor(np.ascontiguousarray(ensemble.centroids, dtype=np.float64), device=self.device).contiguous()      # K x d
+        feats = [int(f) for f in np.atleast_1d(ensemble.feats)]
+        self._feats = (C.c_int32 * len(feats))(*feats)
+        self._handles = (C.c_void_p * len(self.solvers))(*[sv._h for sv in self.solvers])
 
     def close(self):
         for s in self.solvers:
             s.close()
 
-    def select(self, x_sel, u_sel):
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def select(self, x_sel, u_sel, route=None):
         """Cluster of every instance from the state / input the caller selects on (the reference passes the reference state and
-        the input target): nearest centroid of the ensemble's feature, ties to the lowest index.  Device tensors in and out."""
-        xu = torch.cat([x_sel, u_sel], dim=1).to(torch.float64)
-        z = xu[:, self.ensemble.feats]                                                   # B x d
-        return torch.argmin(torch.sqrt(((z[None, :, :] - self._cent[:, None, :]) ** 2).sum(dim=2)), dim=0)
+        the input target): nearest centroid of the ensemble's feature, ties to the lowest index.  float64 [B,7] / [B,2] device
+        tensors in, int32 [B] device tensor out.  Asynchronous."""
+        B = x_sel.shape[0]
+        sv = self.solvers[0]
+        x_sel, u_sel = x_sel.contiguous(), u_sel.contiguous()           # row views (e.g. ubar[:, 0, :]) are welcome
+        sv._chk(x_sel, (B, NX)); sv._chk(u_sel, (B, NU))
+        if route is None:
+            route = torch.empty(B, dtype=torch.int32, device=self.device)
+        sv._chk(route, (B,), torch.int32)
+        _lib.check(self.lib.admpc_select_cluster_batch(self.device_index, B, len(self._feats), self._feats, _ptr(x_sel), _ptr(u_sel),
+                                                       int(self._cent.shape[0]), _ptr(self._cent), _ptr(route), self._stream()))
+        return route
 
     def solve(self, gp_ind, x0, yref, yref_e, p, xbar, ubar, cost=None, status=None, iters=None):
-        """BatchSolver.solve with a cluster index per instance (int64 device tensor).  In place on xbar / ubar."""
-        B = x0.shape[0]
-        for c, sv in enumerate(self.solvers):
-            idx = torch.nonzero(gp_ind == c, as_tuple=False).reshape(-1)
-            n = int(idx.numel())
-            if n == 0:
-                continue
-            g = lambda t: t.index_select(0, idx).contiguous()
-            xb, ub = g(xbar), g(ubar)
-            co = torch.empty(n, dtype=x0.dtype, device=self.device)
-            st = torch.empty(n, dtype=torch.int32, device=self.device)
-            it = torch.empty(n, dtype=torch.int32, device=self.device)
-            sv.solve(g(x0), g(yref), g(yref_e), g(p), xb, ub, co, st, it)
-            xbar.index_copy_(0, idx, xb); ubar.index_copy_(0, idx, ub)
-            if cost is not None: cost.index_copy_(0, idx, co)
-            if status is not None: status.index_copy_(0, idx, st)
-            if iters is not None: iters.index_copy_(0, idx, it)
+        """BatchSolver.solve with a cluster index per instance (int32 device tensor, e.g. from `select`; int64 is converted).  In place
+        on xbar / ubar.  Asynchronous.  An index outside [0, K) gives status 4 and cost +inf for that instance."""
+        N, B = self.N, x0.shape[0]
+        sv = self.solvers[0]
+        if gp_ind.dtype != torch.int32:
+            gp_ind = gp_ind.to(torch.int32)
+        sv._chk(gp_ind, (B,), torch.int32)
+        sv._chk(x0, (B, NX)); sv._chk(yref, (B, N, NY)); sv._chk(yref_e, (B, NX)); sv._chk(p, (B,))
+        sv._chk(xbar, (B, N + 1, NX)); sv._chk(ubar, (B, N, NU))
+        if cost is not None: sv._chk(cost, (B,))
+        if status is not None: sv._chk(status, (B,), torch.int32)
+        if iters is not None: sv._chk(iters, (B,), torch.int32)
+        _lib.check(self.lib.admpc_solve_batch_routed(self._handles, len(self.solvers), B, _ptr(gp_ind), _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p),
+                                                     _ptr(xbar), _ptr(ubar), _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
 
 
 class QuadBatchSolver:

@@ -239,6 +239,23 @@ int admpc_argmin_pairs_host(const double* pairs, int W, double* val, int64_t* id
 int admpc_argmin_global(AdmpcSolver* s, const double* cost, int B, int64_t index_offset, void* nccl_comm,
                         double* val, int64_t* idx, void* stream);
 
+/* Clustered GP ensembles.  The reference keeps one solver per cluster of its GP ensemble (quad_3d_optimizer.py:207) and
+ * picks one per solve with GPEnsemble.select_gp (gp.py:738-770; called at quad_3d_optimizer.py:452, :491): nearest centroid of the
+ * ensemble's feature vector z = [x; u][feats].  For a batch:
+ *   admpc_select_cluster_batch   route[b] = index of the centroid nearest to z_b (Euclidean distance, ties -> lowest index);
+ *                                feats: n_feat (1..3) host indices into [x(7); u(2)]; x_sel [B][7], u_sel [B][2], centroids [K][n_feat],
+ *                                route [B] int32: device arrays;
+ *   admpc_solve_batch_routed     admpc_solve_batch with one handle per cluster: instance b is solved by solvers[route[b]] (same device,
+ *                                same horizon; each handle carries the GP of its cluster).  In place on the full-size arrays, no gather /
+ *                                scatter and no host synchronisation: every handle runs over the batch and leaves the instances of the
+ *                                other clusters alone.  An instance with route[b] outside [0, K) is reported as status 4, cost +inf.
+ * Both asynchronous on `stream`. */
+int admpc_select_cluster_batch(int device, int B, int n_feat, const int32_t* feats, const double* x_sel, const double* u_sel,
+                               int K, const double* centroids, int32_t* route, void* stream);
+int admpc_solve_batch_routed(AdmpcSolver* const* solvers, int K, int B, const int32_t* route,
+                             const double* x0, const double* yref, const double* yref_e, const double* p,
+                             double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream);
+
 /* Receding-horizon shift of the iterate between two solves.  The reference never shifts its iterate
  * (the acados capsule keeps it as it is, acados_solver_sim_car.c:705-731; reset_mpc_optimizer is a stub,
  * gp_ad_mpc_node.py:154-158), so this is an option the caller turns on, never part of admpc_solve_batch.

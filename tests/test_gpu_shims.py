@@ -233,4 +233,13 @@ def test_clustered_gp_ensemble_routes_every_instance_to_its_cluster(tmp_path, or
         oo = oracle.solve_batch(co, s["x0"][m], s["yref"][m], s["yref_e"][m], s["p"][m], s["xbar"][m], s["ubar"][m])
         differs += int(np.abs(U[m] - oo[1]).max() > 1e-6)
     assert differs == 3
+    # an instance routed to no cluster is reported as failed (status 4, cost +inf, iterate untouched), the others are solved as before
+    bad = gp_ind.clone(); bad[5] = 7; bad[11] = -1
+    xb2, ub2 = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+    eng.solve(bad, x0, yref, yref_e, p, xb2, ub2, cost, st, it)
+    torch.cuda.synchronize()
+    stn = st.cpu().numpy()
+    assert stn[5] == 4 and stn[11] == 4 and np.isinf(cost.cpu().numpy()[[5, 11]]).all()
+    keep = np.ones(96, dtype=bool); keep[[5, 11]] = False
+    assert np.array_equal(ub2.cpu().numpy()[keep], U[keep]) and np.array_equal(ub2.cpu().numpy()[[5, 11]], s["ubar"][[5, 11]])
     eng.close()
