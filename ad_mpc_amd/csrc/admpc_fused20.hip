@@ -90,7 +90,7 @@ __device__ __forceinline__ void stage_dq_nt(double* __restrict__ dq, const doubl
 
 // LDS map of one instance (doubles): what the interior point needs and nothing else -- 17.7 KB, eight instances per CU (two waves per
 // SIMD).  The exchange buffers keep the relative layout dense40.h's col_head assumes (sb = cb + 128).  The other phases alias it:
-//   A   JT [0, 1920) Jacobian tables of the RK stages, bl [1920, 2060) defects; then GT [0, 840) (written when the tables are dead)
+//   A   JT [0, 1960) Jacobian tables of the RK stages, bl [1960, 2100) defects; then GT [0, 840) (written when the tables are dead)
 //   C   reads GT, bl; dq [860, 1008), gam [1008, 1456); leaves H in [0, 820) (row store after the last read of GT)
 //   E   GT, bl once more in the places of phase A (second run of phase A, or read back from the slot buffer); dq, du in C's places
 // The packed linearisation (GT, bl: 7.8 KB) is needed again behind the interior point, by the expansion, and LDS cannot keep it at this
@@ -99,8 +99,9 @@ struct FusedLds {
     static constexpr int N = 20, NTRI = 820;
     static constexpr int oH = 0, oL = oH + NTRI, oPark = oL + NTRI, oCb = oPark + 5 * 64;
     static constexpr int total = oCb + 4 * 64;                          // 2216 doubles = 17 728 B
-    static constexpr int JTS = 24;                                      // Jacobian entries per (stage, RK stage)
-    static constexpr int oJT = 0, oBlA = N * 4 * JTS, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
+    static constexpr int JTS = 24, JTK = 4 * JTS + 2;                   // Jacobian entries per (stage, RK stage); doubles per stage: 98, not 96 --
+                                                                        // 768 B apart the 20 stages of a table access all hit one bank group
+    static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
     static constexpr int SLOT = N * GTS + N * NX;                       // doubles per wave in the slot buffer
     static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + NX * 64 <= oPark, "LDS aliases");
 };
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { kx[i] = e.f[i]; accx[i] += ws * e.f[i]; }
                     if (live && g == 0) {
-                        double2* jt = reinterpret_cast<double2*>(JT + (k * 4 + s) * FusedLds::JTS);
+                        double2* jt = reinterpret_cast<double2*>(JT + k * FusedLds::JTK + s * FusedLds::JTS);
                         jt[0] = make_double2(e.j0[0], e.j0[1]); jt[1] = make_double2(e.j0[2], e.j1[0]); jt[2] = make_double2(e.j1[1], e.j1[2]);
 #pragma unroll
                         for (int r = 0; r < 3; ++r) { jt[3 + 2 * r] = make_double2(e.a[r][0], e.a[r][1]); jt[4 + 2 * r] = make_double2(e.a[r][2], e.a[r][3]); }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                         }
                     ModelEvalT<double> e;
                     {
-                        const double2* jt = reinterpret_cast<const double2*>(JT + (k * 4 + s) * FusedLds::JTS);
+                        const double2* jt = reinterpret_cast<const double2*>(JT + k * FusedLds::JTK + s * FusedLds::JTS);
                         double2 q;
                         q = jt[0]; e.j0[0] = q.x; e.j0[1] = q.y; q = jt[1]; e.j0[2] = q.x; e.j1[0] = q.y; q = jt[2]; e.j1[1] = q.x; e.j1[2] = q.y;
 #pragma unroll
