@@ -29,8 +29,15 @@
 #ifndef F20_NT
 #define F20_NT 0
 #endif
+// 1: the condensed Hessian H = sum_k Gamma_k' Q Gamma_k is accumulated on the matrix pipe (v_mfma_f64_16x16x4_f64 tiles); 0: by
+// v_fmac_f64_dpp rows on the vector pipe (A/B: scripts/probes/mfma_condense_probe.hip, profiles/r3/mfma_condense_ab.txt)
+#ifndef F20_MFMA
+#define F20_MFMA 1
+#endif
 
 namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ---- optional per-phase wave-time accounting (build with -DADMPC_PHASE_TIMERS: `make timers`): s_memtime ticks (100 MHz) summed
 //      over all waves: 0 ticket draw, 1 A1 (state RK4 + model), 2 A2 (sensitivity columns), 3 C (condensing), 4 D trial,
@@ -103,7 +110,7 @@ struct FusedLds {
                                                                         // 768 B apart the 20 stages of a table access all hit one bank group
     static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
     static constexpr int SLOT = N * GTS + N * NX;                       // doubles per wave in the slot buffer
-    static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + NX * 64 <= oPark, "LDS aliases");
+    static_assert(oBlA + N * NX <= total && oGTC + N * GTS <= oDqC && oGam + (NX + 1) * 64 <= oPark, "LDS aliases");
 };
 
 // ---- work order.  A wave owns an instance for 40 us (the trial solves it) up to 200 us (13 interior-point iterations), and a batch
@@ -433,11 +440,45 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
 #pragma unroll
             for (int c = 0; c < NX; ++c) xh[c] = x0g[(size_t)inst * NX + c] - xbg[c];      // uniform
             WSYNC();
-            double g[NX], hrow[n];
+            double g[NX];
 #pragma unroll
             for (int c = 0; c < NX; ++c) g[c] = 0.0;
+#if F20_MFMA
+            // H on the matrix pipe: six 16 x 16 tiles (I >= J) of v_mfma_f64_16x16x4_f64.  One MFMA step takes K = 4 rows of the
+            // 60 x 40 matrix G whose rows are the weighted components of Gamma_k: per stage the components of QMASK, four at a time
+            // (QMASK 7: x, y, psi + a zero row).  Operand layout: lane = index + 16 * k  ->  lane >> 4 picks the component, lane & 15
+            // the column inside the block; operands come from the LDS exchange buffer the vector version broadcasts from.  The matrix
+            // pipe is otherwise idle and runs under the propagation FMAs: 1260 v_fmac_f64_dpp per instance leave the vector pipe
+            // (measured in isolation: 13.4 -> 10.1 us per instance, profiles/r3/mfma_condense_ab.txt).
+            constexpr int NCOMP = ((QMASK >> 0) & 1) + ((QMASK >> 1) & 1) + ((QMASK >> 2) & 1) + ((QMASK >> 3) & 1) + ((QMASK >> 4) & 1) + ((QMASK >> 5) & 1) + ((QMASK >> 6) & 1);
+            constexpr int NSTEP = (NCOMP + 3) / 4;
+            const int r16 = lane & 15, kq = lane >> 4;
+            int crow[NSTEP]; double wq_l[NSTEP], we_l[NSTEP];       // per MFMA step: this lane's component (7 = the zero row) and its weights
+            {
+                int seen = 0;
+#pragma unroll
+                for (int st_ = 0; st_ < NSTEP; ++st_) { crow[st_] = 7; wq_l[st_] = 0.0; we_l[st_] = 0.0; }
+                static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr ((QMASK >> c) & 1) {
+                        const int st_ = seen >> 2, kk = seen & 3;          // compile-time after unrolling
+#pragma unroll
+                        for (int q_ = 0; q_ < NSTEP; ++q_) if (q_ == st_ && kq == kk) { crow[q_] = c; wq_l[q_] = Qd[c]; we_l[q_] = Qe[c]; }
+                        ++seen;
+                    }
+                });
+            }
+            gam[7 * 64 + lane] = 0.0;                                // the zero row (gam has room for an eighth row)
+            d4 acc[3][3];
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J < 3; ++J) acc[I][J] = d4{0.0, 0.0, 0.0, 0.0};
+#else
+            double hrow[n];
 #pragma unroll
             for (int i = 0; i < n; ++i) hrow[i] = 0.0;
+#endif
             g0 = r_i;
             static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
@@ -447,7 +488,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 // hipcc hoists every LDS load of the whole instance and spills ~1600 registers.
                 int tok = B; asm volatile("" : "+s"(tok));
                 if (tok > 0) {
-                double wg[NX], Rb[NX][3];
+                double wg[NX];
+#if F20_MFMA
+                double blk[NSTEP][3];
+#else
+                double Rb[NX][3];
+#endif
                 if constexpr (k >= 1) {
                     if (lane == k) xh6_own = xh[6];
                     static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
@@ -459,6 +505,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                             gam[c * 64 + lane] = g[c];
                         }
                     });
+#if F20_MFMA
+#pragma unroll
+                    for (int st_ = 0; st_ < NSTEP; ++st_)
+#pragma unroll
+                        for (int m = 0; m < nblk; ++m) blk[st_][m] = gam[crow[st_] * 64 + 16 * m + r16];
+#else
                     static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
                         constexpr int c = decltype(cc)::value;
                         if constexpr ((QMASK >> c) & 1) {
@@ -466,6 +518,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                             for (int m = 0; m < nblk; ++m) Rb[c][m] = gam[c * 64 + 16 * m + (lane & 15)];
                         }
                     });
+#endif
                 }
                 double xn[NX], gn[NX];
                 if constexpr (k < N) {
@@ -495,6 +548,23 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                     for (int r = 0; r < 6; ++r) gn[r] = mine ? (ji ? bb[6 + r] : bb[r]) : gn[r];
                     gn[6] = mine ? (ji ? h : 0.0) : gn[6];
                 }
+#if F20_MFMA
+                if constexpr (k >= 1) {
+                    // H[I][J] += (W G_I)' G_J for the tiles whose columns are non-zero already (inputs of stages < k): I, J < nblk, I >= J
+#pragma unroll
+                    for (int st_ = 0; st_ < NSTEP; ++st_) {
+                        const double wl = k < N ? wq_l[st_] : we_l[st_];
+                        static_for<0, nblk>([&](auto Ic) __attribute__((always_inline)) {
+                            constexpr int I = decltype(Ic)::value;
+                            const double a = wl * blk[st_][I];
+                            static_for<0, I + 1>([&](auto Jc) __attribute__((always_inline)) {
+                                constexpr int J = decltype(Jc)::value;
+                                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, blk[st_][J], acc[I][J], 0, 0, 0);
+                            });
+                        });
+                    }
+                }
+#else
                 if constexpr (k >= 1) {
                     static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
                         constexpr int c = decltype(cc)::value;
@@ -510,13 +580,27 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                         }
                     });
                 }
+#endif
                 if constexpr (k < N) {
 #pragma unroll
                     for (int r = 0; r < NX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; }
                 }
                 }
             });
+#if F20_MFMA
+            // the tiles into the packed lower-triangular rows: element (row = lane >> 4 + 4 v, column = lane & 15) of tile (I, J)
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * I + kq + 4 * v, col = 16 * J + r16;
+                        if (row < n && col <= row) Hp[row * (row + 1) / 2 + col] = acc[I][J][v];
+                    }
+#else
             store_row_40(hrow, lds_byte_addr(Hp + (uact ? (lane * (lane + 1)) / 2 : 0)));
+#endif
             // diagonal slots of the packed factor: 0.0 (the factorisation stores the strictly-lower part only; the substitution
             // assembly lets the source lane of a step take part with this multiplier).  Phase C used L's space: rewrite them.
             WSYNC();
