@@ -29,8 +29,10 @@
 #ifndef F20_NT
 #define F20_NT 0
 #endif
-// 1: the condensed Hessian H = sum_k Gamma_k' Q Gamma_k is accumulated on the matrix pipe (v_mfma_f64_16x16x4_f64 tiles); 0: by
-// v_fmac_f64_dpp rows on the vector pipe (A/B: scripts/probes/mfma_condense_probe.hip, profiles/r3/mfma_condense_ab.txt)
+// 1 (shipped): the Hessian H = sum_k Gamma_k' Q Gamma_k is accumulated on the matrix pipe (v_mfma_f64_16x16x4_f64 tiles), the stage
+// recursion stays on the vector pipe; 0: everything by v_fmac_f64_dpp rows on the vector pipe; 2: the whole condensing -- recursion
+// Gamma_{k+1} = A_k Gamma_k, free response, Hessian, reduced gradient -- in MFMA tiles (correct, 106 GPU tests green, but 1 % SLOWER
+// than 1: a 16 x 16 x 4 tile carries 7 x 7 useful products in the recursion and the dependent chain of 42 of them is latency-bound) (A/B: scripts/probes/mfma_condense_probe.hip, profiles/r3/mfma_condense_ab.txt)
 #ifndef F20_MFMA
 #define F20_MFMA 1
 #endif
@@ -423,6 +425,114 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         // =================================================================================================================
         F20_STAMP(2);
         double g0, xh6_own = 0.0;
+#if F20_MFMA == 2
+        // ---- condensing on the matrix pipe.  Gamma_k (7 x 40) and the free response xhat_k (as a 41st column) live in three
+        // 16-column MFMA tiles in the C/D register layout (lane & 15 = column inside the block, (lane >> 4) + 4 v = row): register v of a
+        // tile IS the B operand of K-step v of the next product, so the stage recursion Gamma_{k+1} = A_k Gamma_k runs tile -> tile with
+        // no exchange at all, and the same registers are both operands of H += (W Gamma)' Gamma.  Column 40 carries xhat_k through the
+        // recursion (+ b_k) and, with the tracking error added, makes row 40 of the accumulated product the reduced gradient:
+        // g0_i = r_i + sum_k Gamma_k[:, i]' W (xhat_k + xbar_k - xref_k).  Per stage the vector pipe only fetches the operands (A_k, B_k,
+        // b_k, the error from LDS) and selects; 184 v_mfma_f64_16x16x4_f64 per instance replace ~3400 vector instructions.
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ji = lane & 1;
+            const bool uact = lane < n;
+            const int sc = uact ? lane : 0;
+            const int r16 = lane & 15, kq = lane >> 4;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            stage_dq_nt<N>(dqC, xbg, yrg, yrefeg + (size_t)inst * NX, lane);
+            const double ubar_i = ubg[sc];
+            const double r_i = Rj * (ubar_i - yrg[(sc >> 1) * 9 + 7 + (sc & 1)]);
+            // weights of the rows this lane holds: row kq (v = 0) and row 4 + kq (v = 1; row 7 does not exist)
+            const double wq0 = Ts * cf->W[kq], we0 = cf->We[kq];
+            const double wq1 = kq < 3 ? Ts * cf->W[4 + (kq < 3 ? kq : 0)] : 0.0, we1 = kq < 3 ? cf->We[4 + (kq < 3 ? kq : 0)] : 0.0;
+            const bool any_hi = (QMASK >> 4) != 0;                      // a tracking weight on v_y, psi_dot or delta: second K-step of H
+            const bool is40 = r16 == 8;                                 // (tile 2 only) the free-response column
+            const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+            d4 G[3] = { z4, z4, z4 };
+            G[2][0] = is40 ? x0g[(size_t)inst * NX + kq] - xbg[kq] : 0.0;                                          // xhat_0 = x0 - xbar_0
+            G[2][1] = (is40 && kq < 3) ? x0g[(size_t)inst * NX + 4 + (kq < 3 ? kq : 0)] - xbg[4 + (kq < 3 ? kq : 0)] : 0.0;
+            d4 acc[3][3];
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J < 3; ++J) acc[I][J] = z4;
+            WSYNC();
+            static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int lim = 2 * k < n ? 2 * k : n;        // inputs of stages < k: the non-zero columns of Gamma_k
+                constexpr int nblk = (lim + 15) / 16;             // column blocks that hold them
+                int tok = B; asm volatile("" : "+s"(tok));         // one stage = one basic block (see the vector version)
+                if (tok > 0) {
+                if constexpr (k >= 1) {
+                    // ---- cost of stage k: H += (W Gamma_k)' Gamma_k, with the tracking error on the free-response column
+                    const double e0 = dqC[k * 7 + kq], e1 = dqC[k * 7 + 4 + (kq < 3 ? kq : 0)];
+                    d4 Gh2 = G[2];
+                    Gh2[0] += is40 ? e0 : 0.0;
+                    Gh2[1] += (is40 && kq < 3) ? e1 : 0.0;
+                    if constexpr (k < N) { const double x6 = rdlane(G[2][1], 40); if (lane == k) xh6_own = x6; }      // xhat_k[6]: row 6 = 2 + 4 * 1 of column 40
+                    const double wl0 = k < N ? wq0 : we0, wl1 = k < N ? wq1 : we1;
+                    static_for<0, nblk>([&](auto Jc) __attribute__((always_inline)) {
+                        constexpr int J = decltype(Jc)::value;
+                        static_for<J, 3>([&](auto Ic) __attribute__((always_inline)) {
+                            constexpr int I = decltype(Ic)::value;
+                            if constexpr (I < nblk || I == 2) {
+                                const d4& GI = I == 2 ? Gh2 : G[I];
+                                const d4& GJ = J == 2 ? Gh2 : G[J];
+                                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl0 * GI[0], GJ[0], acc[I][J], 0, 0, 0);
+                                if (any_hi) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl1 * GI[1], GJ[1], acc[I][J], 0, 0, 0);
+                            }
+                        });
+                    });
+                }
+                if constexpr (k < N) {
+                    // ---- propagate: Gamma_{k+1} = A_k Gamma_k, xhat_{k+1} = A_k xhat_k + b_k.  A operand of K-step s: A_k[lane & 15][4 s + (lane >> 4)]
+                    // (columns 0, 1 of A are unit vectors, row 6 is e6: not stored in the packed record)
+                    const double* Gk = GT + k * GTS;
+                    const int rr = r16 < 6 ? r16 : 0;
+                    const double a0l = Gk[(kq >= 2 ? kq - 2 : 0) * 6 + rr], a1l = Gk[((kq < 3 ? kq : 0) + 2) * 6 + rr];
+                    const double Aop0 = kq < 2 ? (r16 == kq ? 1.0 : 0.0) : (r16 < 6 ? a0l : 0.0);
+                    const double Aop1 = kq < 3 ? (r16 < 6 ? a1l : ((r16 == 6 && kq == 2) ? 1.0 : 0.0)) : 0.0;
+                    d4 Gn[3] = { z4, z4, z4 };
+                    static_for<0, 3>([&](auto Jc) __attribute__((always_inline)) {
+                        constexpr int J = decltype(Jc)::value;
+                        if constexpr (J < nblk || J == 2)
+                            Gn[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop0, G[J][0], __builtin_amdgcn_mfma_f64_16x16x4f64(Aop1, G[J][1], z4, 0, 0, 0), 0, 0, 0);
+                    });
+                    Gn[2][0] += is40 ? bl[k * 7 + kq] : 0.0;
+                    Gn[2][1] += (is40 && kq < 3) ? bl[k * 7 + 4 + (kq < 3 ? kq : 0)] : 0.0;
+                    // the two inputs of stage k enter with B_k: columns 2k, 2k + 1 of block (2k) / 16, rows 0..5 from the record, row 6 = (0, h)
+                    constexpr int Jn = (2 * k) / 16;
+                    const bool bsel = (r16 >> 1) == (k & 7);
+                    const int jc = r16 & 1;
+                    const double b0l = Gk[(5 + jc) * 6 + kq], b1l = Gk[(5 + jc) * 6 + 4 + (kq < 2 ? kq : 0)];
+                    const double b1v = kq < 2 ? b1l : (kq == 2 ? (jc ? h : 0.0) : 0.0);
+                    Gn[Jn][0] = bsel ? b0l : Gn[Jn][0];
+                    Gn[Jn][1] = bsel ? b1v : Gn[Jn][1];
+#pragma unroll
+                    for (int J = 0; J < 3; ++J) G[J] = Gn[J];
+                }
+                }
+            });
+            // the tiles into the packed lower-triangular rows: element (row = lane >> 4 + 4 v, column = lane & 15) of tile (I, J);
+            // row 40 (tile row block 2, element 8 = 0 + 4 * 2: lanes 0..15, v = 2) is the reduced gradient without its input part
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * I + kq + 4 * v, col = 16 * J + r16;
+                        if (row < n && col <= row) Hp[row * (row + 1) / 2 + col] = acc[I][J][v];
+                    }
+            if (kq == 0) { gam[r16] = acc[2][0][2]; gam[16 + r16] = acc[2][1][2]; gam[32 + r16] = acc[2][2][2]; }
+            WSYNC();
+            g0 = r_i + gam[sc];
+            if (uact) Lp[(lane * (lane + 1)) / 2 + lane] = 0.0;         // diagonal slots of the packed factor (see the vector version)
+            WSYNC();
+        }
+#else
         {
             LAUNDER_LANE(lane); LAUNDER_CFG(cf);
             const int ki = lane >> 1, ji = lane & 1;
@@ -607,6 +717,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             if (uact) Lp[(lane * (lane + 1)) / 2 + lane] = 0.0;
             WSYNC();
         }
+#endif
 
         // =================================================================================================================
         // phase D (H5): unconstrained trial + interior point on the condensed QP (text of admpc_qp_dense_kernel)
