@@ -190,10 +190,10 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 __device__ __forceinline__ int sym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
 __host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + n * (n + 1) + QX * n + 64 + 2 * (N + 1) * QX + N * QY + QX + QX + 2 * QX; }
 
-__device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const Lds& L, int lane, double* phi_out)
+__device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const Lds& L, int lane, double* phi_out, int nt = 64)
 {
     const int N = c->N;
-    for (int t = lane; t < N * (QX + QU); t += 64) {
+    for (int t = lane; t < N * (QX + QU); t += nt) {
         const int k = t / (QX + QU), col = t - k * (QX + QU);
         double x[QX], u[QU], phi[QX], sc[QX];
 #pragma unroll
@@ -518,6 +518,252 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
     QFLUSH();
 }
 
+
+// ---- horizons beyond 16 (N nu up to 96 inputs; the reference class defaults to n_nodes = 20, quad_3d_optimizer.py:29): the same
+// algorithm with one THREAD per input in a workgroup of two wavefronts.  What the one-wave kernel exchanges inside the wave (v_readlane
+// broadcasts, DPP reductions) goes through LDS and workgroup barriers here -- about a thousand barriers per interior-point iteration:
+// a compatibility path (the shipped horizon N = 10 and everything up to 16 stay on the kernel above), with the oracle's summation
+// order in the factorisation and the substitutions, so that iteration counts and results follow the oracle as on the other paths.
+#define QW_NT 128
+struct WideRed { double* red; double* slot; };
+__device__ __forceinline__ double qw_sum(double v, const WideRed& R, int tid) {
+    v = wave_sum(v); if ((tid & 63) == 0) R.red[tid >> 6] = v; __syncthreads(); const double r = R.red[0] + R.red[1]; __syncthreads(); return r;
+}
+__device__ __forceinline__ double qw_max(double v, const WideRed& R, int tid) {
+    v = wave_max(v); if ((tid & 63) == 0) R.red[tid >> 6] = v; __syncthreads(); const double r = OpMaxNan::f(R.red[0], R.red[1]); __syncthreads(); return r;
+}
+__device__ __forceinline__ double qw_min(double v, const WideRed& R, int tid) {
+    v = wave_min(v); if ((tid & 63) == 0) R.red[tid >> 6] = v; __syncthreads(); const double r = fmin(R.red[0], R.red[1]); __syncthreads(); return r;
+}
+
+__global__ __launch_bounds__(QW_NT) void admpc_quad_solve_wide_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                                      const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                                      double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
+                                                                      int* __restrict__ ticket)
+{
+    extern __shared__ double lds_raw[];
+    const int N = c->N, n = N * QU, tid = threadIdx.x;
+    Lds L(lds_raw, N);
+    double* const invs = lds_raw + quad_lds_doubles(N);             // [n] reciprocal pivots, then [2] broadcast slots, [2] reduction slots
+    const WideRed R{ invs + n + 2, invs + n };
+    const bool act = tid < n;
+    const int li = act ? tid : 0, ji = li / QU, mi = li - ji * QU;
+    const double Ts = c->Ts;
+    if (tid < QX) { L.wts[tid] = Ts * c->W[tid]; L.wts[QX + tid] = c->We[tid]; }
+    const double Rw = Ts * c->W[QX + mi], lbm = c->lbu[mi], ubm = c->ubu[mi];
+    const double thr0 = c->ipm_thr0, mu0 = c->ipm_mu0, tolc = c->ipm_tol_comp, tolr = c->ipm_tol_res;
+    const int itmax = c->ipm_iter_max;
+    for (int inst = blockIdx.x; inst < B;) {
+        double* xb = xbarg + (size_t)inst * (N + 1) * QX;
+        double* ub = ubarg + (size_t)inst * N * QU;
+        const double* yr = yrefg + (size_t)inst * N * QY;
+        const double* ye = yrefeg + (size_t)inst * QX;
+        const double* x0 = x0g + (size_t)inst * QX;
+        for (int i = tid; i < (N + 1) * QX; i += QW_NT) L.xbs[i] = xb[i];
+        for (int i = tid; i < N * QY + QX; i += QW_NT) L.yrs[i] = i < N * QY ? yr[i] : ye[i - N * QY];
+        shoot_instance(c, xb, ub, L, tid, nullptr, QW_NT);
+        // ---- condensing (oracle: condense)
+        for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0;
+        double g[QX];
+#pragma unroll
+        for (int i = 0; i < QX; ++i) g[i] = 0.0;
+        if (tid < QX) L.xhs[tid] = x0[tid] - xb[tid];
+        const double ubar_i = ub[li];
+        double grad = Rw * (ubar_i - yr[ji * QY + QX + mi]);
+        __syncthreads();
+        for (int k = 0; k < N; ++k) {
+            double gn[QX];
+            const int rr = tid < QX ? tid : 0;
+            double xn = L.b[k * QX + rr];
+#pragma unroll
+            for (int cc = 0; cc < QX; ++cc) xn += L.A[(k * QX + rr) * QX + cc] * L.xhs[cc];
+#pragma unroll
+            for (int r = 0; r < QX; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < QX; ++cc) s += L.A[(k * QX + r) * QX + cc] * g[cc];
+                gn[r] = ji == k ? L.B[(k * QX + r) * QU + mi] : (ji < k ? s : 0.0);
+            }
+            __syncthreads();                                                     // every read of xhs above is done
+#pragma unroll
+            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; if (act) L.gam[r * n + tid] = gn[r]; }
+            if (tid < QX) L.xhs[tid] = xn;
+            __syncthreads();
+            const double* ref = L.yrs + (k + 1) * QY;
+            const int lim = (k + 1) * QU;
+            double wg[QX];
+#pragma unroll
+            for (int cc = 0; cc < QX; ++cc) {
+                const double wq = L.wts[(k + 1 < N ? 0 : QX) + cc];
+                wg[cc] = g[cc] * wq;
+                if (wq != 0.0) grad += wg[cc] * (L.xbs[(k + 1) * QX + cc] + L.xhs[cc] - ref[cc]);
+            }
+            if (act && li < lim) {
+                for (int j = 0; j <= li; ++j) {
+                    double s = L.H[tri(li, j)];
+#pragma unroll
+                    for (int cc = 0; cc < QX; ++cc) s += wg[cc] * L.gam[cc * n + j];
+                    L.H[tri(li, j)] = s;
+                }
+            }
+            __syncthreads();
+        }
+        if (act) L.H[tri(li, li)] += Rw;
+        __syncthreads();
+        // ---- box QP (oracle: box_qp)
+        const double lo = lbm - ubar_i, hi = ubm - ubar_i;
+        double du = 0.0;
+        double tl = act ? fmax(du - lo, thr0) : 1.0, tu = act ? fmax(hi - du, thr0) : 1.0;
+        double ll = act ? mu0 / tl : 0.0, lu = act ? mu0 / tu : 0.0;
+        double alpha_prev = 1.0;
+        int it = 0, st = 0;
+        bool cons = false;
+        for (;; ++it) {
+            double rs = grad - ll + lu;
+            L.gam[tid] = du;                                                     // (gam is free after the condensing: n <= 96 values here)
+            __syncthreads();
+            if (act) for (int j = 0; j < n; ++j) rs += L.H[sym(li, j)] * L.gam[j];
+            const double rl = du - lo - tl, ru = hi - du - tu;
+            const double mu = qw_sum(act ? tl * ll + tu * lu : 0.0, R, tid) / (2.0 * n);
+            const double cmax = qw_max(act ? fmax(tl * ll, tu * lu) : 0.0, R, tid);
+            const double rmax = qw_max(act ? fmax(fabs(rs), fmax(fabs(rl), fabs(ru))) : 0.0, R, tid);
+            if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
+            if ((cmax <= tolc && rmax <= tolr) || it >= itmax + (cons ? ADMPC_QUAD_IPM_FALLBACK_ITER : 0)) break;
+            if (!cons && it >= ADMPC_QUAD_IPM_FALLBACK_ITER) {
+                cons = true;
+                du = 0.0;
+                tl = act ? fmax(du - lo, thr0) : 1.0; tu = act ? fmax(hi - du, thr0) : 1.0;
+                ll = act ? mu0 / tl : 0.0; lu = act ? mu0 / tu : 0.0;
+                alpha_prev = 1.0;
+                --it;
+                continue;
+            }
+            const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
+            if (act) { for (int j = 0; j <= li; ++j) L.M[tri(li, j)] = L.H[tri(li, j)]; L.M[tri(li, li)] += Dl + Du; }
+            __syncthreads();
+            // Cholesky M = L L' (lower), row i on thread i, columns left to right (oracle: chol)
+            bool posdef = true;
+            for (int j = 0; j < n; ++j) {
+                double s = 0.0;
+                if (act && li >= j) {
+                    const double* ri = L.M + tri(li, 0);
+                    const double* rj = L.M + tri(j, 0);
+                    s = ri[j];
+                    for (int k2 = 0; k2 < j; ++k2) s -= ri[k2] * rj[k2];
+                }
+                if (tid == j) R.slot[j & 1] = s;
+                __syncthreads();
+                const double dj = R.slot[j & 1];
+                if (!(dj > 0.0)) { posdef = false; break; }                       // uniform: every thread reads the same slot
+                const double inv = 1.0 / sqrt(dj);
+                if (tid == j) invs[j] = inv;
+                if (act && li > j) L.M[tri(li, j)] = s * inv;
+                __syncthreads();
+            }
+            if (!posdef) { st = 4; break; }
+            auto solve = [&](double rhs) -> double {
+                double r = rhs;
+                for (int k2 = 0; k2 < n; ++k2) {
+                    if (tid == k2) { r = r * invs[k2]; R.slot[k2 & 1] = r; }
+                    __syncthreads();
+                    const double xk = R.slot[k2 & 1];
+                    if (act && li > k2) r -= L.M[tri(li, k2)] * xk;
+                }
+                __syncthreads();
+                for (int k2 = n - 1; k2 >= 0; --k2) {
+                    if (tid == k2) { r = r * invs[k2]; R.slot[k2 & 1] = r; }
+                    __syncthreads();
+                    const double xk = R.slot[k2 & 1];
+                    if (act && li < k2) r -= L.M[tri(k2, li)] * xk;
+                }
+                __syncthreads();
+                return r;
+            };
+            const double da = solve(act ? -rs + (-ll - Dl * rl) - (-lu - Du * ru) : 0.0);
+            double dtl = da + rl, dtu = -da + ru;
+            double dll = -ll - Dl * dtl, dlu = -lu - Du * dtu;
+            auto ratio = [&]() -> double {
+                double a = 1.0;
+                if (act) {
+                    if (dtl < 0) a = fmin(a, -tl / dtl);
+                    if (dtu < 0) a = fmin(a, -tu / dtu);
+                    if (dll < 0) a = fmin(a, -ll / dll);
+                    if (dlu < 0) a = fmin(a, -lu / dlu);
+                }
+                return qw_min(a, R, tid);
+            };
+            double amax = ratio();
+            const double muaff = qw_sum(act ? (tl + amax * dtl) * (ll + amax * dll) + (tu + amax * dtu) * (lu + amax * dlu) : 0.0, R, tid) / (2.0 * n);
+            double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+            if (alpha_prev < ADMPC_QUAD_IPM_BLOCKED_STEP) sigma = 1.0;
+            const double smu = sigma * mu;
+            const double cl = act ? (smu - (cons ? 0.0 : dtl * dll)) / tl : 0.0, cu = act ? (smu - (cons ? 0.0 : dtu * dlu)) / tu : 0.0;
+            const double d = solve(act ? -rs + (cl - ll - Dl * rl) - (cu - lu - Du * ru) : 0.0);
+            dtl = d + rl; dtu = -d + ru;
+            dll = cl - ll - Dl * dtl; dlu = cu - lu - Du * dtu;
+            amax = ratio();
+            double tau = 1.0 - muaff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+            const double alpha = fmin(tau * amax, 1.0);
+            if (act) {
+                du += alpha * d;
+                tl = fmax(tl + alpha * dtl, 1e-40); tu = fmax(tu + alpha * dtu, 1e-40);
+                ll = fmax(ll + alpha * dll, 1e-40); lu = fmax(lu + alpha * dlu, 1e-40);
+            }
+            alpha_prev = alpha;
+            __syncthreads();
+        }
+        // ---- expansion, full step, cost (oracle: rti_step)
+        __syncthreads();
+        L.gam[QX + tid] = act ? du : 0.0;                                        // du of all inputs behind the dx slot
+        if (tid < QX) L.xnew[tid] = xb[tid] + (x0[tid] - xb[tid]);
+        __syncthreads();
+        bool bad = st != 0;
+        const double un = ubar_i + du;
+        if (act && !(fabs(un) <= 1e300)) bad = true;
+        double dx = tid < QX ? x0[tid] - xb[tid] : 0.0;
+        double J = 0.0;
+        if (act) { const double e = un - yr[ji * QY + QX + mi]; J += 0.5 * Rw * e * e; }
+        for (int k = 0; k < N; ++k) {
+            if (tid < QX) L.gam[tid] = dx;
+            __syncthreads();
+            double dn = 0.0;
+            if (tid < QX) {
+                dn = L.b[k * QX + tid];
+                for (int cc = 0; cc < QX; ++cc) dn += L.A[(k * QX + tid) * QX + cc] * L.gam[cc];
+                for (int m = 0; m < QU; ++m) dn += L.B[(k * QX + tid) * QU + m] * L.gam[QX + k * QU + m];
+                const double xv = L.xbs[(k + 1) * QX + tid] + dn;
+                L.xnew[(k + 1) * QX + tid] = xv;
+                if (!(fabs(xv) <= 1e300)) bad = true;
+            }
+            __syncthreads();
+            dx = dn;
+        }
+        for (int i = tid; i < (N + 1) * QX; i += QW_NT) {
+            const int k = i / QX, cc = i - k * QX;
+            const double e = L.xnew[i] - L.yrs[k * QY + cc];
+            J += 0.5 * (k < N ? Ts * c->W[cc] : c->We[cc]) * e * e;
+        }
+        bad = qw_max(bad ? 1.0 : 0.0, R, tid) > 0.0;
+        J = qw_sum(J, R, tid);
+        if (!bad) {
+            for (int i = tid; i < (N + 1) * QX; i += QW_NT) xb[i] = L.xnew[i];
+            if (act) ub[li] = un;
+        }
+        if (tid == 0) {
+            if (costg) costg[inst] = bad ? INFINITY : J;
+            if (statusg) statusg[inst] = bad ? 4 : 0;
+            if (itersg) itersg[inst] = it;
+        }
+        __syncthreads();
+        if (ticket) {
+            if (tid == 0) R.red[0] = (double)atomicAdd(ticket, 1);
+            __syncthreads();
+            inst = (int)gridDim.x + (int)R.red[0];
+            __syncthreads();
+        } else inst += (int)gridDim.x;
+    }
+}
+
 }  // namespace
 
 struct AdmpcQuadSolver {
@@ -559,7 +805,7 @@ void admpc_quad_default_config(AdmpcQuadConfig* c)
 int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** out)
 {
     if (!cfg || !out) return admpc_set_error(ADMPC_EINVAL, "admpc_quad_create: null argument");
-    if (cfg->N < 2 || cfg->N > ADMPC_QUAD_MAX_N) return admpc_set_error(ADMPC_EINVAL, "quad: N must be in [2, 16]");
+    if (cfg->N < 2 || cfg->N > ADMPC_QUAD_MAX_N) return admpc_set_error(ADMPC_EINVAL, "quad: N must be in [2, 24]");
     if (!(cfg->Ts > 0) || !(cfg->mass > 0) || !(cfg->J[0] > 0 && cfg->J[1] > 0 && cfg->J[2] > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: Ts, mass, J must be positive");
     for (int m = 0; m < QU; ++m) {
         if (!(cfg->W[QX + m] > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: input weights must be positive (strict convexity)");
@@ -585,7 +831,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return admpc_set_error(ADMPC_EHIP, "hipGetDeviceProperties failed"); }
     s->num_cu = prop.multiProcessorCount;
-    s->lds_bytes = quad_lds_doubles(cfg->N) * (int)sizeof(double);
+    s->lds_bytes = (quad_lds_doubles(cfg->N) + (cfg->N * QU > 64 ? cfg->N * QU + 4 : 0)) * (int)sizeof(double);      // wide path: + pivots, broadcast and reduction slots
     { const char* e = getenv("ADMPC_QUAD_GENERIC"); s->generic = e && e[0] == '1'; }
     if (hipMalloc((void**)&s->d_cfg, sizeof(AdmpcQuadConfig)) != hipSuccess || hipMalloc((void**)&s->d_ticket, sizeof(int)) != hipSuccess ||
         hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcQuadConfig), hipMemcpyHostToDevice) != hipSuccess) {
@@ -596,6 +842,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_shoot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_quad_solve_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
 }
@@ -622,7 +869,9 @@ int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const do
     int grid = s->num_cu * per_cu; if (grid > B) grid = B;
     int* ticket = B > 8 * grid ? s->d_ticket : nullptr;
     if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
-    if (s->cfg.N * QU == 40 && !s->generic)
+    if (s->cfg.N * QU > 64)          // horizons beyond 16: one thread per input, two waves per instance
+        hipLaunchKernelGGL(admpc_quad_solve_wide_kernel, dim3(grid), dim3(QW_NT), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
+    else if (s->cfg.N * QU == 40 && !s->generic)
         hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
     else
         hipLaunchKernelGGL(admpc_quad_solve_kernel<false>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);

@@ -7,7 +7,7 @@ import numpy as np
 
 from .config import AdmpcGp, GP_MAX_FEAT, GP_MAX_POINTS
 
-QNX, QNU, QNY, QUAD_MAX_N, QUAD_GP_MAX = 13, 4, 17, 16, 3
+QNX, QNU, QNY, QUAD_MAX_N, QUAD_GP_MAX = 13, 4, 17, 24, 3
 
 
 class AdmpcQuadConfig(C.Structure):

@@ -28,7 +28,8 @@ extern "C" {
 #define ADMPC_QUAD_NX 13
 #define ADMPC_QUAD_NU 4
 #define ADMPC_QUAD_NY 17
-#define ADMPC_QUAD_MAX_N 16      /* N * nu <= 64: one lane per input of the condensed QP */
+#define ADMPC_QUAD_MAX_N 24      /* N * nu <= 64 (N <= 16): one lane per input of the condensed QP, one wave per instance; up to 24 (96
+                                  * inputs; the reference class defaults to n_nodes = 20): one thread per input, two waves per instance */
 #define ADMPC_QUAD_GP_MAX 3      /* residual GPs: one per body-frame acceleration component */
 /* Centring safeguard of the box-QP interior point (cf. ADMPC_IPM_BLOCKED_STEP of admpc.h): after a step shorter than this the next
  * iteration is a pure centring step.  0.3 for this problem: with 0.05, 1 - 2 of 4096 aggressive scenarios fall into a limit cycle of

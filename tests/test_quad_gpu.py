@@ -46,7 +46,7 @@ def test_quad_shooting_against_the_reference_golden_vectors(qeng):
             assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("N,B", [(10, 257), (10, 2048), (5, 64), (16, 40)])
+@pytest.mark.parametrize("N,B", [(10, 257), (10, 2048), (5, 64), (16, 40), (17, 33), (20, 300), (24, 40)])
 def test_quad_solve_parity_with_oracle(qoracle, N, B):
     """One RTI step per instance: identical status and interior-point iteration counts, inputs and states within 1e-8, cost 1e-9
     relative; saturated inputs in the batch; x_0 pinned; inputs inside the box."""
@@ -97,6 +97,19 @@ def test_quad_failure_status_and_repeatability(qeng, qoracle):
     assert a[3][7] == 4 and np.isinf(a[2][7]) and (a[0][7] == s["xbar"][7]).all() and (a[1][7] == s["ubar"][7]).all()
     o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
     np.testing.assert_array_equal(a[3], o[3])
+
+
+def test_quad_3d_optimizer_constructs_with_the_reference_defaults(qoracle):
+    """The reference class defaults to n_nodes = 20, t_horizon = 1 (quad_3d_optimizer.py:29): 80 inputs, more than one per lane of a
+    wavefront.  Round 2 refused it at admpc_quad_create; it now runs on the two-wave kernel (horizons 17..24) and follows the oracle."""
+    from ad_mpc_amd.quad_3d_optimizer import Quad3DOptimizer
+    opt = Quad3DOptimizer()
+    assert opt.N == 20 and opt.cfg.N == 20
+    x0 = np.array([0.3, -0.2, 1.0, 1, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.1])
+    opt.set_reference_state([[1.0, 0.5, 1.5], [1, 0, 0, 0], [0, 0, 0], [0, 0, 0]])
+    w, x = opt.run_optimization(x0, return_x=True)
+    assert w.shape == (80,) and x.shape == (21, 13) and np.isfinite(w).all() and w.min() >= -1e-9 and w.max() <= 1 + 1e-9
+    np.testing.assert_allclose(x[0], x0, atol=1e-12)
 
 
 def test_quad_argument_errors():
