@@ -320,7 +320,7 @@ def main():
           torch.cuda.synchronize()
           dt2 = time.perf_counter() - t1
           two = {"ms_per_step": dt2 / K * 1e3, "solves_per_s": B * K / dt2,
-                 "note": "two batches in flight (two handles, two streams): the idle tail of kernel D of one step is filled by the next step; not `value`"}
+                 "note": "two batches in flight (two handles, two streams): the drain of one step's persistent kernel (its last, slowest instances) is filled by the next step; not `value`"}
           two["bit_identical_to_the_timed_run"] = bool(torch.equal(xb2[Wm + K - 1], xb[Wm + K - 1]) and torch.equal(ub2[Wm + K - 1], ub[Wm + K - 1]))
           del eng2
     except Exception as e:                      # a side measurement: never a reason to lose the bench line
@@ -356,11 +356,13 @@ def main():
             "roofline": {"bound": "fp32-valu" if f32 else "fp64-valu", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": ach_tf / peak_tf, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
-                         "kernel": ("one step = admpc_f20_order_kernel (work-order pre-pass, ~3 us) + admpc_fused20_kernel (dominant, > 97 %: shooting, condensing, dense interior point and expansion of an instance in one persistent wave)"
+                         "kernel": ("one step = admpc_f20_order_kernel (work-order pre-pass, ~5 us) + admpc_fused20_kernel (dominant, > 97 %: shooting, condensing, dense interior point and expansion of an instance in one persistent wave)"
                                     if fused else "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
                                     if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than one round of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
                          "kernel_ms": kern_ms,
-                         "note": "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt); roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)" % ("fp32" if f32 else "fp64", peak_tf)},
+                         "note": ("%s; roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"
+                                  % ("vector FMAs, the condensed Hessian alone on v_mfma_f64_16x16x4_f64 tiles (2 %% of the arithmetic; the fp64 matrix peak equals the vector peak: profiles/r3/mfma_condense_ab.txt)"
+                                     if fused else "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt)", "fp32" if f32 else "fp64", peak_tf))},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N, elem)},
             "host_enqueue_ms_per_step": t_enq / K * 1e3, "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
