@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmpc.so")
 
 EXPORTS = (
-    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_ex", "admpc_solve_batch_f32", "admpc_shoot_batch",
+    "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_ex", "admpc_nlp_residuals_batch", "admpc_solve_batch_f32", "admpc_shoot_batch",
     "admpc_argmin", "admpc_argmin_pairs", "admpc_argmin_pairs_host", "admpc_argmin_global", "admpc_select_cluster_batch", "admpc_solve_batch_routed", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_actuation_batch", "admpc_resample_vel_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
 )
 QUAD_EXPORTS = ("admpc_quad_default_config", "admpc_quad_create", "admpc_quad_destroy", "admpc_quad_solve_batch", "admpc_quad_shoot_batch")   # include/admpc_quad.h
@@ -44,6 +44,8 @@ def load():
     L.admpc_solve_batch.restype = C.c_int
     L.admpc_solve_batch_ex.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, dp, vp]
     L.admpc_solve_batch_ex.restype = C.c_int
+    L.admpc_nlp_residuals_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, vp]
+    L.admpc_nlp_residuals_batch.restype = C.c_int
     L.admpc_solve_batch_f32.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]
     L.admpc_solve_batch_f32.restype = C.c_int
     L.admpc_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, vp]; L.admpc_shoot_batch.restype = C.c_int

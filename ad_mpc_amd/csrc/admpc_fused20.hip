@@ -999,7 +999,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             const double Ts = cf->Ts, h = cf->Ts;
             const double Rj = Ts * cf->W[NX + ji];
             const double rho_l = Ts * cf->zl, rho_u = Ts * cf->zu;
-            const double sqp_tol = (cf->sqp_iters > 1 && cf->sqp_tol > 0.0) ? cf->sqp_tol : 0.0;
             const int r6 = lane < 6 ? lane : 0;                     // row of the packed linearisation this lane reads
             const int r7 = lane < NX ? lane : 0;
             const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
@@ -1021,13 +1020,12 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             double dx = lane < NX ? x0g[(size_t)inst * NX + r7] - xbg[r7] : 0.0;      // dx_0 (lanes 0..6)
             WSYNC();
             bool bad = false;
-            double J = 0.0, snorm = 0.0;                       // snorm: max |full step| and |shooting defect| of this SQP step (cfg.sqp_tol)
+            double J = 0.0;
             static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
                 const double e = dx + dqE[k * 7 + r7];
                 J += 0.5 * (k < N ? wq : wqe) * e * e;
                 if (!(fabs(dx) <= 1e300)) bad = true;
-                if (lane < NX) { snorm = OpMaxNan::f(snorm, fabs(dx)); if constexpr (k < N) snorm = OpMaxNan::f(snorm, fabs(ble[k * 7 + r7])); }
                 if (lane < NX) dqE[k * 7 + lane] = dx;            // slot k now holds dx_k
                 if constexpr (k < N) {
                     const double* Gk = GTe + k * GTS;
@@ -1045,12 +1043,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             });
             const double unew = ubar_i + du;
             if (uact && !(fabs(unew) <= 1e300)) bad = true;
-            if (uact) snorm = OpMaxNan::f(snorm, fabs(du));
-            const bool conv = sqp_tol > 0.0 && wave_reduce<OpMaxNan>(snorm) <= sqp_tol;
-            const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : (conv ? -1 : ADMPC_STATUS_SUCCESS);     // -1: converged, see admpc_solve_batch
+            const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
             double Ju = 0.0;
             WSYNC();
-            if (status <= 0) {
+            if (status == 0) {
 #pragma unroll
                 for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i < (N + 1) * NX) STG(xbg + i, LDG(xbg + i) + dqE[i]); }
                 if (uact) {
@@ -1063,7 +1059,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             }
             const double Jt = wave_reduce<OpSum>(J + Ju);
             if (lane == 0) {
-                if (costg) costg[inst] = status <= 0 ? Jt : INFINITY;
+                if (costg) costg[inst] = status == 0 ? Jt : INFINITY;
                 statusg[inst] = status;
             }
             WSYNC();

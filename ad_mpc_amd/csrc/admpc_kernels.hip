@@ -761,7 +761,6 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
     const double wq = lane < NX ? Ts * cfg->W[r7] : 0.0, wqe = lane < NX ? cfg->We[r7] : 0.0;
     const double Rj = Ts * cfg->W[NX + ji];
     const double rho_l = Ts * cfg->zl, rho_u = Ts * cfg->zu;
-    const double sqp_tol = (cfg->sqp_iters > 1 && cfg->sqp_tol > 0.0) ? cfg->sqp_tol : 0.0;
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
         if (statusg[inst] != 0) continue;                   // failed in the interior-point kernel (or failed / converged in an earlier SQP iteration)
         const double* xbg = xbarg + (size_t)inst * (N + 1) * NX;
@@ -778,13 +777,12 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         double dx = lane < NX ? x0g[(size_t)inst * NX + r7] - xbg[r7] : 0.0;      // dx_0 (lanes 0..6)
         WSYNC();
         bool bad = false;
-        double J = 0.0, snorm = 0.0;                       // snorm: max |full step| and |shooting defect| of this SQP step (cfg.sqp_tol)
+        double J = 0.0;
         static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             const double e = dx + dq[k * 7 + r7];
             J += 0.5 * (k < N ? wq : wqe) * e * e;
             if (!(fabs(dx) <= 1e300)) bad = true;
-            if (lane < NX) { snorm = OpMaxNan::f(snorm, fabs(dx)); if constexpr (k < N) snorm = OpMaxNan::f(snorm, fabs(bl[k * 7 + r7])); }
             if (lane < NX) dq[k * 7 + lane] = dx;            // slot k now holds dx_k
             if constexpr (k < N) {
                 const double* Gk = GT + k * GTS;
@@ -803,12 +801,10 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         });
         const double unew = ubar_i + du;
         if (uact && !(fabs(unew) <= 1e300)) bad = true;
-        if (uact) snorm = OpMaxNan::f(snorm, fabs(du));
-        const bool conv = sqp_tol > 0.0 && wave_reduce<OpMaxNan>(snorm) <= sqp_tol;
-        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : (conv ? -1 : ADMPC_STATUS_SUCCESS);     // -1: converged, see admpc_solve_batch
+        const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
         double Ju = 0.0;
         WSYNC();
-        if (status <= 0) {
+        if (status == 0) {
             double* xo = xbarg + (size_t)inst * (N + 1) * NX;
             double* uo = ubarg + (size_t)inst * N * NU;
 #pragma unroll
@@ -824,7 +820,7 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         const double Jt = wave_reduce<OpSum>(J + Ju);
         if (lane == 0) {
 #ifndef ADMPC_TRACE_SCHED
-            if (costg) costg[inst] = status <= 0 ? Jt : INFINITY;
+            if (costg) costg[inst] = status == 0 ? Jt : INFINITY;
 #endif
             statusg[inst] = status;
         }
@@ -1080,6 +1076,107 @@ __global__ void admpc_epilogue_kernel(int N, int B, const double* __restrict__ x
     ack[b * 4 + 0] = (float)x[6]; ack[b * 4 + 1] = (float)u[1]; ack[b * 4 + 2] = (float)x[3]; ack[b * 4 + 3] = (float)u[0];
 }
 
+// SQP solve with a tolerance (cfg.sqp_iters > 1, cfg.sqp_tol > 0: reference solver_type "SQP", create_ros_ad_mpc.py:47-51; the tolerances
+// are acados' defaults nlp_solver_tol_{stat,eq,ineq,comp} = 1e-6, acados_models/sim_car_acados_ocp.json:870-873): acados' stopping test
+// (ocp_nlp_sqp.c: linearise -> residuals of the NLP's KKT system with the iterate's multipliers -> all four inf-norms within tolerance:
+// ACADOS_SUCCESS, else solve the QP and step; ACADOS_MAXITER after nlp_solver_max_iter QPs).  Runs between the linearisation and kernel R
+// in every pass of a solve but the first (the C ABI takes no multipliers in: a cold solver), on the NEW linearisation GT / bl with the
+// multipliers kernel R left for the previous QP (pi: adjoint recursion, as HPIPM's expansion of the condensed solution; ineq: slacks t and
+// multipliers lam in the record order of admpc.h):
+//   res_stat  rows of grad L:  u: R (u - uref) + B' pi_k - lam_lo + lam_up;  slacks: rho - lam - lam_s;
+//                              x_k: Q (x_k - xref_k) + A_k' pi_k - pi_{k-1} (- lam_d,lo + lam_d,up on delta);  x_N: Q_e (x_N - xref_e) - pi_{N-1};
+//                              x_0: against pi_N, the multiplier of the initial-state equality
+//   res_eq    shooting defects b_k, x0 - x_0
+//   res_ineq  constraint value minus its slack t (slack variables read from the slacks of their own bounds)
+//   res_comp  lam .* t
+// One wave per instance, lane <-> stage.  A converged instance gets status -1 and is skipped by the rest of the solve.
+// fp32 (kernel R's float instantiation stops its QPs at residual 1e-2 / complementarity 1e-3, rowqp_core.h): the tolerances are floored
+// at those levels (and the defects at 1e-4: the float shooting), since no NLP residual can be driven below the QP's own.
+template <class T>
+__global__ __launch_bounds__(WAVE) void admpc_nlp_res_kernel(const AdmpcConfig* __restrict__ cfg, int B, const T* __restrict__ x0g,
+                                                             const T* __restrict__ yrefg, const T* __restrict__ yrefeg,
+                                                             const T* __restrict__ xbarg, const T* __restrict__ ubarg,
+                                                             const T* __restrict__ GTg, const T* __restrict__ blg,
+                                                             const T* __restrict__ pig, const T* __restrict__ ineqg,
+                                                             int32_t* __restrict__ statusg, T* __restrict__ resg)
+{
+    constexpr bool f32 = sizeof(T) == 4;
+    const int N = cfg->N, lane = threadIdx.x;
+    const T h = (T)cfg->Ts;
+    const T rho_l = (T)(cfg->Ts * cfg->zl), rho_u = (T)(cfg->Ts * cfg->zu);
+    const double tol = cfg->sqp_tol;
+    const double tol_stat = f32 && tol < 1e-2 ? 1e-2 : tol, tol_eq = f32 && tol < 1e-4 ? 1e-4 : tol;
+    const double tol_ineq = tol_stat, tol_comp = f32 && tol < 1e-3 ? 1e-3 : tol;
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        if (statusg[inst] != 0) continue;                                   // failed or converged in an earlier pass
+        const T* xb = xbarg + (size_t)inst * (N + 1) * NX;
+        const T* ub = ubarg + (size_t)inst * N * NU;
+        const T* yr = yrefg + (size_t)inst * N * NY;
+        const T* pi = pig + (size_t)inst * (N + 1) * NX;
+        T rs = 0, re = 0, ri = 0, rc = 0;
+        auto upd = [](T& acc, T v) __attribute__((always_inline)) { const T a = v < 0 ? -v : v; if (a > acc || a != a) acc = a; };
+        for (int k = lane; k <= N; k += WAVE) {
+            T x[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xb[k * NX + i];
+            if (k == N) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) upd(rs, (T)cfg->We[i] * (x[i] - yrefeg[(size_t)inst * NX + i]) - pi[(N - 1) * NX + i]);
+                continue;
+            }
+            const T* G = GTg + ((size_t)inst * N + k) * GTS;
+            const T* pk = pi + k * NX;
+            const T* pp = pi + (k >= 1 ? k - 1 : N) * NX;
+            const T* iq = ineqg + ((size_t)inst * N + k) * 20;
+            T pv[NX], t[10], lm[10];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pv[i] = pk[i];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { t[i] = iq[i]; lm[i] = iq[10 + i]; }
+            // stationarity in x_k: columns 0, 1 of A_k are unit vectors, row 6 of [A B] is [e6, 0, h] (not stored)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                T a = (T)(cfg->Ts * cfg->W[i]) * (x[i] - yr[k * NY + i]) - pp[i];
+                if (i < 2) a += pv[i];
+                else {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) a += G[(i - 2) * 6 + r] * pv[r];
+                    if (i == 6) { a += pv[6]; if (k >= 1) a += lm[5] - lm[4]; }
+                }
+                upd(rs, a);
+            }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const T u = ub[k * NU + j];
+                T a = (T)(cfg->Ts * cfg->W[NX + j]) * (u - yr[k * NY + NX + j]) - lm[2 * j] + lm[2 * j + 1];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) a += G[(5 + j) * 6 + r] * pv[r];
+                if (j == 1) a += h * pv[6];
+                upd(rs, a);
+                upd(rs, rho_l - lm[2 * j] - lm[6 + 2 * j]); upd(rs, rho_u - lm[2 * j + 1] - lm[7 + 2 * j]);
+                upd(ri, u + t[6 + 2 * j] - (T)cfg->lbu[j] - t[2 * j]); upd(ri, (T)cfg->ubu[j] - u + t[7 + 2 * j] - t[2 * j + 1]);
+                upd(rc, lm[2 * j] * t[2 * j]); upd(rc, lm[2 * j + 1] * t[2 * j + 1]);
+                upd(rc, lm[6 + 2 * j] * t[6 + 2 * j]); upd(rc, lm[7 + 2 * j] * t[7 + 2 * j]);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) upd(re, blg[((size_t)inst * N + k) * NX + i]);
+            if (k >= 1) {
+                upd(ri, x[6] - (T)cfg->lbx_delta - t[4]); upd(ri, (T)cfg->ubx_delta - x[6] - t[5]);
+                upd(rc, lm[4] * t[4]); upd(rc, lm[5] * t[5]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) upd(re, x0g[(size_t)inst * NX + i] - x[i]);
+            }
+        }
+        const double ws = wave_reduce<OpMaxNan>((double)rs), we = wave_reduce<OpMaxNan>((double)re);
+        const double wi = wave_reduce<OpMaxNan>((double)ri), wc = wave_reduce<OpMaxNan>((double)rc);
+        if (lane == 0) {
+            if (ws <= tol_stat && we <= tol_eq && wi <= tol_ineq && wc <= tol_comp) statusg[inst] = -1;
+            if (resg) { resg[(size_t)inst * 4 + 0] = (T)ws; resg[(size_t)inst * 4 + 1] = (T)we; resg[(size_t)inst * 4 + 2] = (T)wi; resg[(size_t)inst * 4 + 3] = (T)wc; }
+        }
+    }
+}
+
 // end of an SQP solve with a tolerance: -1 (converged in some step) -> 0, still 0 after the last step -> ADMPC_STATUS_MAXITER
 __global__ void admpc_sqp_finalize_kernel(int B, int32_t* __restrict__ status)
 {
@@ -1204,6 +1301,8 @@ struct AdmpcSolver {
     double* d_ws;            // [cap_row][N+1][38] workspace of the row kernel (sweep-private state, L2-resident)
     int32_t* d_split;        // [2 cap_row + 1] keys, order and count of the row kernel's second phase (split batches)
     double* d_dump;          // [cap_row][16 + 31 N] LDS regions of the deferred instances between the two phases
+    double* d_mult;          // [cap_mult][(N+1) 7 + 20 N] multipliers between the passes of an SQP solve with a tolerance, when the caller keeps none
+    int cap_mult, mult_elem;
     int row_chunk;           // > 0: cap of the chunk size of kernel-R solves (ADMPC_ROWQP_CHUNK; tests)
     int split_mode;          // -1: split batches of more than one round of waves (default), 0: never, 1: always (ADMPC_ROWQP_SPLIT)
     double* d_pairs;         // [1 + 256] 16-byte (cost, index) records: this rank's, then the all-gathered ones (admpc_argmin_global)
@@ -1307,7 +1406,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     }
     s->cap = s->cap_lin = s->cap_dense = s->cap_row = 0; s->row_elem = 8; s->sched_cap = 0; s->d_tick = nullptr; s->d_slot = nullptr; s->cap_fused = 0;
-    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr; s->d_dump = nullptr;
+    s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr; s->d_dump = nullptr; s->d_mult = nullptr; s->cap_mult = 0; s->mult_elem = 0;
     {   // ADMPC_ROWQP_SPLIT=0 / 1: never / always run the row kernel in two phases (A/B tests); default: by batch size
         const char* e = getenv("ADMPC_ROWQP_SPLIT");
         s->split_mode = e && e[0] == '0' ? 0 : (e && e[0] == '1' ? 1 : -1);
@@ -1364,6 +1463,7 @@ void admpc_destroy(AdmpcSolver* s)
     if (s->d_aux) (void)hipFree(s->d_aux);
     if (s->d_ws) (void)hipFree(s->d_ws);
     if (s->d_split) (void)hipFree(s->d_split);
+    if (s->d_mult) (void)hipFree(s->d_mult);
     if (s->d_dump) (void)hipFree(s->d_dump);
     if (s->d_pairs) (void)hipFree(s->d_pairs);
     delete s;
@@ -1457,15 +1557,32 @@ static int ensure_row(AdmpcSolver* s, int B, int elem)          // kernel R; siz
     return ADMPC_OK;
 }
 
+static int ensure_mult(AdmpcSolver* s, int B, int elem)         // SQP solves with a tolerance whose caller passes no multiplier arrays
+{
+    if (B <= s->cap_mult && elem <= s->mult_elem) return ADMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    const size_t N = (size_t)s->cfg.N;
+    const int nb = B > s->cap_mult ? B : s->cap_mult;
+    const int ne = elem > s->mult_elem ? elem : s->mult_elem;
+    s->cap_mult = 0;
+    if (s->d_mult) (void)hipFree(s->d_mult); s->d_mult = nullptr;
+    HIPCHK(hipMalloc((void**)&s->d_mult, (size_t)nb * ((N + 1) * NX + 20 * N) * (size_t)ne));
+    s->cap_mult = nb; s->mult_elem = ne;
+    return ADMPC_OK;
+}
+
 int admpc_reserve(AdmpcSolver* s, int B)
 {
     if (!s || B < 0) return fail(ADMPC_EINVAL, "admpc_reserve: bad argument");
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     int rc = ensure_status(s, B); if (rc) return rc;
-    if (s->use_dense && s->n20_fused) return ensure_fused(s, B);      // no per-instance workspace
-    if (s->use_dense) return ensure_dense(s, B);
-    { const int chunk = rowqp_chunk(s, s->cfg.N, 8); return ensure_row(s, B < chunk ? B : chunk, 8); }
+    const bool tol_on = s->cfg.sqp_iters > 1 && s->cfg.sqp_tol > 0.0;  // such solves run on the row kernel at every horizon (solve_impl)
+    if (s->use_dense && s->n20_fused && !tol_on) return ensure_fused(s, B);      // no per-instance workspace
+    if (s->use_dense && !tol_on) return ensure_dense(s, B);
+    const int chunk = rowqp_chunk(s, s->cfg.N, 8);
+    rc = ensure_row(s, B < chunk ? B : chunk, 8); if (rc) return rc;
+    return tol_on ? ensure_mult(s, B < chunk ? B : chunk, 8) : ADMPC_OK;
 }
 
 // Two phases for the row kernel (admpc_rowqp.hip)?  Only with the unconstrained trial on; by default when the batch is more than one
@@ -1487,7 +1604,9 @@ static int solve_rows(AdmpcSolver* s, int B, const T* x0, const T* yref, const T
     const int N = s->cfg.N, elem = (int)sizeof(T);
     const int chunk = rowqp_chunk(s, N, elem);
     const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
+    const bool tol_on = nsqp > 1 && s->cfg.sqp_tol > 0.0;      // acados' residual test in front of every QP but the first (admpc_nlp_res_kernel)
     { int rc = ensure_row(s, B < chunk ? B : chunk, elem); if (rc) return rc; }
+    if (tol_on && !pi) { int rc = ensure_mult(s, B < chunk ? B : chunk, elem); if (rc) return rc; }
     for (long off = 0; off < (long)B; off += chunk) {
         const int nb = (long)B - off < (long)chunk ? (int)((long)B - off) : chunk;
         int rows, stride, ldsb, gridR;
@@ -1499,10 +1618,14 @@ static int solve_rows(AdmpcSolver* s, int B, const T* x0, const T* yref, const T
         T* cxb = xbar + off * (N + 1) * NX; T* cub = ubar + off * N * NU;
         T* cco = cost ? cost + off : nullptr; int32_t* cst = stat + off; int32_t* cit = iters ? iters + off : nullptr;
         T* cpi = pi ? pi + off * (N + 1) * NX : nullptr; T* ciq = ineq ? ineq + off * N * 20 : nullptr;
+        if (tol_on && !pi) { cpi = (T*)s->d_mult; ciq = cpi + (size_t)nb * (N + 1) * NX; }      // the chunk's multipliers live between its passes only
         for (int sq = 0; sq < nsqp; ++sq) {
             const int first = (sq == 0 && !routed) ? 1 : 0;      // routed: the status array says which instances are this handle's (0) from the start
             hipLaunchKernelGGL(admpc_linearize_kernel<T>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, nb, (const T*)cxb, (const T*)cub, cp,
                                first ? (const int32_t*)nullptr : (const int32_t*)cst, (T*)s->d_GT, (T*)s->d_bl, s->d_sched);
+            if (tol_on && sq > 0)
+                hipLaunchKernelGGL(admpc_nlp_res_kernel<T>, dim3(nb < s->num_cu * 32 ? nb : s->num_cu * 32), dim3(WAVE), 0, st, s->d_cfg, nb, cx0, cyr, cye,
+                                   (const T*)cxb, (const T*)cub, (const T*)s->d_GT, (const T*)s->d_bl, (const T*)cpi, (const T*)ciq, cst, (T*)nullptr);
             if constexpr (sizeof(T) == 8)
                 admpc_rowqp_launch_f64(gridR, ldsb, st, s->d_cfg, nb, rows, stride, cx0, cyr, cye, (const double*)s->d_GT, (const double*)s->d_bl,
                                        cxb, cub, cco, cst, cit, cpi, ciq, s->d_ws, first, s->d_sched, rowqp_split(s, nb, rows, gridR), s->d_dump);
@@ -1542,7 +1665,10 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
     DeviceGuard guard(s->device);
     if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
     const int N = s->cfg.N;
-    const bool dense = s->use_dense && !snap, fused = dense && s->n20_fused;
+    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
+    // the condensed N = 20 kernels carry no multipliers: solves that return them, and SQP solves with a tolerance (whose stopping test
+    // needs them between the passes), run on the row kernel at every horizon
+    const bool dense = s->use_dense && !snap && !(nsqp > 1 && s->cfg.sqp_tol > 0.0), fused = dense && s->n20_fused;
     {   // workspaces of the path this call takes (no-ops once sized: admpc_reserve up front keeps the default path allocation-free)
         int rc = ensure_status(s, B); if (rc) return rc;
         if (fused) { rc = ensure_fused(s, B); if (rc) return rc; }
@@ -1550,7 +1676,6 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
     }
     hipStream_t st = (hipStream_t)stream;
     int32_t* stat = status ? status : s->d_status;
-    const int nsqp = s->cfg.sqp_iters > 0 ? s->cfg.sqp_iters : 1;
     if (!dense) {      // every horizon but N = 20, and every solve that asks for multipliers: kernel A + kernel R, in chunks if need be
         int rc = solve_rows<double>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, pi, ineq, st, routed); if (rc) return rc;
         if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
@@ -1592,8 +1717,6 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, (const double*)s->d_aux);
         }
     }
-    if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
-        hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }
@@ -1706,6 +1829,31 @@ int admpc_solve_batch_f32(AdmpcSolver* s, int B, const float* x0, const float* y
     { int rc = solve_rows<float>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (float*)nullptr, (float*)nullptr, st); if (rc) return rc; }
     if (nsqp > 1 && s->cfg.sqp_tol > 0.0)
         hipLaunchKernelGGL(admpc_sqp_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, stat);
+    HIPCHK(hipGetLastError());
+    return ADMPC_OK;
+}
+
+int admpc_nlp_residuals_batch(AdmpcSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* p,
+                              const double* xbar, const double* ubar, const double* pi, const double* ineq, double* res, void* stream)
+{
+    if (!s) return fail(ADMPC_EINVAL, "null solver");
+    if (B < 0) return fail(ADMPC_EINVAL, "negative batch");
+    if (B == 0) return ADMPC_OK;
+    if (!x0 || !yref || !yref_e || !p || !xbar || !ubar || !pi || !ineq || !res) return fail(ADMPC_EINVAL, "null array argument");
+    const int N = s->cfg.N;
+    if ((double)B * N * GTS * 8.0 > 4.0e9) return fail(ADMPC_EINVAL, "batch too large for one linearisation: split it");
+    DeviceGuard guard(s->device);
+    if (!guard.ok()) return fail(ADMPC_EHIP, "hipSetDevice failed");
+    { int rc = ensure_status(s, B); if (rc) return rc; rc = ensure_lin(s, B); if (rc) return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    const long totalA = (long)B * N * 3;
+    int gridA = (int)((totalA + LIN_TASKS - 1) / LIN_TASKS);
+    if (gridA > s->num_cu * 64) gridA = s->num_cu * 64;
+    HIPCHK(hipMemsetAsync(s->d_status, 0, (size_t)B * sizeof(int32_t), st));
+    hipLaunchKernelGGL(admpc_linearize_kernel<double>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
+                       (const int32_t*)nullptr, s->d_GT, s->d_bl, s->d_sched);
+    hipLaunchKernelGGL(admpc_nlp_res_kernel<double>, dim3(B < s->num_cu * 32 ? B : s->num_cu * 32), dim3(WAVE), 0, st, s->d_cfg, B, x0, yref, yref_e,
+                       xbar, ubar, (const double*)s->d_GT, (const double*)s->d_bl, pi, ineq, s->d_status, res);
     HIPCHK(hipGetLastError());
     return ADMPC_OK;
 }

@@ -67,12 +67,9 @@ __global__ __launch_bounds__(64) void admpc_rowqp_kernel(const AdmpcConfig* __re
         valid = valid && !res.deferred;
         bool failed = res.failed;
         T J;
-        bool conv;
-        S.finish(valid, failed, J, conv);
+        S.finish(valid, failed, J);
         if (valid && lane16 == 0) {
-            // SQP mode with a tolerance: -1 marks a converged instance for the remaining steps of this solve (skipped like a failed
-            // one); admpc_solve_batch turns it into 0 and what is still 0 after the last step into ADMPC_STATUS_MAXITER
-            statusg[ic] = failed ? ADMPC_STATUS_QP_FAILURE : (conv ? -1 : ADMPC_STATUS_SUCCESS);
+            statusg[ic] = failed ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
             if (costg) costg[ic] = failed ? (T)INFINITY : J;
             if (itersg) itersg[ic] = res.iters;
         }

@@ -75,7 +75,6 @@ struct RqParams {              // wave-uniform scalars
     T big;                     // |value| above this (or NaN) = failed step
     T floor_;                  // lower clamp of t, lam
     T mu_floor;                // lower bound of the centring target sigma * mu (ADMPC_IPM_MU_FLOOR, admpc.h)
-    T sqp_tol;                 // > 0 in SQP mode with a tolerance: finish() reports convergence of the outer iteration
     T blocked;                 // centring safeguard: step length below which the next iteration centres (ADMPC_IPM_BLOCKED_STEP)
     T wrest;                   // a warm start whose first step is shorter than this is abandoned for the cold start (0: never)
     int fbit;                  // fallback: a row still iterating after this many iterations restarts without the second-order term (0: never)
@@ -937,11 +936,11 @@ struct RowQp {
     }
 
     // full step, cost, outputs.  Call after solve(); `write`: rows whose iterate may be overwritten when the step is finite.
-    // conv (SQP mode with a tolerance): the full step and the shooting defects it started from are both within q.sqp_tol.
-    RQ_FN void finish(M write, M& failed, V& cost, M& conv) {
+    // (The stop of an SQP solve with a tolerance is decided in front of the QP, on acados' four residuals: admpc_nlp_res_kernel.)
+    RQ_FN void finish(M write, M& failed, V& cost) {
         const V zero = splat((T)0), half = splat((T)0.5);
         M bad = X::mfalse();
-        V J = zero, sn = zero;
+        V J = zero;
         RQ_NOUNROLL
         for (int pass = 0; pass < 2; ++pass) {
             const M wr = write & !failed;
@@ -960,11 +959,6 @@ struct RowQp {
                     const V e = xn - X::sel(term, re, rr);
                     J = J + X::sel(in, half * X::sel(term, wesd, wsd) * e * e, zero);
                     bad = bad | (in & !(X::vabs(xn) <= splat(q.big)));
-                    if (q.sqp_tol > (T)0) {      // step of this state and the defect of the interval that ends in it
-                        const V xo = X::gld(io.xbar, ixb + kc * 7 + o_dxu);
-                        const V bd = X::gld(io.bl, ibl + X::isel(kc >= 1, kc - 1, X::isplat(0)) * 7 + o_dxu);
-                        sn = X::vmaxnan(sn, X::sel(in, X::vmaxnan(X::vabs(xn - xo), X::sel(kc >= 1, X::vabs(bd), zero)), zero));
-                    }
                 } else {
                     X::gst(io.xbar, ixb + kc * 7 + o_dxu, xn, in & wr);
                 }
@@ -982,7 +976,6 @@ struct RowQp {
                     j = j + X::sel(un < lbj, splat(q.rho_l) * (lbj - un), zero) + X::sel(un > ubj, splat(q.rho_u) * (un - ubj), zero);
                     J = J + X::sel(in, j, zero);
                     bad = bad | (in & !(X::vabs(un) <= splat(q.big)));
-                    if (q.sqp_tol > (T)0) sn = X::vmaxnan(sn, X::sel(in, X::vabs(un - X::gld(io.ubar, iub + kc * 2 + jin)), zero));
                 } else {
                     X::gst(io.ubar, iub + kc * 2 + jin, un, in & wr);
                 }
@@ -990,7 +983,6 @@ struct RowQp {
             if (pass == 0) { failed = failed | X::row_or(bad); }
         }
         cost = X::row_sum(J);
-        conv = X::mfrom(q.sqp_tol > (T)0) & (X::row_maxnan(sn) <= splat(q.sqp_tol));
     }
 };
 
@@ -1025,5 +1017,4 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     q.blocked = (T)ADMPC_IPM_BLOCKED_STEP;
     q.wrest = (T)c.ipm_warm_restart;
     q.fbit = (int)c.ipm_fallback_iter;
-    q.sqp_tol = (T)((c.sqp_iters > 1 && c.sqp_tol > 0) ? (f32 && c.sqp_tol < 1e-4 ? 1e-4 : c.sqp_tol) : 0.0);
 }

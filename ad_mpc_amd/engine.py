@@ -90,6 +90,18 @@ class BatchSolver:
                                                  _ptr(cost), _ptr(status), _ptr(iters), _ptr(pi), _ptr(ineq), self._stream()))
         return pi, ineq
 
+    def nlp_residuals(self, x0, yref, yref_e, p, xbar, ubar, pi, ineq):
+        """admpc_nlp_residuals_batch: [B,4] = (res_stat, res_eq, res_ineq, res_comp) of acados' SQP stopping test at the iterate
+        (xbar, ubar) with the multipliers solve_with_multipliers returned for it (AcadosOcpSolver.get_residuals())."""
+        N = self.N
+        B = x0.shape[0]
+        self._chk(x0, (B, NX)); self._chk(yref, (B, N, NY)); self._chk(yref_e, (B, NX)); self._chk(p, (B,))
+        self._chk(xbar, (B, N + 1, NX)); self._chk(ubar, (B, N, NU)); self._chk(pi, (B, N + 1, NX)); self._chk(ineq, (B, N, 20))
+        res = torch.empty((B, 4), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.admpc_nlp_residuals_batch(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(p), _ptr(xbar), _ptr(ubar),
+                                                      _ptr(pi), _ptr(ineq), _ptr(res), self._stream()))
+        return res
+
     def solve_numpy(self, x0, yref, yref_e, p, xbar, ubar, dtype=np.float64):
         """Convenience for tests / the single-instance shims: host arrays in, host arrays out
         (x, u, cost, status, iters).  dtype=np.float32 runs the fp32 path."""

@@ -137,10 +137,15 @@ typedef struct AdmpcConfig {
                                 * which do not cycle); the iterations keep counting and the instance may use ipm_iter_max further iterations.
                                 * Default 30 (healthy instances need up to 18 / 23 / 27 iterations at N = 40 / 80 / 128:
                                 * scripts/sweep_convergence.py); 0: never. */
-    double  sqp_tol;           /* sqp_iters > 1 only (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): > 0 stops an instance as soon
-                                * as a full step is no longer than sqp_tol (max-norm over states and inputs) from a linearisation point
-                                * whose shooting defects are below sqp_tol too; an instance that has not got there after sqp_iters
-                                * steps returns status 2 (acados ACADOS_MAXITER) with its last iterate.  0: always sqp_iters steps. */
+    double  sqp_tol;           /* sqp_iters > 1 only (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): > 0 is acados' stopping test with
+                                * all four of nlp_solver_tol_{stat,eq,ineq,comp} set to this value (the reference leaves them at acados'
+                                * default 1e-6: acados_models/sim_car_acados_ocp.json:870-873).  In front of every QP of a solve but the first
+                                * the iterate is linearised and the inf-norms of the NLP's KKT residuals are formed with the multipliers of
+                                * the previous QP (see admpc_nlp_residuals_batch); an instance whose four norms are within sqp_tol stops with
+                                * status 0, one that has not got there after sqp_iters QPs returns status 2 (acados ACADOS_MAXITER) with
+                                * its last iterate.  Such solves run on the row kernel at every horizon (the condensed N = 20 kernels carry
+                                * no multipliers).  fp32 entry point: the tolerances are floored at the float QP's own stop levels (1e-2
+                                * stationarity / inequalities, 1e-3 complementarity, 1e-4 defects).  0: always sqp_iters steps. */
     AdmpcGp gp[ADMPC_GP_MAX];
 } AdmpcConfig;
 
@@ -193,6 +198,17 @@ int admpc_solve_batch_ex(AdmpcSolver* s, int B,
                          double* xbar, double* ubar,
                          double* cost, int32_t* status, int32_t* iters,
                          double* pi, double* ineq, void* stream);
+
+/* The four residuals of acados' SQP stopping test (what AcadosOcpSolver.get_residuals() returns: res_stat, res_eq, res_ineq, res_comp)
+ * at an iterate (xbar, ubar) with the multipliers pi / ineq that admpc_solve_batch_ex returned for it:
+ *   res [B][4]   inf-norms of  {gradient of the Lagrangian (states, inputs, slack variables), shooting defects and x0 - x_0,
+ *                               constraint values minus their slacks t, lam .* t}
+ * The library linearises at the iterate (kernel A) and evaluates the rows on the device (admpc_nlp_res_kernel, the kernel that decides
+ * convergence inside an SQP solve with cfg.sqp_tol > 0).  Batches whose linearisation would pass 4 GB are refused (ADMPC_EINVAL). */
+int admpc_nlp_residuals_batch(AdmpcSolver* s, int B,
+                              const double* x0, const double* yref, const double* yref_e, const double* p,
+                              const double* xbar, const double* ubar, const double* pi, const double* ineq,
+                              double* res, void* stream);
 
 /* The same step in fp32 storage AND arithmetic (BASELINE configs[4]: long horizons, large batches).  Arguments as above with
  * float arrays.  The interior point of this entry stops at fp32 levels (complementarity 1e-3, residual 1e-2, last step 1e-3;

@@ -500,6 +500,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
                 for (int i = 0; i < NX; ++i) { s->dx[k + 1][i] += w->ddx[k + 1][i]; s->pi[k][i] = w->dpi[k][i]; }
                 s->lamd[k][0] = s->lamd[k][1] = 0;
             }
+            for (int k = 1; k < N; ++k) { s->td[k][0] = s->dx[k][6] - qp->dld[k]; s->td[k][1] = qp->dud[k] - s->dx[k][6]; }   /* slacks of the idle delta box */
             return 0;
         }
         if (c->ipm_warm_thr > 0) {
@@ -630,10 +631,14 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
 /* ------------------------------------------------------------------------------------------ */
 /* one RTI step of one instance                                                               */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { StageQP qp; IpmState st; IpmWork wk; RicFactor F; real dx[MAXN + 1][NX]; } Workspace;
+typedef struct {
+    StageQP qp; IpmState st; IpmWork wk; RicFactor F; real dx[MAXN + 1][NX];
+    real pia[MAXN + 1][NX];      /* SQP mode with a tolerance: dynamics multipliers of the last QP by the adjoint recursion; [N]: of dx_0 = x0 - xbar_0 */
+} Workspace;
 
-static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const double* yref, const double* yref_e,
-                    double p, double* xbar, double* ubar, int* iters, double* step_norm, double* defect_norm)
+/* H1-H3: linearisation of the OCP at the iterate -> the stage QP of this step */
+static void build_qp(const AdmpcConfig* c, Workspace* W, const double* x0, const double* yref, const double* yref_e,
+                     double p, const double* xbar, const double* ubar)
 {
     const int N = c->N;
     StageQP* qp = &W->qp;
@@ -658,6 +663,81 @@ static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const 
         qp->q[N][i] = qp->Qe[i] * ((real)xbar[N * NX + i] - (real)yref_e[i]);
         qp->dx0[i] = (real)x0[i] - (real)xbar[i];
     }
+}
+
+/* SQP mode with a tolerance (reference solver_type "SQP", create_ros_ad_mpc.py:47-51; the tolerances are acados' defaults,
+ * acados_models/sim_car_acados_ocp.json:870-873 nlp_solver_tol_{comp,eq,ineq,stat} = 1e-6).  acados is not vendored in the
+ * reference (requirements.txt:1 pins github.com/acados/acados at commit 91a01d4c8db1; acados/ocp_nlp/ocp_nlp_sqp.c and
+ * ocp_nlp_common.c:ocp_nlp_res_compute there, restated from their published algorithm): its SQP loop is
+ *     for (iter < nlp_solver_max_iter) { linearise at the iterate; residuals of the NLP's KKT system with the iterate's
+ *         multipliers; all four inf-norms <= their tolerance -> ACADOS_SUCCESS; solve the QP; full step }  -> ACADOS_MAXITER
+ * with  res_stat = || grad of the Lagrangian ||, res_eq = || shooting defects ||, res_ineq = || constraint + slack t ||,
+ * res_comp = || lam .* t ||.  With FULL_CONDENSING_HPIPM the QP solver returns no dynamics multipliers of its own: the
+ * expansion of the condensed solution recovers them by the adjoint recursion, which is what adjoint_multipliers() does (and what
+ * kernel R's sweep_adjoint does on the device).
+ * adjoint_multipliers: call after the full step, with the QP (old linearisation) still in W->qp and the new iterate in xbar. */
+static void adjoint_multipliers(const AdmpcConfig* c, Workspace* W, const double* yref, const double* yref_e, const double* xbar)
+{
+    const int N = c->N;
+    const StageQP* qp = &W->qp; const IpmState* s = &W->st;
+    real lam[NX];
+    for (int i = 0; i < NX; ++i) lam[i] = qp->Qe[i] * ((real)xbar[N * NX + i] - (real)yref_e[i]);
+    for (int k = N - 1; k >= 0; --k) {
+        for (int i = 0; i < NX; ++i) W->pia[k][i] = lam[i];                 /* pi_k multiplies dx_{k+1} = A dx_k + B du_k + b_k */
+        real nx[NX];
+        for (int i = 0; i < NX; ++i) {
+            real a = qp->Qd[i] * ((real)xbar[k * NX + i] - (real)yref[k * NY + i]);
+            if (i == 6 && k >= 1) a += -s->lamd[k][0] + s->lamd[k][1];
+            for (int l = 0; l < NX; ++l) a += qp->A[k][l][i] * lam[l];
+            nx[i] = a;
+        }
+        for (int i = 0; i < NX; ++i) lam[i] = nx[i];
+    }
+    for (int i = 0; i < NX; ++i) W->pia[N][i] = lam[i];                     /* multiplier of the initial-state equality */
+}
+
+/* the four residuals at the iterate the QP in W->qp was linearised at (zero step), with the multipliers and slacks the previous QP
+ * left in W->st / W->pia; the slack variables are read from the slacks of their own bounds (sl = t[2], su = t[3]: the device record
+ * holds nothing else).  res: stat, eq, ineq, comp */
+static void nlp_residuals(const Workspace* W, real res[4])
+{
+    const StageQP* qp = &W->qp; const IpmState* s = &W->st;
+    const int N = qp->N;
+    real rs = 0, re = 0, ri = 0, rc = 0;
+#define UPD1(acc, v) do { real a_ = R_FABS(v); if (a_ > acc || !(a_ == a_)) acc = a_; } while (0)
+    for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < NU; ++j) {
+            const real* t = s->t[k][j]; const real* l = s->lam[k][j];
+            real a = qp->r[k][j] - l[0] + l[1];
+            for (int i = 0; i < NX; ++i) a += qp->B[k][i][j] * W->pia[k][i];
+            UPD1(rs, a); UPD1(rs, qp->rho_l - l[0] - l[2]); UPD1(rs, qp->rho_u - l[1] - l[3]);
+            UPD1(ri, -qp->dlu[k][j] + t[2] - t[0]); UPD1(ri, qp->duu[k][j] + t[3] - t[1]);
+            for (int i = 0; i < 4; ++i) UPD1(rc, l[i] * t[i]);
+        }
+        for (int i = 0; i < NX; ++i) {
+            UPD1(re, qp->b[k][i]);
+            real a = qp->q[k][i] - (k >= 1 ? W->pia[k - 1][i] : W->pia[N][i]);
+            if (i == 6 && k >= 1) a += -s->lamd[k][0] + s->lamd[k][1];
+            for (int l = 0; l < NX; ++l) a += qp->A[k][l][i] * W->pia[k][l];
+            UPD1(rs, a);
+        }
+        if (k >= 1) {
+            UPD1(ri, -qp->dld[k] - s->td[k][0]); UPD1(ri, qp->dud[k] - s->td[k][1]);
+            UPD1(rc, s->lamd[k][0] * s->td[k][0]); UPD1(rc, s->lamd[k][1] * s->td[k][1]);
+        }
+    }
+    for (int i = 0; i < NX; ++i) { UPD1(rs, qp->q[N][i] - W->pia[N - 1][i]); UPD1(re, qp->dx0[i]); }
+#undef UPD1
+    res[0] = rs; res[1] = re; res[2] = ri; res[3] = rc;
+}
+
+/* one RTI step; built != 0: the caller has linearised at this iterate already (build_qp) */
+static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const double* yref, const double* yref_e,
+                    double p, double* xbar, double* ubar, int* iters, int built)
+{
+    const int N = c->N;
+    StageQP* qp = &W->qp;
+    if (!built) build_qp(c, W, x0, yref, yref_e, p, xbar, ubar);
     int it = ipm_solve(c, qp, &W->st, &W->wk, &W->F);                       /* H4+H5 */
     if (iters) *iters = it;
     if (it < 0) return ADMPC_STATUS_QP_FAILURE;
@@ -670,15 +750,6 @@ static int rti_step(const AdmpcConfig* c, Workspace* W, const double* x0, const 
             for (int l = 0; l < NU; ++l) a += qp->B[k][i][l] * W->st.du[k][l];
             W->dx[k + 1][i] = a;
         }
-    if (step_norm && defect_norm) {           /* SQP mode with a tolerance (cfg.sqp_tol): size of the full step and of the defects it starts from */
-        real sn = 0, dn = 0;
-        for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real a = R_FABS(W->dx[k][i]); if (a > sn || !(a == a)) sn = a; }
-        for (int k = 0; k < N; ++k) {
-            for (int j = 0; j < NU; ++j) { real a = R_FABS(W->st.du[k][j]); if (a > sn || !(a == a)) sn = a; }
-            for (int i = 0; i < NX; ++i) { real a = R_FABS(qp->b[k][i]); if (a > dn || !(a == a)) dn = a; }
-        }
-        *step_norm = (double)sn; *defect_norm = (double)dn;
-    }
     int bad = 0;      /* a non-finite step is a QP failure: the iterate is left untouched (acados returns before the update) */
     for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) { real v = (real)xbar[k * NX + i] + W->dx[k][i]; if (!(R_FABS(v) <= 1e300)) bad = 1; }
     for (int k = 0; k < N; ++k) for (int j = 0; j < NU; ++j) { real v = (real)ubar[k * NU + j] + W->st.du[k][j]; if (!(R_FABS(v) <= 1e300)) bad = 1; }
@@ -800,9 +871,18 @@ int oracle_solve_batch(const AdmpcConfig* c, int B, const double* x0, const doub
                 const int tol_on = nsqp > 1 && c->sqp_tol > 0;      /* reference solver_type "SQP": stop on tolerance, status 2 at the limit */
                 int conv = 0;
                 for (int s = 0; s < nsqp && st == 0 && !conv; ++s) {
-                    double sn = 0, dn = 0;
-                    st = rti_step(c, W, x0 + (size_t)b * NX, yr, ye, p[b], xb, ub, &it, &sn, &dn);
-                    if (st == 0 && tol_on && sn <= c->sqp_tol && dn <= c->sqp_tol) conv = 1;
+                    if (tol_on) {
+                        /* acados' loop: linearise, test the four residuals with the multipliers of the previous QP, solve.  The first
+                         * pass has no multipliers to test with (this entry point takes none: a cold solver) and always solves. */
+                        build_qp(c, W, x0 + (size_t)b * NX, yr, ye, p[b], xb, ub);
+                        if (s > 0) {
+                            real res[4];
+                            nlp_residuals(W, res);
+                            if (res[0] <= c->sqp_tol && res[1] <= c->sqp_tol && res[2] <= c->sqp_tol && res[3] <= c->sqp_tol) { conv = 1; break; }
+                        }
+                    }
+                    st = rti_step(c, W, x0 + (size_t)b * NX, yr, ye, p[b], xb, ub, &it, tol_on);
+                    if (st == 0 && tol_on) adjoint_multipliers(c, W, yr, ye, xb);
                 }
                 if (st == 0 && tol_on && !conv) st = ADMPC_STATUS_MAXITER;
                 if (status) status[b] = st;
@@ -829,7 +909,7 @@ int oracle_qp_debug(const AdmpcConfig* c, const double* x0, const double* yref, 
     memcpy(xb, xbar_in, sizeof(double) * (N + 1) * NX);
     memcpy(ub, ubar_in, sizeof(double) * N * NU);
     int it = 0;
-    int st = rti_step(c, W, x0, yref, yref_e, p, xb, ub, &it, NULL, NULL);
+    int st = rti_step(c, W, x0, yref, yref_e, p, xb, ub, &it, 0);
     if (iters) *iters = it;
     for (int k = 0; k < N; ++k) {
         for (int j = 0; j < NU; ++j) {
@@ -847,4 +927,31 @@ int oracle_qp_debug(const AdmpcConfig* c, const double* x0, const double* yref, 
     for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) dx[k * NX + i] = (double)W->dx[k][i];
     free(W); free(xb); free(ub);
     return st;
+}
+
+/* acados' four stopping residuals (res_stat, res_eq, res_ineq, res_comp) at an iterate with given multipliers, in the record layout of
+ * include/admpc.h (pi [N+1][7], ineq [N][20] = t[10], lam[10]): the checker of admpc_nlp_residuals_batch / admpc_nlp_res_kernel.  One instance. */
+int oracle_nlp_residuals(const AdmpcConfig* c, const double* x0, const double* yref, const double* yref_e, double p,
+                         const double* xbar, const double* ubar, const double* pi, const double* ineq, double* res)
+{
+    if (!c || c->N < 2 || c->N > MAXN) return ADMPC_EINVAL;
+    const int N = c->N;
+    Workspace* W = (Workspace*)malloc(sizeof(Workspace));
+    if (!W) return ADMPC_ENOMEM;
+    build_qp(c, W, x0, yref, yref_e, p, xbar, ubar);
+    IpmState* s = &W->st;
+    for (int k = 0; k < N; ++k) {
+        const double* t = ineq + (size_t)k * 20; const double* l = t + 10;
+        for (int j = 0; j < NU; ++j) {
+            s->t[k][j][0] = (real)t[2 * j]; s->t[k][j][1] = (real)t[2 * j + 1]; s->t[k][j][2] = (real)t[6 + 2 * j]; s->t[k][j][3] = (real)t[7 + 2 * j];
+            s->lam[k][j][0] = (real)l[2 * j]; s->lam[k][j][1] = (real)l[2 * j + 1]; s->lam[k][j][2] = (real)l[6 + 2 * j]; s->lam[k][j][3] = (real)l[7 + 2 * j];
+        }
+        s->td[k][0] = (real)t[4]; s->td[k][1] = (real)t[5]; s->lamd[k][0] = (real)l[4]; s->lamd[k][1] = (real)l[5];
+    }
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < NX; ++i) W->pia[k][i] = (real)pi[(size_t)k * NX + i];
+    real r[4];
+    nlp_residuals(W, r);
+    for (int i = 0; i < 4; ++i) res[i] = (double)r[i];
+    free(W);
+    return ADMPC_OK;
 }

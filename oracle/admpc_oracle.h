@@ -43,6 +43,12 @@ int oracle_qp_debug(const AdmpcConfig* c,
                     double* du, double* dx, double* A, double* Bm, double* b,
                     double* lam_u, double* lam_d, double* sl, double* su, int32_t* iters);
 
+/* acados' four SQP stopping residuals (res_stat, res_eq, res_ineq, res_comp; restated from ocp_nlp_common.c:ocp_nlp_res_compute of the
+ * acados commit the reference pins) for one instance at the iterate (xbar, ubar) with multipliers in the record layout of
+ * include/admpc.h -- the checker of admpc_nlp_residuals_batch. */
+int oracle_nlp_residuals(const AdmpcConfig* c, const double* x0, const double* yref, const double* yref_e, double p,
+                         const double* xbar, const double* ubar, const double* pi, const double* ineq, double* res);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

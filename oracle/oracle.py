@@ -52,6 +52,8 @@ class Oracle:
         L.oracle_solve_batch.restype = C.c_int
         L.oracle_qp_debug.argtypes = [cp, _dp, _dp, _dp, C.c_double, _dp, _dp] + [_dp] * 9 + [_ip]
         L.oracle_qp_debug.restype = C.c_int
+        L.oracle_nlp_residuals.argtypes = [cp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_nlp_residuals.restype = C.c_int
         L.oracle_shift_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, C.c_int]
         L.oracle_shift_batch.restype = C.c_int
         L.oracle_max_threads.restype = C.c_int
@@ -121,6 +123,16 @@ class Oracle:
                                       C.byref(it))
         out["status"] = st; out["iters"] = it.value
         return out
+
+    def nlp_residuals(self, cfg, x0, yref, yref_e, p, xbar, ubar, pi, ineq):
+        """(res_stat, res_eq, res_ineq, res_comp) of one instance (acados' SQP stopping test; record layout of include/admpc.h)."""
+        a = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+        x0, yref, yref_e, xbar, ubar, pi, ineq = map(a, (x0, yref, yref_e, xbar, ubar, pi, ineq))
+        res = np.empty(4)
+        rc = self.lib.oracle_nlp_residuals(C.byref(cfg), _ptr(x0), _ptr(yref), _ptr(yref_e), float(p), _ptr(xbar), _ptr(ubar), _ptr(pi), _ptr(ineq), _ptr(res))
+        if rc != 0:
+            raise RuntimeError("oracle_nlp_residuals: %d" % rc)
+        return res
 
 
 class RefModel:

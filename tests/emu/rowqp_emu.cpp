@@ -138,8 +138,8 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
                 for (auto& v : lds) v = std::nan("");            // the second launch finds nothing in LDS; workspace and dump persist
                 RowQp<X> S2(q, io, L, X::isplat(b), X::mtrue());
                 S2.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 2);
-                typename X::M failed2 = res.failed; typename X::V J2; typename X::M conv2;
-                S2.finish(X::mtrue(), failed2, J2, conv2);
+                typename X::M failed2 = res.failed; typename X::V J2;
+                S2.finish(X::mtrue(), failed2, J2);
                 status[b] = failed2.v[0] ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
                 iters[b] = res.iters.v[0];
                 cost[b] = failed2.v[0] ? (T)INFINITY : J2.v[0];
@@ -150,8 +150,7 @@ int emu_solve(const AdmpcConfig* cfg, int B, const T* x0, const T* yref, const T
         S.solve(X::mtrue(), res, pi != nullptr, X::mtrue(), 0);
         typename X::M failed = res.failed;
         typename X::V J;
-        typename X::M conv;
-        S.finish(X::mtrue(), failed, J, conv);
+        S.finish(X::mtrue(), failed, J);
         status[b] = failed.v[0] ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
         iters[b] = res.iters.v[0];
         cost[b] = failed.v[0] ? (T)INFINITY : J.v[0];

@@ -88,3 +88,35 @@ def kkt_residuals_from_multipliers(cfg, x0, yref, yref_e, xbar, ubar, A, B, phi,
     res["comp"] = np.abs(lam * t)[1:].max(initial=0.0) if N > 1 else 0.0
     res["comp"] = max(res["comp"], np.abs(lam[0, [0, 1, 2, 3, 6, 7, 8, 9]] * t[0, [0, 1, 2, 3, 6, 7, 8, 9]]).max())
     return res
+
+
+def nlp_residuals_numpy(cfg, x0, yref, yref_e, xbar, ubar, A, B, phi, pi, ineq):
+    """acados' four SQP stopping residuals (res_stat, res_eq, res_ineq, res_comp: inf-norms of the rows of the NLP's KKT system) at the
+    iterate (xbar, ubar), written out independently of the C restatement: A, B, phi = linearisation AT that iterate, pi [N+1,7] and ineq
+    [N,20] in the record order of include/admpc.h.  The slack variables are read from the slacks of their own bounds (t[6..9])."""
+    N = cfg.N
+    Ts = cfg.Ts
+    W = np.array(cfg.W[:]); We = np.array(cfg.We[:])
+    Q = Ts * W[:NX]; R = Ts * W[NX:]
+    rho_l, rho_u = Ts * cfg.zl, Ts * cfg.zu
+    lbu = np.array(cfg.lbu[:]); ubu = np.array(cfg.ubu[:])
+    t, lam = ineq[:, :10], ineq[:, 10:]
+    stat = [np.abs(We * (xbar[N] - yref_e) - pi[N - 1]).max()]
+    ineq_r, comp = [], []
+    for k in range(N):
+        g = Q * (xbar[k] - yref[k, :NX]) + A[k].T @ pi[k] - (pi[k - 1] if k >= 1 else pi[N])
+        if k >= 1:
+            g[6] += -lam[k, 4] + lam[k, 5]
+        gu = R * (ubar[k] - yref[k, NX:]) + B[k].T @ pi[k]
+        gu[0] += -lam[k, 0] + lam[k, 1]; gu[1] += -lam[k, 2] + lam[k, 3]
+        gs = [rho_l - lam[k, 0] - lam[k, 6], rho_u - lam[k, 1] - lam[k, 7], rho_l - lam[k, 2] - lam[k, 8], rho_u - lam[k, 3] - lam[k, 9]]
+        stat.append(max(np.abs(g).max(), np.abs(gu).max(), np.abs(gs).max()))
+        for j in range(NU):
+            ineq_r += [ubar[k, j] + t[k, 6 + 2 * j] - lbu[j] - t[k, 2 * j], ubu[j] - ubar[k, j] + t[k, 7 + 2 * j] - t[k, 2 * j + 1]]
+        idx = [0, 1, 2, 3, 6, 7, 8, 9]
+        if k >= 1:
+            ineq_r += [xbar[k, 6] - cfg.lbx_delta - t[k, 4], cfg.ubx_delta - xbar[k, 6] - t[k, 5]]
+            idx += [4, 5]
+        comp.append(np.abs(lam[k, idx] * t[k, idx]).max())
+    eq = max(np.abs(phi - xbar[1:]).max(), np.abs(x0 - xbar[0]).max())
+    return np.array([max(stat), eq, np.abs(ineq_r).max(), max(comp)])

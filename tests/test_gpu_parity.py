@@ -772,8 +772,8 @@ def test_two_level_argmin_through_a_process_group(gpu_engine_factory):
 
 @pytest.mark.parametrize("N", [20, 40])
 def test_sqp_mode_stops_on_tolerance(gpu_engine_factory, oracle, N):
-    """cfg.sqp_tol on the device (condensed pipeline at N = 20, kernel R at N = 40): per-instance stop inside one
-    admpc_solve_batch call, same statuses as the oracle (0 converged, 2 at the step limit, 4 failed), same iterates."""
+    """cfg.sqp_tol on the device (acados' residual test in front of every QP but the first; kernel R at both horizons): per-instance
+    stop inside one admpc_solve_batch call, same statuses as the oracle (0 converged, 2 at the step limit, 4 failed), same iterates."""
     s = random_scenarios(48, N=N, seed=11, blend=(3.0, 5.0))
     bad = random_scenarios(4, N=N, seed=3, blend=(3.0, 5.0), init="zeros")          # non-finite model: status 4 in the first step
     s = {k: np.concatenate([s[k][:20], bad[k], s[k][20:]]) for k in s}
@@ -793,6 +793,53 @@ def test_sqp_mode_stops_on_tolerance(gpu_engine_factory, oracle, N):
         np.testing.assert_array_equal(g[0][first], s["xbar"][first])
         if N == 20:
             assert first.sum() == (~okm).sum() == 4
+
+
+@pytest.mark.parametrize("N", [20, 40])
+def test_nlp_residuals_on_the_device_and_the_sqp_stop(gpu_engine_factory, oracle, N):
+    """acados' SQP stopping test on the device (admpc_nlp_res_kernel behind admpc_nlp_residuals_batch and inside every SQP solve with a
+    tolerance).  (a) After one RTI step the four residuals the device forms at the NEW iterate with the multipliers it returned equal
+    the oracle's restatement on the same data, and an independent numpy statement with the device's own shooting; the dynamics rows
+    really are non-zero there (the linearisation moved).  (b) A solve with sqp_tol stops exactly when they are within tolerance:
+    status 0 <=> all four <= sqp_tol at the returned iterate with the returned multipliers; at the step limit (status 2) at least
+    one is above."""
+    import torch
+    from kkt_check import nlp_residuals_numpy
+    B = 64
+    s = random_scenarios(B, N=N, seed=21, blend=(3.0, 5.0))
+    cfg = default_config(N=N)
+    eng = gpu_engine_factory(cfg)
+    d = eng.to_device
+    args = [d(s[k]) for k in ("x0", "yref", "yref_e", "p")]
+    xb, ub = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+    st = torch.empty(B, dtype=torch.int32, device=eng.device)
+    pi, ineq = eng.solve_with_multipliers(*args, xb, ub, None, st, None)
+    res = eng.nlp_residuals(*args, xb, ub, pi, ineq)
+    phi, A, Bm = eng.shoot(xb, ub, args[3])
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all()
+    res, xn, un, pin, iqn, phi, A, Bm = (t.cpu().numpy() for t in (res, xb, ub, pi, ineq, phi, A, Bm))
+    for i in range(B):
+        want = oracle.nlp_residuals(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], s["p"][i], xn[i], un[i], pin[i], iqn[i])
+        assert np.all(np.abs(res[i] - want) <= 1e-9 * (1.0 + np.abs(want))), (i, res[i], want)
+        if i < 8:
+            ind = nlp_residuals_numpy(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], xn[i], un[i], A[i], Bm[i], phi[i], pin[i], iqn[i])
+            assert np.all(np.abs(res[i] - ind) <= 1e-9 * (1.0 + np.abs(ind))), (i, res[i], ind)
+    assert np.median(res[:, 0]) > 1e-6 and np.median(res[:, 1]) > 1e-6 and res[:, 2].max() <= 1e-7 and res[:, 3].max() <= 1e-7
+    for iters, want_status in ((30, 0), (2, 2)):
+        cfg2 = default_config(N=N, sqp_iters=iters, sqp_tol=1e-6)
+        eng2 = gpu_engine_factory(cfg2)
+        xb, ub = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+        pi, ineq = eng2.solve_with_multipliers(*args, xb, ub, None, st, None)
+        res = eng2.nlp_residuals(*args, xb, ub, pi, ineq)
+        torch.cuda.synchronize()
+        stn, res = st.cpu().numpy(), res.cpu().numpy()
+        ok = np.abs(xb.cpu().numpy()).max(axis=(1, 2)) < 1e3            # full Newton steps without a line search may diverge
+        assert ok.sum() >= B - 8 and (stn[ok] == want_status).sum() >= ok.sum() - 4, (iters, np.unique(stn, return_counts=True))
+        conv = res.max(axis=1) <= 1e-6
+        assert conv[stn == 0].all()                                      # stopped <=> the test passed at the returned iterate
+        if want_status == 2:
+            assert (~conv[ok]).sum() >= ok.sum() - 4                     # two QPs do not get there (the last iterate is never tested: acados' loop)
 
 
 def test_argmin_global_through_the_c_abi_with_an_rccl_communicator(gpu_engine_factory):

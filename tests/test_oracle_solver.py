@@ -139,9 +139,9 @@ def test_zero_iterate_with_dynamic_branch_reports_qp_failure(oracle):
 
 
 def test_sqp_mode_stops_on_tolerance_and_reports_maxiter(oracle, golden_kat):
-    """cfg.sqp_tol (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): a cold-started SQP with a step / defect tolerance stops
-    at the reference's acados iterate with status 0; with too few steps allowed it returns status 2 (acados MAXITER), a finite cost
-    and its last iterate; sqp_tol = 0 keeps the fixed step count."""
+    """cfg.sqp_tol (reference solver_type "SQP", create_ros_ad_mpc.py:47-51): a cold-started SQP with acados' residual test at acados'
+    default tolerances (1e-6) stops at the reference's acados iterate with status 0; with too few steps allowed it returns status 2
+    (acados MAXITER), a finite cost and its last iterate; sqp_tol = 0 keeps the fixed step count."""
     k = golden_kat
     N = k["N"]
     X, U = np.array(k["X"]), np.array(k["U"])
@@ -202,3 +202,23 @@ def _mid_rti_statement(solve, k):
 def test_second_stored_iterate_dynamic_branch(oracle, golden_kat_mid_rti):
     """Second solver pin (weaker than the converged fixture): the oracle against the reference's mid-RTI acados iterate."""
     _mid_rti_statement(lambda cfg, *a: oracle.solve_batch(cfg, *a), golden_kat_mid_rti)
+
+
+def test_nlp_residuals_restatement_against_an_independent_numpy_statement(oracle):
+    """acados' four stopping residuals (oracle_nlp_residuals, the checker of the device's admpc_nlp_res_kernel) against the same rows
+    written out in numpy (tests/kkt_check.py) on random iterates with random multipliers: the function is a formula, any input pins it."""
+    from kkt_check import nlp_residuals_numpy
+    rng = np.random.default_rng(5)
+    for N in (2, 7, 20, 40):
+        cfg = default_config(N=N)
+        s = random_scenarios(3, N=N, seed=40 + N, blend=(3.0, 5.0))
+        for i in range(3):
+            xb = s["xbar"][i] + 0.05 * rng.standard_normal((N + 1, 7)); ub = s["ubar"][i] + 0.1 * rng.standard_normal((N, 2))
+            pi = rng.standard_normal((N + 1, 7)) * 3.0
+            ineq = np.abs(rng.standard_normal((N, 20))) + 0.01
+            lin = [oracle.rk4_sens(cfg, xb[k], ub[k], s["p"][i], cfg.Ts) for k in range(N)]
+            phi = np.array([l[0] for l in lin]); A = np.array([l[1] for l in lin]); Bm = np.array([l[2] for l in lin])
+            want = nlp_residuals_numpy(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], xb, ub, A, Bm, phi, pi, ineq)
+            got = oracle.nlp_residuals(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], s["p"][i], xb, ub, pi, ineq)
+            assert np.all(np.abs(got - want) <= 1e-12 * (1.0 + np.abs(want))), (N, i, got, want)
+            assert np.all(want > 1e-3)                              # every one of the four is exercised
