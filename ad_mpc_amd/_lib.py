@@ -16,7 +16,8 @@ EXPORTS = (
     "admpc_default_config", "admpc_create", "admpc_destroy", "admpc_reserve", "admpc_solve_batch", "admpc_solve_batch_ex", "admpc_nlp_residuals_batch", "admpc_solve_batch_f32", "admpc_shoot_batch",
     "admpc_argmin", "admpc_argmin_pairs", "admpc_argmin_pairs_host", "admpc_argmin_global", "admpc_select_cluster_batch", "admpc_solve_batch_routed", "admpc_shift_batch", "admpc_epilogue_batch", "admpc_actuation_batch", "admpc_resample_vel_batch", "admpc_waypoints_batch", "admpc_last_error", "admpc_version",
 )
-QUAD_EXPORTS = ("admpc_quad_default_config", "admpc_quad_create", "admpc_quad_destroy", "admpc_quad_solve_batch", "admpc_quad_shoot_batch")   # include/admpc_quad.h
+QUAD_EXPORTS = ("admpc_quad_default_config", "admpc_quad_create", "admpc_quad_destroy", "admpc_quad_solve_batch", "admpc_quad_solve_batch_ex", "admpc_quad_select_cluster_batch",
+                "admpc_quad_solve_batch_routed", "admpc_quad_shoot_batch", "admpc_quad_shoot_batch_ex")   # include/admpc_quad.h
 
 _lib = None
 
@@ -67,6 +68,10 @@ def load():
     L.admpc_quad_destroy.argtypes = [C.c_void_p]; L.admpc_quad_destroy.restype = None
     L.admpc_quad_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, ip, ip, vp]; L.admpc_quad_solve_batch.restype = C.c_int
     L.admpc_quad_shoot_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, vp]; L.admpc_quad_shoot_batch.restype = C.c_int
+    L.admpc_quad_solve_batch_ex.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]; L.admpc_quad_solve_batch_ex.restype = C.c_int
+    L.admpc_quad_shoot_batch_ex.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, vp]; L.admpc_quad_shoot_batch_ex.restype = C.c_int
+    L.admpc_quad_select_cluster_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), dp, dp, C.c_int, dp, ip, vp]; L.admpc_quad_select_cluster_batch.restype = C.c_int
+    L.admpc_quad_solve_batch_routed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, ip, dp, dp, dp, dp, dp, dp, dp, ip, ip, vp]; L.admpc_quad_solve_batch_routed.restype = C.c_int
     L.admpc_last_error.restype = C.c_char_p
     L.admpc_version.restype = C.c_char_p
     _lib = L

@@ -44,21 +44,45 @@ constexpr int QX = ADMPC_QUAD_NX, QU = ADMPC_QUAD_NU, QY = ADMPC_QUAD_NY;
 typedef AdmpcQuadConfig Cfg;
 
 // f(x, u) and df = Jx sx + Ju su   (oracle/quad_oracle.c:quad_f_tan, same expressions)
+// rotation matrix of a quaternion and its directional derivative along sq (utils.py:323-338)
+__device__ __forceinline__ void quad_rot(double qw, double qx, double qy, double qz, double (&R)[3][3]) {
+    R[0][0] = 1 - 2 * (qy * qy + qz * qz); R[0][1] = 2 * (qx * qy - qw * qz); R[0][2] = 2 * (qx * qz + qw * qy);
+    R[1][0] = 2 * (qx * qy + qw * qz); R[1][1] = 1 - 2 * (qx * qx + qz * qz); R[1][2] = 2 * (qy * qz - qw * qx);
+    R[2][0] = 2 * (qx * qz - qw * qy); R[2][1] = 2 * (qy * qz + qw * qx); R[2][2] = 1 - 2 * (qx * qx + qy * qy);
+}
+__device__ __forceinline__ void quad_drot(double qw, double qx, double qy, double qz, double sw, double sxx, double sy, double sz, double (&D)[3][3]) {
+    D[0][0] = -4 * (qy * sy + qz * sz); D[0][1] = 2 * (sxx * qy + qx * sy - sw * qz - qw * sz); D[0][2] = 2 * (sxx * qz + qx * sz + sw * qy + qw * sy);
+    D[1][0] = 2 * (sxx * qy + qx * sy + sw * qz + qw * sz); D[1][1] = -4 * (qx * sxx + qz * sz); D[1][2] = 2 * (sy * qz + qy * sz - sw * qx - qw * sxx);
+    D[2][0] = 2 * (sxx * qz + qx * sz - sw * qy - qw * sy); D[2][1] = 2 * (sy * qz + qy * sz + sw * qx + qw * sxx); D[2][2] = -4 * (qx * sxx + qy * sy);
+}
+
+// trig / gq: the first node's GP-state parameter (quad_3d_optimizer.py:291-297, :546-552; oracle: gpx).  On lanes with trig set the GP
+// features and the rotation of the means come from the constant state gq[13] (zero tangent along sx), elsewhere from x.  gq must be
+// readable on every lane when c->n_gp > 0.
 __device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const double* x, const double* u, const double* sx, const double* su,
-                                           double* f, double* df)
+                                           bool trig, const double* __restrict__ gq, double* f, double* df)
 {
     const double qw = x[3], qx = x[4], qy = x[5], qz = x[6], r0 = x[10], r1 = x[11], r2 = x[12];
     const double sw = sx[3], sxx = sx[4], sy = sx[5], sz = sx[6], t0 = sx[10], t1 = sx[11], t2 = sx[12];
-    double ga[3] = { 0, 0, 0 }, dga[3] = { 0, 0, 0 };        // GP residual of the acceleration, evaluated first (shorter live ranges)
+    double ga[3] = { 0, 0, 0 }, dga[3] = { 0, 0, 0 };        // GP residual and drag term of the acceleration, evaluated first (shorter live ranges)
     if (c->n_gp > 0) {                       // wave-uniform.  GP residual: v' += R(q) mu(z), z = [x with v in the body frame; u]
-        const double R[3][3] = { { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy) },
-                                 { 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx) },
-                                 { 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy) } };
-        // dR = directional derivative of R along sq, formed where it is used (twice) instead of kept live across the GP loop
+        // the state the features and the rotation come from: entries 3..12 (attitude, velocity, body rates) of x or of the parameter
+        double xe[10], se[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            double gv = gq[3 + i];
+            asm volatile("" : "+v"(gv));      // a value, not an address: otherwise the select becomes `load (trig ? gq : &x)` with x spilled to scratch for it
+            xe[i] = trig ? gv : x[3 + i]; se[i] = trig ? 0.0 : sx[3 + i];
+        }
+        const double ew = xe[0], ex = xe[1], ey = xe[2], ez = xe[3], fw = se[0], fx = se[1], fy = se[2], fz = se[3];
+        const double R[3][3] = { { 1 - 2 * (ey * ey + ez * ez), 2 * (ex * ey - ew * ez), 2 * (ex * ez + ew * ey) },
+                                 { 2 * (ex * ey + ew * ez), 1 - 2 * (ex * ex + ez * ez), 2 * (ey * ez - ew * ex) },
+                                 { 2 * (ex * ez - ew * ey), 2 * (ey * ez + ew * ex), 1 - 2 * (ex * ex + ey * ey) } };
+        // dR = directional derivative of R, formed where it is used (twice) instead of kept live across the GP loop
         auto dRm = [&](double (&D)[3][3]) {
-            D[0][0] = -4 * (qy * sy + qz * sz); D[0][1] = 2 * (sxx * qy + qx * sy - sw * qz - qw * sz); D[0][2] = 2 * (sxx * qz + qx * sz + sw * qy + qw * sy);
-            D[1][0] = 2 * (sxx * qy + qx * sy + sw * qz + qw * sz); D[1][1] = -4 * (qx * sxx + qz * sz); D[1][2] = 2 * (sy * qz + qy * sz - sw * qx - qw * sxx);
-            D[2][0] = 2 * (sxx * qz + qx * sz - sw * qy - qw * sy); D[2][1] = 2 * (sy * qz + qy * sz + sw * qx + qw * sxx); D[2][2] = -4 * (qx * sxx + qy * sy);
+            D[0][0] = -4 * (ey * fy + ez * fz); D[0][1] = 2 * (fx * ey + ex * fy - fw * ez - ew * fz); D[0][2] = 2 * (fx * ez + ex * fz + fw * ey + ew * fy);
+            D[1][0] = 2 * (fx * ey + ex * fy + fw * ez + ew * fz); D[1][1] = -4 * (ex * fx + ez * fz); D[1][2] = 2 * (fy * ez + ey * fz - fw * ex - ew * fx);
+            D[2][0] = 2 * (fx * ez + ex * fz - fw * ey - ew * fy); D[2][1] = 2 * (fy * ez + ey * fz + fw * ex + ew * fx); D[2][2] = -4 * (ex * fx + ey * fy);
         };
         // candidate features: entries 7..16 of z (body-frame velocity, body rates, inputs); position and attitude are not offered
         double z[10], dz[10];
@@ -67,9 +91,9 @@ __device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const doub
         for (int i = 0; i < 3; ++i) {
             double a2 = 0, d2 = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { a2 += R[k][i] * x[7 + k]; d2 += dR[k][i] * x[7 + k] + R[k][i] * sx[7 + k]; }
+            for (int k = 0; k < 3; ++k) { a2 += R[k][i] * xe[4 + k]; d2 += dR[k][i] * xe[4 + k] + R[k][i] * se[4 + k]; }
             z[i] = a2; dz[i] = d2;
-            z[3 + i] = x[10 + i]; dz[3 + i] = sx[10 + i];
+            z[3 + i] = xe[7 + i]; dz[3 + i] = se[7 + i];
         } }
 #pragma unroll
         for (int m = 0; m < QU; ++m) { z[6 + m] = u[m]; dz[6 + m] = su[m]; }
@@ -107,6 +131,29 @@ __device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const doub
             ga[i] = a2; dga[i] = d2;
         }
     }
+    if (c->rdrv[0] != 0.0 || c->rdrv[1] != 0.0 || c->rdrv[2] != 0.0) {      // wave-uniform.  Linear rotor drag (:364-381): v' += R(q) D R(q)' v
+        const double R[3][3] = { { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy) },
+                                 { 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx) },
+                                 { 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy) } };
+        const double dR[3][3] = { { -4 * (qy * sy + qz * sz), 2 * (sxx * qy + qx * sy - sw * qz - qw * sz), 2 * (sxx * qz + qx * sz + sw * qy + qw * sy) },
+                                  { 2 * (sxx * qy + qx * sy + sw * qz + qw * sz), -4 * (qx * sxx + qz * sz), 2 * (sy * qz + qy * sz - sw * qx - qw * sxx) },
+                                  { 2 * (sxx * qz + qx * sz - sw * qy - qw * sy), 2 * (sy * qz + qy * sz + sw * qx + qw * sxx), -4 * (qx * sxx + qy * sy) } };
+        double wb[3], dwb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a2 = 0, d2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a2 += R[k][i] * x[7 + k]; d2 += dR[k][i] * x[7 + k] + R[k][i] * sx[7 + k]; }
+            wb[i] = c->rdrv[i] * a2; dwb[i] = c->rdrv[i] * d2;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a2 = 0, d2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a2 += R[i][k] * wb[k]; d2 += dR[i][k] * wb[k] + R[i][k] * dwb[k]; }
+            ga[i] += a2; dga[i] += d2;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { f[i] = x[7 + i]; df[i] = sx[7 + i]; }
     f[3] = 0.5 * (-r0 * qx - r1 * qy - r2 * qz);
@@ -140,7 +187,7 @@ __device__ __forceinline__ void quad_f_tan(const Cfg* __restrict__ c, const doub
 }
 
 // classic RK4, one step of length h: the state and ONE sensitivity column (col < 13: d/dx_col, else d/du_(col-13))
-__device__ __forceinline__ void rk4_col(const Cfg* __restrict__ c, const double* x, const double* u, double h, int col, double* phi, double* scol)
+__device__ __forceinline__ void rk4_col(const Cfg* __restrict__ c, const double* x, const double* u, bool trig, const double* __restrict__ gq, double h, int col, double* phi, double* scol)
 {
     const double cs[4] = { 0, 0.5, 0.5, 1.0 }, ws[4] = { 1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6 };
     double kx[QX], ks[QX], ax[QX], as[QX], su[QU];
@@ -153,7 +200,7 @@ __device__ __forceinline__ void rk4_col(const Cfg* __restrict__ c, const double*
         double X[QX], S[QX], f[QX], df[QX];
 #pragma unroll
         for (int i = 0; i < QX; ++i) { X[i] = x[i] + cs[s] * h * kx[i]; S[i] = (col == i ? 1.0 : 0.0) + cs[s] * h * ks[i]; }
-        quad_f_tan(c, X, u, S, su, f, df);
+        quad_f_tan(c, X, u, S, su, trig, gq, f, df);
 #pragma unroll
         for (int i = 0; i < QX; ++i) { kx[i] = f[i]; ks[i] = df[i]; ax[i] += ws[s] * f[i]; as[i] += ws[s] * df[i]; }
     }
@@ -190,7 +237,8 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 __device__ __forceinline__ int sym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
 __host__ __device__ inline int quad_lds_doubles(int N) { const int n = N * QU; return N * (QX * QX + QX * QU + QX) + n * (n + 1) + QX * n + 64 + 2 * (N + 1) * QX + N * QY + QX + QX + 2 * QX; }
 
-__device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const Lds& L, int lane, double* phi_out, int nt = 64)
+// gq: GP state of the first node (instance's x0 or the caller's gp_state); only read when the model carries GPs
+__device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, const double* ub, const double* __restrict__ gq, const Lds& L, int lane, double* phi_out, int nt = 64)
 {
     const int N = c->N;
     for (int t = lane; t < N * (QX + QU); t += nt) {
@@ -200,7 +248,7 @@ __device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, cons
         for (int i = 0; i < QX; ++i) x[i] = xb[k * QX + i];
 #pragma unroll
         for (int m = 0; m < QU; ++m) u[m] = ub[k * QU + m];
-        rk4_col(c, x, u, c->Ts, col, phi, sc);
+        rk4_col(c, x, u, k == 0, gq, c->Ts, col, phi, sc);
 #pragma unroll
         for (int i = 0; i < QX; ++i) {
             if (col < QX) L.A[(k * QX + i) * QX + col] = sc[i]; else L.B[(k * QX + i) * QU + (col - QX)] = sc[i];
@@ -211,13 +259,14 @@ __device__ void shoot_instance(const Cfg* __restrict__ c, const double* xb, cons
 }
 
 __global__ __launch_bounds__(64) void admpc_quad_shoot_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ xbarg, const double* __restrict__ ubarg,
-                                                             double* __restrict__ phig, double* __restrict__ Ag, double* __restrict__ Bg)
+                                                             const double* __restrict__ gpsg, double* __restrict__ phig, double* __restrict__ Ag, double* __restrict__ Bg)
 {
     extern __shared__ double lds_raw[];
     const int N = c->N, lane = threadIdx.x;
     Lds L(lds_raw, N);
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
-        shoot_instance(c, xbarg + (size_t)inst * (N + 1) * QX, ubarg + (size_t)inst * N * QU, L, lane, phig + (size_t)inst * N * QX);
+        shoot_instance(c, xbarg + (size_t)inst * (N + 1) * QX, ubarg + (size_t)inst * N * QU,
+                       gpsg ? gpsg + (size_t)inst * QX : xbarg + (size_t)inst * (N + 1) * QX, L, lane, phig + (size_t)inst * N * QX);
         for (int i = lane; i < N * QX * QX; i += 64) Ag[(size_t)inst * N * QX * QX + i] = L.A[i];
         for (int i = lane; i < N * QX * QU; i += 64) Bg[(size_t)inst * N * QX * QU + i] = L.B[i];
         __syncthreads();
@@ -230,7 +279,7 @@ template <bool FAST>
 __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                              const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                              double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
-                                                             int* __restrict__ ticket)
+                                                             int* __restrict__ ticket, const double* __restrict__ gpsg, const int32_t* __restrict__ routeg, int which)
 {
     extern __shared__ double lds_raw[];
     const int N = c->N, n = N * QU, lane = threadIdx.x;
@@ -248,17 +297,27 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
     QDECL();
     // instances need 5 .. 18 interior-point iterations: with many rounds per wave the instances are drawn from a work counter (zeroed by
     // the host before the launch; + 5 % at B = 16384), with few a static stride is cheaper (no memset node, no atomics; + 5 % at B = 4096)
+    // next instance of this wave: from the work counter (many rounds) or by a static stride
+    auto next_inst = [&](int inst) -> int {
+        if (!ticket) return inst + (int)gridDim.x;
+        int tk = 0;
+        if (lane == 0) tk = atomicAdd(ticket, 1);
+        return (int)gridDim.x + __builtin_amdgcn_readfirstlane(tk);
+    };
     for (int inst = blockIdx.x; inst < B;) {
+        // routed solve (admpc_quad_solve_batch_routed): this handle carries the model of cluster `which`; the others' instances are left alone
+        if (routeg && routeg[inst] != which) { inst = next_inst(inst); continue; }
         double* xb = xbarg + (size_t)inst * (N + 1) * QX;
         double* ub = ubarg + (size_t)inst * N * QU;
         const double* yr = yrefg + (size_t)inst * N * QY;
         const double* ye = yrefeg + (size_t)inst * QX;
         const double* x0 = x0g + (size_t)inst * QX;
+        const double* gq = gpsg ? gpsg + (size_t)inst * QX : x0;       // GP state of the first node: run_optimization's default is the initial state
         QSTART();
         for (int i = lane; i < (N + 1) * QX; i += 64) L.xbs[i] = xb[i];
         for (int i = lane; i < N * QY + QX; i += 64) L.yrs[i] = i < N * QY ? yr[i] : ye[i - N * QY];
         // ---- 1. shooting
-        shoot_instance(c, xb, ub, L, lane, nullptr);
+        shoot_instance(c, xb, ub, gq, L, lane, nullptr);
         QSTAMP(0);
         // ---- 2. condensing (oracle: condense)
         if constexpr (!FAST) { for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0; }
@@ -509,11 +568,7 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
             if (itersg) itersg[inst] = it;
         }
         __syncthreads();
-        if (ticket) {                                                // many rounds: the next instance from the work counter
-            int tk = 0;
-            if (lane == 0) tk = atomicAdd(ticket, 1);
-            inst = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tk);
-        } else inst += (int)gridDim.x;
+        inst = next_inst(inst);
     }
     QFLUSH();
 }
@@ -539,7 +594,7 @@ __device__ __forceinline__ double qw_min(double v, const WideRed& R, int tid) {
 __global__ __launch_bounds__(QW_NT) void admpc_quad_solve_wide_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                                       const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                                       double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
-                                                                      int* __restrict__ ticket)
+                                                                      int* __restrict__ ticket, const double* __restrict__ gpsg, const int32_t* __restrict__ routeg, int which)
 {
     extern __shared__ double lds_raw[];
     const int N = c->N, n = N * QU, tid = threadIdx.x;
@@ -553,15 +608,25 @@ __global__ __launch_bounds__(QW_NT) void admpc_quad_solve_wide_kernel(const Cfg*
     const double Rw = Ts * c->W[QX + mi], lbm = c->lbu[mi], ubm = c->ubu[mi];
     const double thr0 = c->ipm_thr0, mu0 = c->ipm_mu0, tolc = c->ipm_tol_comp, tolr = c->ipm_tol_res;
     const int itmax = c->ipm_iter_max;
+    auto next_inst = [&](int inst) -> int {                          // block-uniform: the draw of thread 0 through an LDS slot
+        if (!ticket) return inst + (int)gridDim.x;
+        if (tid == 0) R.red[0] = (double)atomicAdd(ticket, 1);
+        __syncthreads();
+        const int nx = (int)gridDim.x + (int)R.red[0];
+        __syncthreads();
+        return nx;
+    };
     for (int inst = blockIdx.x; inst < B;) {
+        if (routeg && routeg[inst] != which) { inst = next_inst(inst); continue; }      // routed solve: another cluster's instance
         double* xb = xbarg + (size_t)inst * (N + 1) * QX;
         double* ub = ubarg + (size_t)inst * N * QU;
         const double* yr = yrefg + (size_t)inst * N * QY;
         const double* ye = yrefeg + (size_t)inst * QX;
         const double* x0 = x0g + (size_t)inst * QX;
+        const double* gq = gpsg ? gpsg + (size_t)inst * QX : x0;
         for (int i = tid; i < (N + 1) * QX; i += QW_NT) L.xbs[i] = xb[i];
         for (int i = tid; i < N * QY + QX; i += QW_NT) L.yrs[i] = i < N * QY ? yr[i] : ye[i - N * QY];
-        shoot_instance(c, xb, ub, L, tid, nullptr, QW_NT);
+        shoot_instance(c, xb, ub, gq, L, tid, nullptr, QW_NT);
         // ---- condensing (oracle: condense)
         for (int j = 0; j <= li; ++j) if (act) L.H[tri(li, j)] = 0.0;
         double g[QX];
@@ -755,13 +820,56 @@ __global__ __launch_bounds__(QW_NT) void admpc_quad_solve_wide_kernel(const Cfg*
             if (itersg) itersg[inst] = it;
         }
         __syncthreads();
-        if (ticket) {
-            if (tid == 0) R.red[0] = (double)atomicAdd(ticket, 1);
-            __syncthreads();
-            inst = (int)gridDim.x + (int)R.red[0];
-            __syncthreads();
-        } else inst += (int)gridDim.x;
+        inst = next_inst(inst);
     }
+}
+
+// Cluster of an instance (the reference keeps one acados solver per GP cluster, quad_3d_optimizer.py:207, and picks one per solve from
+// the reference state: set_reference_state / set_reference_trajectory :446-452, :485-491 -> gp.py:738-770 select_gp): nearest centroid in
+// the selected features of z = [x with the velocity in the BODY frame; u], Euclidean distance, ties to the lower index (numpy.argmin).
+// x_sel [B][13] (world-frame velocity: the rotation happens here), u_sel [B][4].  One thread per instance.
+__global__ void admpc_quad_select_cluster_kernel(int B, int d, int f0, int f1, int f2, const double* __restrict__ xs, const double* __restrict__ us,
+                                                 int K, const double* __restrict__ cent, int32_t* __restrict__ route)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* x = xs + (size_t)b * QX;
+    double R[3][3];
+    quad_rot(x[3], x[4], x[5], x[6], R);
+    double zz[QY];
+#pragma unroll
+    for (int i = 0; i < QX; ++i) zz[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) zz[7 + i] = R[0][i] * x[7] + R[1][i] * x[8] + R[2][i] * x[9];        // v_b = R' v
+#pragma unroll
+    for (int m = 0; m < QU; ++m) zz[QX + m] = us[(size_t)b * QU + m];
+    const int f[3] = { f0, f1, f2 };
+    double z[3] = { 0, 0, 0 };
+    for (int j = 0; j < d; ++j) {
+        double v = 0;
+#pragma unroll
+        for (int i = 0; i < QY; ++i) v = f[j] == i ? zz[i] : v;
+        z[j] = v;
+    }
+    double best = INFINITY; int bi = 0;
+    for (int c = 0; c < K; ++c) {
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) { const double e = z[j] - cent[c * d + j]; acc = acc + e * e; }
+        const double dist = __dsqrt_rn(acc);
+        if (dist < best) { best = dist; bi = c; }
+    }
+    route[b] = bi;
+}
+// routed solve: an instance whose route names no cluster fails (status 4, infinite cost) with its iterate untouched
+__global__ void admpc_quad_route_invalid_kernel(int B, const int32_t* __restrict__ route, int K, int32_t* __restrict__ status, double* __restrict__ cost,
+                                                int32_t* __restrict__ iters)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (route[b] >= 0 && route[b] < K) return;
+    if (status) status[b] = 4;
+    if (cost) cost[b] = INFINITY;
+    if (iters) iters[b] = 0;
 }
 
 }  // namespace
@@ -856,8 +964,25 @@ void admpc_quad_destroy(AdmpcQuadSolver* s)
     delete s;
 }
 
-int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e,
-                           double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
+static int quad_solve(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* gp_state,
+                      double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, const int32_t* route, int which, hipStream_t st)
+{
+    int per_cu = (160 * 1024) / s->lds_bytes; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    int grid = s->num_cu * per_cu; if (grid > B) grid = B;
+    int* ticket = B > 8 * grid ? s->d_ticket : nullptr;
+    if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), st) != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
+    if (s->cfg.N * QU > 64)          // horizons beyond 16: one thread per input, two waves per instance
+        hipLaunchKernelGGL(admpc_quad_solve_wide_kernel, dim3(grid), dim3(QW_NT), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
+    else if (s->cfg.N * QU == 40 && !s->generic)
+        hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
+    else
+        hipLaunchKernelGGL(admpc_quad_solve_kernel<false>, dim3(grid), dim3(64), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
+    if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad solve kernel launch failed");
+    return ADMPC_OK;
+}
+
+int admpc_quad_solve_batch_ex(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* gp_state,
+                              double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
 {
     if (!s) return admpc_set_error(ADMPC_EINVAL, "null solver");
     if (B < 0) return admpc_set_error(ADMPC_EINVAL, "negative batch");
@@ -865,21 +990,55 @@ int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const do
     if (!x0 || !yref || !yref_e || !xbar || !ubar) return admpc_set_error(ADMPC_EINVAL, "null array argument");
     QGuard guard(s->device);
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
-    int per_cu = (160 * 1024) / s->lds_bytes; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
-    int grid = s->num_cu * per_cu; if (grid > B) grid = B;
-    int* ticket = B > 8 * grid ? s->d_ticket : nullptr;
-    if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
-    if (s->cfg.N * QU > 64)          // horizons beyond 16: one thread per input, two waves per instance
-        hipLaunchKernelGGL(admpc_quad_solve_wide_kernel, dim3(grid), dim3(QW_NT), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
-    else if (s->cfg.N * QU == 40 && !s->generic)
-        hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
-    else
-        hipLaunchKernelGGL(admpc_quad_solve_kernel<false>, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket);
-    if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad solve kernel launch failed");
+    return quad_solve(s, B, x0, yref, yref_e, gp_state, xbar, ubar, cost, status, iters, nullptr, 0, (hipStream_t)stream);
+}
+
+int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e,
+                           double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
+{
+    return admpc_quad_solve_batch_ex(s, B, x0, yref, yref_e, nullptr, xbar, ubar, cost, status, iters, stream);
+}
+
+int admpc_quad_select_cluster_batch(int device, int B, int n_feat, const int32_t* feats, const double* x_sel, const double* u_sel,
+                                    int K, const double* centroids, int32_t* route, void* stream)
+{
+    if (B < 0 || n_feat < 1 || n_feat > ADMPC_GP_MAX_FEAT || !feats || K < 1) return admpc_set_error(ADMPC_EINVAL, "bad argument");
+    if (B == 0) return ADMPC_OK;
+    if (!x_sel || !u_sel || !centroids || !route) return admpc_set_error(ADMPC_EINVAL, "null array argument");
+    for (int j = 0; j < n_feat; ++j) if (feats[j] < 0 || feats[j] >= QY) return admpc_set_error(ADMPC_EINVAL, "feature index outside z = [x; u]");
+    QGuard guard(device);
+    if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(admpc_quad_select_cluster_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n_feat, feats[0], n_feat > 1 ? feats[1] : 0,
+                       n_feat > 2 ? feats[2] : 0, x_sel, u_sel, K, centroids, route);
+    if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad select kernel launch failed");
     return ADMPC_OK;
 }
 
-int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, double* phi, double* A, double* Bm, void* stream)
+int admpc_quad_solve_batch_routed(AdmpcQuadSolver* const* solvers, int K, int B, const int32_t* route,
+                                  const double* x0, const double* yref, const double* yref_e, const double* gp_state,
+                                  double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream)
+{
+    if (!solvers || K < 1) return admpc_set_error(ADMPC_EINVAL, "bad argument");
+    if (B < 0) return admpc_set_error(ADMPC_EINVAL, "negative batch");
+    if (B == 0) return ADMPC_OK;
+    if (!route || !x0 || !yref || !yref_e || !xbar || !ubar) return admpc_set_error(ADMPC_EINVAL, "null array argument");
+    for (int c = 0; c < K; ++c) {
+        if (!solvers[c]) return admpc_set_error(ADMPC_EINVAL, "null solver");
+        if (solvers[c]->device != solvers[0]->device || solvers[c]->cfg.N != solvers[0]->cfg.N) return admpc_set_error(ADMPC_EINVAL, "the cluster solvers must share device and horizon");
+    }
+    QGuard guard(solvers[0]->device);
+    if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(admpc_quad_route_invalid_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, route, K, status, cost, iters);
+    for (int c = 0; c < K; ++c) {
+        const int rc = quad_solve(solvers[c], B, x0, yref, yref_e, gp_state, xbar, ubar, cost, status, iters, route, c, st);
+        if (rc) return rc;
+    }
+    return ADMPC_OK;
+}
+
+int admpc_quad_shoot_batch_ex(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, const double* gp_state,
+                              double* phi, double* A, double* Bm, void* stream)
 {
     if (!s) return admpc_set_error(ADMPC_EINVAL, "null solver");
     if (B <= 0) return B == 0 ? ADMPC_OK : admpc_set_error(ADMPC_EINVAL, "negative batch");
@@ -887,9 +1046,14 @@ int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const 
     QGuard guard(s->device);
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
     int grid = s->num_cu * 2; if (grid > B) grid = B;
-    hipLaunchKernelGGL(admpc_quad_shoot_kernel, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, xbar, ubar, phi, A, Bm);
+    hipLaunchKernelGGL(admpc_quad_shoot_kernel, dim3(grid), dim3(64), s->lds_bytes, (hipStream_t)stream, s->d_cfg, B, xbar, ubar, gp_state, phi, A, Bm);
     if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad shoot kernel launch failed");
     return ADMPC_OK;
+}
+
+int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, double* phi, double* A, double* Bm, void* stream)
+{
+    return admpc_quad_shoot_batch_ex(s, B, xbar, ubar, nullptr, phi, A, Bm, stream);
 }
 
 #ifdef ADMPC_QUAD_TIMERS

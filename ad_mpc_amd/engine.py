@@ -308,32 +308,98 @@ class QuadBatchSolver:
         if t.dtype != dtype or not t.is_contiguous() or t.device != self.device or tuple(t.shape) != tuple(shape):
             raise ValueError("expected contiguous %s tensor of shape %s on %s" % (dtype, tuple(shape), self.device))
 
-    def solve(self, x0, yref, yref_e, xbar, ubar, cost=None, status=None, iters=None):
-        """In place on xbar [B,N+1,13] / ubar [B,N,4] (float64 device tensors).  Asynchronous."""
+    def solve(self, x0, yref, yref_e, xbar, ubar, cost=None, status=None, iters=None, gp_state=None):
+        """In place on xbar [B,N+1,13] / ubar [B,N,4] (float64 device tensors).  Asynchronous.  gp_state [B,13]: the first node's GP
+        state (run_optimization's gp_regression_state); None: the initial state x0, the reference's default."""
         from .quad_config import QNX, QNU, QNY
         N, B = int(self.cfg.N), x0.shape[0]
         self._chk(x0, (B, QNX)); self._chk(yref, (B, N, QNY)); self._chk(yref_e, (B, QNX)); self._chk(xbar, (B, N + 1, QNX)); self._chk(ubar, (B, N, QNU))
         if cost is not None: self._chk(cost, (B,))
         if status is not None: self._chk(status, (B,), torch.int32)
         if iters is not None: self._chk(iters, (B,), torch.int32)
-        _lib.check(self.lib.admpc_quad_solve_batch(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(xbar), _ptr(ubar), _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
+        if gp_state is not None: self._chk(gp_state, (B, QNX))
+        _lib.check(self.lib.admpc_quad_solve_batch_ex(self._h, B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(gp_state), _ptr(xbar), _ptr(ubar),
+                                                      _ptr(cost), _ptr(status), _ptr(iters), self._stream()))
 
-    def shoot(self, xbar, ubar):
+    def shoot(self, xbar, ubar, gp_state=None):
         from .quad_config import QNX, QNU
         N, B = int(self.cfg.N), xbar.shape[0]
         self._chk(xbar, (B, N + 1, QNX)); self._chk(ubar, (B, N, QNU))
+        if gp_state is not None: self._chk(gp_state, (B, QNX))
         phi = torch.empty((B, N, QNX), dtype=torch.float64, device=self.device)
         A = torch.empty((B, N, QNX, QNX), dtype=torch.float64, device=self.device)
         Bm = torch.empty((B, N, QNX, QNU), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.admpc_quad_shoot_batch(self._h, B, _ptr(xbar), _ptr(ubar), _ptr(phi), _ptr(A), _ptr(Bm), self._stream()))
+        _lib.check(self.lib.admpc_quad_shoot_batch_ex(self._h, B, _ptr(xbar), _ptr(ubar), _ptr(gp_state), _ptr(phi), _ptr(A), _ptr(Bm), self._stream()))
         return phi, A, Bm
 
-    def solve_numpy(self, x0, yref, yref_e, xbar, ubar):
+    def solve_numpy(self, x0, yref, yref_e, xbar, ubar, gp_state=None):
         """Host arrays in, host arrays out: (x, u, cost, status, iters)."""
         d = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
         B = np.asarray(x0).shape[0]
         tx, tu = d(xbar).clone(), d(ubar).clone()
         cost = torch.empty(B, dtype=torch.float64, device=self.device); st = torch.empty(B, dtype=torch.int32, device=self.device); it = torch.empty(B, dtype=torch.int32, device=self.device)
-        self.solve(d(x0), d(yref), d(yref_e), tx, tu, cost, st, it)
+        self.solve(d(x0), d(yref), d(yref_e), tx, tu, cost, st, it, gp_state=None if gp_state is None else d(gp_state))
         torch.cuda.synchronize(self.device)
         return tx.cpu().numpy(), tu.cpu().numpy(), cost.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()
+
+
+class QuadEnsembleBatchSolver:
+    """Clustered GP ensembles of the quadrotor (reference: one AcadosOcpSolver per cluster, quad_3d_optimizer.py:207, chosen per solve
+    from the reference state by GPEnsemble.select_gp, :446-452 / :485-491).  One handle per cluster; selection and routing are HIP
+    kernels of the library (admpc_quad_select_cluster_batch, admpc_quad_solve_batch_routed).  ``clusters[c]``: the ``set_quad_gp`` list
+    of cluster c; ``centroids`` K x d in the features ``feats`` (indices into z = [x with the velocity in the body frame; u])."""
+
+    def __init__(self, cfg, clusters, centroids, feats, device=0):
+        from .quad_config import set_quad_gp
+        self.solvers = []
+        for gps in clusters:
+            cc = cfg.copy()
+            set_quad_gp(cc, gps)
+            self.solvers.append(QuadBatchSolver(cc, device=device))
+        s0 = self.solvers[0]
+        self.lib, self.device, self.device_index, self.N = s0.lib, s0.device, s0.device_index, int(s0.cfg.N)
+        self._cent = torch.as_tensor(np.ascontiguousarray(np.asarray(centroids, dtype=np.float64).reshape(len(clusters), -1)), device=self.device).contiguous()
+        feats = [int(f) for f in np.atleast_1d(feats)]
+        if self._cent.shape[1] != len(feats):
+            raise ValueError("centroids must be K x len(feats)")
+        self._feats = (C.c_int32 * len(feats))(*feats)
+        self._handles = (C.c_void_p * len(self.solvers))(*[sv._h for sv in self.solvers])
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def select(self, x_sel, u_sel, route=None):
+        """Cluster of every instance from the reference state [B,13] (world-frame velocity: the kernel rotates it to the body frame as
+        the reference does before select_gp) and input target [B,4]; int32 [B] device tensor out.  Asynchronous."""
+        from .quad_config import QNX, QNU
+        B = x_sel.shape[0]
+        sv = self.solvers[0]
+        x_sel, u_sel = x_sel.contiguous(), u_sel.contiguous()
+        sv._chk(x_sel, (B, QNX)); sv._chk(u_sel, (B, QNU))
+        if route is None:
+            route = torch.empty(B, dtype=torch.int32, device=self.device)
+        sv._chk(route, (B,), torch.int32)
+        _lib.check(self.lib.admpc_quad_select_cluster_batch(self.device_index, B, len(self._feats), self._feats, _ptr(x_sel), _ptr(u_sel),
+                                                            int(self._cent.shape[0]), _ptr(self._cent), _ptr(route), self._stream()))
+        return route
+
+    def solve(self, gp_ind, x0, yref, yref_e, xbar, ubar, cost=None, status=None, iters=None, gp_state=None):
+        """QuadBatchSolver.solve with a cluster index per instance (int32 device tensor).  In place on xbar / ubar.  Asynchronous.
+        An index outside [0, K) gives status 4 and cost +inf for that instance."""
+        from .quad_config import QNX, QNU, QNY
+        N, B = self.N, x0.shape[0]
+        sv = self.solvers[0]
+        if gp_ind.dtype != torch.int32:
+            gp_ind = gp_ind.to(torch.int32)
+        sv._chk(gp_ind, (B,), torch.int32)
+        sv._chk(x0, (B, QNX)); sv._chk(yref, (B, N, QNY)); sv._chk(yref_e, (B, QNX)); sv._chk(xbar, (B, N + 1, QNX)); sv._chk(ubar, (B, N, QNU))
+        if cost is not None: sv._chk(cost, (B,))
+        if status is not None: sv._chk(status, (B,), torch.int32)
+        if iters is not None: sv._chk(iters, (B,), torch.int32)
+        if gp_state is not None: sv._chk(gp_state, (B, QNX))
+        _lib.check(self.lib.admpc_quad_solve_batch_routed(self._handles, len(self.solvers), B, _ptr(gp_ind), _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(gp_state),
+                                                          _ptr(xbar), _ptr(ubar), _ptr(cost), _ptr(status), _ptr(iters), self._stream()))

@@ -25,10 +25,33 @@ def quaternion_inverse(q):
     return np.array([q[0], -q[1], -q[2], -q[3]], dtype=np.float64)
 
 
+class QuadGPEnsemble:
+    """What the optimiser needs of the reference's ``GPEnsemble`` (src/model_fitting/gp.py) for the quadrotor: per cluster the regressors
+    of the body-frame acceleration components (``set_quad_gp`` dicts), the K x d centroids and the features they live in (indices into
+    z = [x with the velocity in the body frame; u]).  Homogeneous ensembles only -- the reference's MPC path keys its solvers with ONE
+    index per solve (quad_3d_optimizer.py:452-462)."""
+
+    def __init__(self, clusters, centroids, feats):
+        self.clusters = [list(c) for c in clusters]
+        self.centroids = np.asarray(centroids, dtype=np.float64).reshape(len(self.clusters), -1)
+        self.feats = [int(f) for f in np.atleast_1d(feats).reshape(-1)]
+        self.n_models = len(self.clusters)
+
+    def select_gp(self, z):
+        """gp.py:738-770: nearest centroid of the selected features; z = the full 17-vector [x (body-frame velocity); u]."""
+        zz = np.asarray(z, dtype=np.float64)[self.feats]
+        return int(np.argmin(np.sqrt(((zz[None, :] - self.centroids) ** 2).sum(1))))
+
+
 class Quad3DOptimizer:
-    def __init__(self, quad=None, t_horizon=1, n_nodes=20, q_cost=None, r_cost=None, q_mask=None, solver_options=None, device=0):
-        """quad_3d_optimizer.py:40-207.  ``quad``: an object with mass, J, max_thrust, x_f, y_f, z_l_tau, min_u / max_u (or
-        max_input_value / min_input_value) as ``Quadrotor3D`` has them; None = the vehicle of quad_3d.py."""
+    def __init__(self, quad=None, t_horizon=1, n_nodes=20, q_cost=None, r_cost=None, q_mask=None,
+                 B_x=None, gp_regressors=None, rdrv_d_mat=None, model_name="quad_3d_acados_mpc", solver_options=None, device=0):
+        """quad_3d_optimizer.py:29-207 (same argument order).  ``quad``: an object with mass, J, max_thrust, x_f, y_f, z_l_tau, min_u /
+        max_u (or max_input_value / min_input_value) as ``Quadrotor3D`` has them; None = the vehicle of quad_3d.py.
+        ``gp_regressors``: a ``QuadGPEnsemble`` (or a plain list of ``set_quad_gp`` dicts = one cluster) -- one engine handle per cluster
+        as the reference keeps one acados solver per cluster (:207), each with its own persistent iterate.  ``B_x`` is implied by the
+        regressors' ``out`` entries (7, 8, 9: the velocity rows) and only accepted for signature compatibility.  ``rdrv_d_mat``: the 3 x 3
+        (diagonal) linear drag matrix of :364-381."""
         from .engine import QuadBatchSolver
         if q_cost is None:
             q_cost = np.array([10, 10, 10, 0.1, 0.1, 0.1, 0.05, 0.05, 0.05, 0.05, 0.05, 0.05])
@@ -56,10 +79,30 @@ class Quad3DOptimizer:
             lo = getattr(quad, "min_u", getattr(quad, "min_input_value", 0.0)); hi = getattr(quad, "max_u", getattr(quad, "max_input_value", 1.0))
             for m in range(QNU):
                 cfg.lbu[m], cfg.ubu[m] = float(lo), float(hi)
+        if rdrv_d_mat is not None:
+            d = np.asarray(rdrv_d_mat, dtype=np.float64)
+            if d.shape != (3, 3) or np.abs(d - np.diag(np.diag(d))).max() != 0.0:
+                raise ValueError("rdrv_d_mat must be a 3 x 3 diagonal matrix (quad_3d_optimizer.py:364-381)")
+            for i in range(3):
+                cfg.rdrv[i] = float(d[i, i])
         self.cfg = cfg
-        self.solver = QuadBatchSolver(cfg, device=device)
-        self.yref = np.zeros((self.N, QNX + QNU)); self.yref_e = np.zeros(QNX)
-        self.x_iter = np.zeros((self.N + 1, QNX)); self.u_iter = np.zeros((self.N, QNU))      # acados starts from a zero iterate and keeps it
+        if gp_regressors is not None and not isinstance(gp_regressors, QuadGPEnsemble):
+            gp_regressors = QuadGPEnsemble([list(gp_regressors)], np.zeros((1, 1)), [7])
+        self.gp_reg_ensemble = gp_regressors
+        self.with_gp = gp_regressors is not None
+        if self.with_gp:
+            from .quad_config import set_quad_gp
+            self.solvers = []
+            for gps in gp_regressors.clusters:
+                cc = cfg.copy(); set_quad_gp(cc, gps)
+                self.solvers.append(QuadBatchSolver(cc, device=device))
+        else:
+            self.solvers = [QuadBatchSolver(cfg, device=device)]
+        self.solver = self.solvers[0]
+        K = len(self.solvers)
+        # every acados solver of the reference has its own references and its own (zero-initialised, never shifted) iterate
+        self.yref = [np.zeros((self.N, QNX + QNU)) for _ in range(K)]; self.yref_e = [np.zeros(QNX) for _ in range(K)]
+        self.x_iter = [np.zeros((self.N + 1, QNX)) for _ in range(K)]; self.u_iter = [np.zeros((self.N, QNU)) for _ in range(K)]
         self.target = None
         self.status = 0
 
@@ -73,9 +116,10 @@ class Quad3DOptimizer:
         ref = np.concatenate([np.asarray(x_target[i], dtype=np.float64) for i in range(4)])
         v_b = v_dot_q(ref[7:10], quaternion_inverse(ref[3:7]))
         ref = np.concatenate((ref[:7], v_b, ref[10:], np.asarray(u_target, dtype=np.float64)))
-        self.yref[:] = ref
-        self.yref_e[:] = ref[:-4]
-        return 0
+        gp_ind = self.gp_reg_ensemble.select_gp(ref) if self.with_gp else 0          # :449-452: from the reference, velocity in the body frame
+        self.yref[gp_ind][:] = ref
+        self.yref_e[gp_ind][:] = ref[:-4]
+        return gp_ind
 
     def set_reference_trajectory(self, x_target, u_target):
         """:465-503: short trajectories are padded with their last row; the last node has a state reference only."""
@@ -86,20 +130,31 @@ class Quad3DOptimizer:
             if u_target is not None:
                 u_target = np.concatenate((u_target, np.expand_dims(u_target[-1, :], 0)), 0)
         stacked = np.concatenate([x for x in x_target], 1)
+        if self.with_gp:                                          # :484-491: the model is chosen from the middle of the reference
+            x_mean = stacked[int(self.N / 2)]
+            v_b = v_dot_q(x_mean[7:10], quaternion_inverse(x_mean[3:7]))
+            gp_ind = self.gp_reg_ensemble.select_gp(np.concatenate((x_mean[:7], v_b, x_mean[10:], u_target[int(self.N / 2)])))
+        else:
+            gp_ind = 0
         self.target = copy(x_target)
         for j in range(self.N):
-            self.yref[j] = np.concatenate((stacked[j, :], u_target[j, :]))
-        self.yref_e[:] = stacked[self.N, :]
-        return 0
+            self.yref[gp_ind][j] = np.concatenate((stacked[j, :], u_target[j, :]))
+        self.yref_e[gp_ind][:] = stacked[self.N, :]
+        return gp_ind
 
     def run_optimization(self, initial_state=None, use_model=0, return_x=False, gp_regression_state=None):
         """:527-566: one RTI step from the stored iterate; returns the flattened input sequence (and the states)."""
         if initial_state is None:
             initial_state = [0, 0, 0] + [1, 0, 0, 0] + [0, 0, 0] + [0, 0, 0]
         x_init = np.stack(initial_state).astype(np.float64).reshape(1, QNX)
-        x, u, cost, st, it = self.solver.solve_numpy(x_init, self.yref[None], self.yref_e[None], self.x_iter[None], self.u_iter[None])
+        m = int(use_model)
+        gp_state = None
+        if self.with_gp and gp_regression_state is not None:      # :546-552: p = [gp_state, 1] at node 0 (default: the initial state)
+            gp_state = np.asarray(gp_regression_state, dtype=np.float64).reshape(1, QNX)
+        x, u, cost, st, it = self.solvers[m].solve_numpy(x_init, self.yref[m][None], self.yref_e[m][None], self.x_iter[m][None], self.u_iter[m][None],
+                                                         gp_state=gp_state)
         self.status = int(st[0])
         if self.status == 0:
-            self.x_iter, self.u_iter = x[0], u[0]
-        w_opt = np.reshape(self.u_iter.copy(), (-1))
-        return w_opt if not return_x else (w_opt, self.x_iter.copy())
+            self.x_iter[m], self.u_iter[m] = x[0], u[0]
+        w_opt = np.reshape(self.u_iter[m].copy(), (-1))
+        return w_opt if not return_x else (w_opt, self.x_iter[m].copy())

@@ -16,7 +16,7 @@ class AdmpcQuadConfig(C.Structure):
         ("W", C.c_double * QNY), ("We", C.c_double * QNX),
         ("lbu", C.c_double * QNU), ("ubu", C.c_double * QNU),
         ("mass", C.c_double), ("J", C.c_double * 3), ("max_thrust", C.c_double),
-        ("x_f", C.c_double * 4), ("y_f", C.c_double * 4), ("z_l_tau", C.c_double * 4), ("g", C.c_double),
+        ("x_f", C.c_double * 4), ("y_f", C.c_double * 4), ("z_l_tau", C.c_double * 4), ("g", C.c_double), ("rdrv", C.c_double * 3),
         ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double), ("ipm_tol_comp", C.c_double), ("ipm_tol_res", C.c_double),
         ("n_gp", C.c_int32), ("_pad", C.c_int32), ("gp", AdmpcGp * QUAD_GP_MAX),
     ]

@@ -8,7 +8,9 @@
  *   quad_3d_optimizer.py:150-207   AcadosOcp: LINEAR_LS cost, input box, ERK, GN,    AdmpcQuadConfig
  *                                  FULL_CONDENSING_HPIPM, SQP_RTI
  *   acados_models/my_quad_acados_ocp.json  dims / W / bounds / tf                   admpc_quad_default_config
- *   quad_3d_optimizer.py:530-566   set x0 / solve() / get x, u                      admpc_quad_solve_batch
+ *   quad_3d_optimizer.py:530-566   set x0 / p / solve() / get x, u                  admpc_quad_solve_batch, _ex (gp_regression_state)
+ *   quad_3d_optimizer.py:207, 446-452, 485-491  one solver per GP cluster, select_gp  admpc_quad_select_cluster_batch, admpc_quad_solve_batch_routed
+ *   quad_3d_optimizer.py:364-381   linear drag (rdrv_d_mat)                          cfg.rdrv
  *
  * State  x = [p(3), q_wxyz(4), v(3), w(3)],  input u = activations of the four rotors in [0, 1].
  * Conventions as in admpc.h: device pointers owned by the caller, instance-major and dense, fp64; `stream` is a hipStream_t passed
@@ -53,6 +55,8 @@ typedef struct AdmpcQuadConfig {
     double  max_thrust;           /* quad_3d.py:40  20 N per rotor                                                 */
     double  x_f[4], y_f[4], z_l_tau[4];                   /* rotor arms and yaw-torque coefficients (:62-74)       */
     double  g;                    /* 9.81                                                                          */
+    double  rdrv[3];              /* diagonal of Faessler's linear rotor-drag matrix D (quad_3d_optimizer.py:364-381, rdrv_d_mat of the
+                                   * class): v' += R(q) D R(q)' v.  Zeros (the shipped generated code, default): no drag term.     */
     double  ipm_mu0, ipm_thr0, ipm_tol_comp, ipm_tol_res; /* interior point: start and stop levels                 */
     /* GP residual of the acceleration (quad_3d_optimizer.py:289-327): the features are taken from z = [x with the velocity in the
      * BODY frame; u] (feat[] indexes these 17 entries; 7..16 are offered: body-frame velocity, body rates, inputs), gp[g].out in {7, 8, 9} names the body-frame acceleration component the mean
@@ -77,8 +81,31 @@ void admpc_quad_destroy(AdmpcQuadSolver* s);
 int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e,
                            double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream);
 
+/* The same with the GP state of the first optimisation node given per instance: gp_state [B][13] is run_optimization's
+ * gp_regression_state (quad_3d_optimizer.py:546-552: parameter p = [gp_state, 1] at node 0, zeros elsewhere; :291-297: there the GP
+ * features and the rotation of the GP means come from the parameter instead of the integrated state).  NULL: the initial state x0, the
+ * reference's default -- which is also what admpc_quad_solve_batch does.  Ignored by a model without GPs. */
+int admpc_quad_solve_batch_ex(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* gp_state,
+                              double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream);
+
+/* Clustered GP ensembles.  The reference keeps one acados solver per cluster (quad_3d_optimizer.py:207) and picks one per solve from the
+ * reference state (set_reference_state :446-452 / set_reference_trajectory :485-491 -> gp.py:738-770 select_gp: nearest centroid).
+ * admpc_quad_select_cluster_batch: route[b] = index of the centroid (centroids [K][n_feat]) nearest to the selected features (feats[]
+ * index z = [x with the velocity in the body frame; u], 17 entries) of (x_sel [B][13] world-frame velocity, u_sel [B][4]); ties to the
+ * lower index.  admpc_quad_solve_batch_routed: one call for the batch, solvers[route[b]] solves instance b in place (every handle
+ * runs over the batch and leaves the others' instances alone: no gather / scatter); an out-of-range route gives status 4, infinite
+ * cost and an untouched iterate.  The solvers must share device and horizon. */
+int admpc_quad_select_cluster_batch(int device, int B, int n_feat, const int32_t* feats, const double* x_sel, const double* u_sel,
+                                    int K, const double* centroids, int32_t* route, void* stream);
+int admpc_quad_solve_batch_routed(AdmpcQuadSolver* const* solvers, int K, int B, const int32_t* route,
+                                  const double* x0, const double* yref, const double* yref_e, const double* gp_state,
+                                  double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, void* stream);
+
 /* Test hook: the shooting step alone -- phi [B][N][13], A [B][N][13][13], Bm [B][N][13][4] of every interval. */
 int admpc_quad_shoot_batch(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, double* phi, double* A, double* Bm, void* stream);
+/* ... with the first node's GP state (NULL: xbar_0 of the instance) */
+int admpc_quad_shoot_batch_ex(AdmpcQuadSolver* s, int B, const double* xbar, const double* ubar, const double* gp_state,
+                              double* phi, double* A, double* Bm, void* stream);
 
 #ifdef __cplusplus
 }

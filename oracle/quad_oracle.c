@@ -3,7 +3,8 @@
  * TEST INFRASTRUCTURE ONLY: loaded by tests/ (and nothing else); the product path is ad_mpc_amd/csrc/admpc_quad.hip.
  *
  * What it follows (data_driven_mpc/ros_gp_mpc):
- *   model        src/quad_mpc/quad_3d_optimizer.py:341-393 (p, q, v, w dynamics; no drag in the shipped generated code),
+ *   model        src/quad_mpc/quad_3d_optimizer.py:341-393 (p, q, v, w dynamics; the linear drag term :364-381 is an option of the class
+ *                that the shipped generated code does not contain: cfg.rdrv), :289-327 GP residual with the first node's GP state,
  *                src/utils/utils.py:323-338 (q_to_rot_mat), :392-410 (skew_symmetric), src/quad_mpc/quad_3d.py:40-74 (vehicle)
  *   formulation  src/quad_mpc/quad_3d_optimizer.py:150-207 + acados_models/my_quad_acados_ocp.json (LINEAR_LS, W scaled by Ts,
  *                hard input box, x0 fixed, ERK4 with one step per interval, Gauss-Newton, full condensing, RTI)
@@ -22,8 +23,12 @@
 typedef double real;
 typedef AdmpcQuadConfig Cfg;
 
-/* f(x, u) and its directional derivative df = Jx sx + Ju su (forward mode, by hand) */
-static void quad_f_tan(const Cfg* c, const real* x, const real* u, const real* sx, const real* su, real* f, real* df)
+/* f(x, u) and its directional derivative df = Jx sx + Ju su (forward mode, by hand).
+ * gpx (may be NULL): the "GP state" parameter of the first optimisation node (quad_3d_optimizer.py:291-297, :546-552: p = [gp_x, 1] at node
+ * 0, zeros elsewhere -- `gp_x * trigger_var + x * (1 - trigger_var)`): with it the GP features AND the rotation of the GP means back to the
+ * world frame are taken from that constant state instead of the integrated one, so the residual does not depend on x there (zero tangent
+ * along sx; the input features still carry su). */
+static void quad_f_tan(const Cfg* c, const real* x, const real* u, const real* sx, const real* su, const real* gpx, real* f, real* df)
 {
     const real qw = x[3], qx = x[4], qy = x[5], qz = x[6], r0 = x[10], r1 = x[11], r2 = x[12];
     const real sw = sx[3], sxx = sx[4], sy = sx[5], sz = sx[6], t0 = sx[10], t1 = sx[11], t2 = sx[12];
@@ -54,20 +59,45 @@ static void quad_f_tan(const Cfg* c, const real* x, const real* u, const real* s
     df[10] = (dtx + (c->J[1] - c->J[2]) * (t1 * r2 + r1 * t2)) / c->J[0];
     df[11] = (dty + (c->J[2] - c->J[0]) * (t2 * r0 + r2 * t0)) / c->J[1];
     df[12] = (dtz + (c->J[0] - c->J[1]) * (t0 * r1 + r0 * t1)) / c->J[2];
-    if (c->n_gp > 0) {
-        /* GP residual (quad_3d_optimizer.py:289-327): features from z = [x with v in the body frame; u], means of the body-frame
-         * acceleration components rotated back to the world frame:  v' += R(q) mu(z);  utils.py:323-338 for R */
-        real R[3][3] = { { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy) },
-                         { 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx) },
-                         { 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy) } };
-        real dR[3][3] = { { -4 * (qy * sy + qz * sz), 2 * (sxx * qy + qx * sy - sw * qz - qw * sz), 2 * (sxx * qz + qx * sz + sw * qy + qw * sy) },
-                          { 2 * (sxx * qy + qx * sy + sw * qz + qw * sz), -4 * (qx * sxx + qz * sz), 2 * (sy * qz + qy * sz - sw * qx - qw * sxx) },
-                          { 2 * (sxx * qz + qx * sz - sw * qy - qw * sy), 2 * (sy * qz + qy * sz + sw * qx + qw * sxx), -4 * (qx * sxx + qy * sy) } };
-        real z[17], dz[17];
-        for (int i = 0; i < NX; ++i) { z[i] = x[i]; dz[i] = sx[i]; }
-        for (int i = 0; i < 3; ++i) {                                  /* v_b = R' v  (v_dot_q(v, q^-1)) */
+    const int drag = c->rdrv[0] != 0 || c->rdrv[1] != 0 || c->rdrv[2] != 0;
+    if (drag) {
+        /* linear rotor-drag compensation (quad_3d_optimizer.py:364-381, Faessler et al.): v' += R(q) D R(q)' v, D = diag(rdrv) */
+        const real R[3][3] = { { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy) },
+                               { 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx) },
+                               { 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy) } };
+        const real dR[3][3] = { { -4 * (qy * sy + qz * sz), 2 * (sxx * qy + qx * sy - sw * qz - qw * sz), 2 * (sxx * qz + qx * sz + sw * qy + qw * sy) },
+                                { 2 * (sxx * qy + qx * sy + sw * qz + qw * sz), -4 * (qx * sxx + qz * sz), 2 * (sy * qz + qy * sz - sw * qx - qw * sxx) },
+                                { 2 * (sxx * qz + qx * sz - sw * qy - qw * sy), 2 * (sy * qz + qy * sz + sw * qx + qw * sxx), -4 * (qx * sxx + qy * sy) } };
+        real wb[3], dwb[3];
+        for (int i = 0; i < 3; ++i) {                                  /* D v_b, v_b = R' v */
             real a2 = 0, d2 = 0;
             for (int k = 0; k < 3; ++k) { a2 += R[k][i] * x[7 + k]; d2 += dR[k][i] * x[7 + k] + R[k][i] * sx[7 + k]; }
+            wb[i] = c->rdrv[i] * a2; dwb[i] = c->rdrv[i] * d2;
+        }
+        for (int i = 0; i < 3; ++i) {
+            real a2 = 0, d2 = 0;
+            for (int k = 0; k < 3; ++k) { a2 += R[i][k] * wb[k]; d2 += dR[i][k] * wb[k] + R[i][k] * dwb[k]; }
+            f[7 + i] += a2; df[7 + i] += d2;
+        }
+    }
+    if (c->n_gp > 0) {
+        /* GP residual (quad_3d_optimizer.py:289-327): features from z = [x with v in the body frame; u], means of the body-frame
+         * acceleration components rotated back to the world frame:  v' += R(q) mu(z);  utils.py:323-338 for R.
+         * The state the features and the rotation come from: the integrated one, or the node's GP-state parameter (zero tangent). */
+        real xe[NX], se[NX];
+        for (int i = 0; i < NX; ++i) { xe[i] = gpx ? gpx[i] : x[i]; se[i] = gpx ? 0 : sx[i]; }
+        const real ew = xe[3], ex = xe[4], ey = xe[5], ez = xe[6], fw = se[3], fx = se[4], fy = se[5], fz = se[6];
+        real R[3][3] = { { 1 - 2 * (ey * ey + ez * ez), 2 * (ex * ey - ew * ez), 2 * (ex * ez + ew * ey) },
+                         { 2 * (ex * ey + ew * ez), 1 - 2 * (ex * ex + ez * ez), 2 * (ey * ez - ew * ex) },
+                         { 2 * (ex * ez - ew * ey), 2 * (ey * ez + ew * ex), 1 - 2 * (ex * ex + ey * ey) } };
+        real dR[3][3] = { { -4 * (ey * fy + ez * fz), 2 * (fx * ey + ex * fy - fw * ez - ew * fz), 2 * (fx * ez + ex * fz + fw * ey + ew * fy) },
+                          { 2 * (fx * ey + ex * fy + fw * ez + ew * fz), -4 * (ex * fx + ez * fz), 2 * (fy * ez + ey * fz - fw * ex - ew * fx) },
+                          { 2 * (fx * ez + ex * fz - fw * ey - ew * fy), 2 * (fy * ez + ey * fz + fw * ex + ew * fx), -4 * (ex * fx + ey * fy) } };
+        real z[17], dz[17];
+        for (int i = 0; i < NX; ++i) { z[i] = xe[i]; dz[i] = se[i]; }
+        for (int i = 0; i < 3; ++i) {                                  /* v_b = R' v  (v_dot_q(v, q^-1)) */
+            real a2 = 0, d2 = 0;
+            for (int k = 0; k < 3; ++k) { a2 += R[k][i] * xe[7 + k]; d2 += dR[k][i] * xe[7 + k] + R[k][i] * se[7 + k]; }
             z[7 + i] = a2; dz[7 + i] = d2;
         }
         for (int m = 0; m < NU; ++m) { z[NX + m] = u[m]; dz[NX + m] = su[m]; }
@@ -92,7 +122,7 @@ static void quad_f_tan(const Cfg* c, const real* x, const real* u, const real* s
 }
 
 /* classic RK4 (one step of length h) of the state and ONE sensitivity column: col < 13 -> d/dx_col, col >= 13 -> d/du_(col-13) */
-static void rk4_col(const Cfg* c, const real* x, const real* u, real h, int col, real* phi, real* scol)
+static void rk4_col(const Cfg* c, const real* x, const real* u, const real* gpx, real h, int col, real* phi, real* scol)
 {
     static const real cs[4] = { 0, 0.5, 0.5, 1.0 }, ws[4] = { 1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6 };
     real kx[NX] = {0}, ks[NX] = {0}, ax[NX] = {0}, as[NX] = {0}, su[NU] = {0};
@@ -100,24 +130,25 @@ static void rk4_col(const Cfg* c, const real* x, const real* u, real h, int col,
     for (int s = 0; s < 4; ++s) {
         real X[NX], S[NX], f[NX], df[NX];
         for (int i = 0; i < NX; ++i) { X[i] = x[i] + cs[s] * h * kx[i]; S[i] = (col == i ? 1.0 : 0.0) + cs[s] * h * ks[i]; }
-        quad_f_tan(c, X, u, S, su, f, df);
+        quad_f_tan(c, X, u, S, su, gpx, f, df);
         for (int i = 0; i < NX; ++i) { kx[i] = f[i]; ks[i] = df[i]; ax[i] += ws[s] * f[i]; as[i] += ws[s] * df[i]; }
     }
     for (int i = 0; i < NX; ++i) { phi[i] = x[i] + h * ax[i]; scol[i] = (col == i ? 1.0 : 0.0) + h * as[i]; }
 }
 
-void quad_oracle_f(const Cfg* c, const double* x, const double* u, double* f)
+/* gpx: NULL, or the GP-state parameter of a first node (see quad_f_tan) */
+void quad_oracle_f(const Cfg* c, const double* x, const double* u, const double* gpx, double* f)
 {
     real z13[NX] = {0}, z4[NU] = {0}, df[NX];
-    quad_f_tan(c, x, u, z13, z4, f, df);
+    quad_f_tan(c, x, u, z13, z4, gpx, f, df);
 }
 
 /* phi [13], A [13][13], B [13][4] (row-major) */
-void quad_oracle_rk4_sens(const Cfg* c, const double* x, const double* u, double h, double* phi, double* A, double* B)
+void quad_oracle_rk4_sens(const Cfg* c, const double* x, const double* u, const double* gpx, double h, double* phi, double* A, double* B)
 {
     real col[NX];
     for (int cc = 0; cc < NX + NU; ++cc) {
-        rk4_col(c, x, u, h, cc, phi, col);
+        rk4_col(c, x, u, gpx, h, cc, phi, col);
         for (int i = 0; i < NX; ++i) { if (cc < NX) A[i * NX + cc] = col[i]; else B[i * NU + (cc - NX)] = col[i]; }
     }
 }
@@ -276,14 +307,15 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
     return 0;
 }
 
-static int rti_step(const Cfg* c, const real* x0, const real* yref, const real* yref_e, real* xbar, real* ubar, real* cost, int* iters,
+/* gp_state: the GP state of the first node (run_optimization's gp_regression_state, :546-552; NULL: the initial state x0, its default) */
+static int rti_step(const Cfg* c, const real* x0, const real* yref, const real* yref_e, const real* gp_state, real* xbar, real* ubar, real* cost, int* iters,
                     real* H_out, real* g_out)
 {
     Work w;
     const int N = c->N, n = N * NU;
     for (int k = 0; k < N; ++k) {
         real phi[NX];
-        quad_oracle_rk4_sens(c, xbar + k * NX, ubar + k * NU, c->Ts, phi, &w.A[k][0][0], &w.B[k][0][0]);
+        quad_oracle_rk4_sens(c, xbar + k * NX, ubar + k * NU, (k == 0 && c->n_gp > 0) ? (gp_state ? gp_state : x0) : 0, c->Ts, phi, &w.A[k][0][0], &w.B[k][0][0]);
         for (int i = 0; i < NX; ++i) w.b[k][i] = phi[i] - xbar[(k + 1) * NX + i];
     }
     condense(c, x0, yref, yref_e, xbar, ubar, &w);
@@ -319,7 +351,7 @@ static int rti_step(const Cfg* c, const real* x0, const real* yref, const real* 
 }
 
 /* x, u in place; returns the number of instances with a non-zero status */
-int quad_oracle_solve_batch(const Cfg* c, int B, const double* x0, const double* yref, const double* yref_e,
+int quad_oracle_solve_batch(const Cfg* c, int B, const double* x0, const double* yref, const double* yref_e, const double* gp_state,
                             double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, int nthreads)
 {
     const int N = c->N;
@@ -331,7 +363,7 @@ int quad_oracle_solve_batch(const Cfg* c, int B, const double* x0, const double*
     for (int b = 0; b < B; ++b) {
         int it = 0; real J;
         const int st = rti_step(c, x0 + (size_t)b * NX, yref + (size_t)b * N * ADMPC_QUAD_NY, yref_e + (size_t)b * NX,
-                                xbar + (size_t)b * (N + 1) * NX, ubar + (size_t)b * N * NU, &J, &it, 0, 0);
+                                gp_state ? gp_state + (size_t)b * NX : 0, xbar + (size_t)b * (N + 1) * NX, ubar + (size_t)b * N * NU, &J, &it, 0, 0);
         if (cost) cost[b] = J;
         if (status) status[b] = st;
         if (iters) iters[b] = it;
@@ -345,7 +377,7 @@ int quad_oracle_qp_debug(const Cfg* c, const double* x0, const double* yref, con
                          double* H, double* g, int32_t* iters)
 {
     int it = 0; real J;
-    const int st = rti_step(c, x0, yref, yref_e, xbar, ubar, &J, &it, H, g);
+    const int st = rti_step(c, x0, yref, yref_e, 0, xbar, ubar, &J, &it, H, g);
     *iters = it;
     return st;
 }

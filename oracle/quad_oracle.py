@@ -22,30 +22,35 @@ class QuadOracle:
         subprocess.run(["make", "-C", _HERE, "libquad_oracle.so"], check=True, stdout=subprocess.DEVNULL)
         self.lib = L = C.CDLL(os.path.join(_HERE, "libquad_oracle.so"))
         cp = C.POINTER(AdmpcQuadConfig)
-        L.quad_oracle_f.argtypes = [cp, _dp, _dp, _dp]
-        L.quad_oracle_rk4_sens.argtypes = [cp, _dp, _dp, C.c_double, _dp, _dp, _dp]
-        L.quad_oracle_solve_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
+        L.quad_oracle_f.argtypes = [cp, _dp, _dp, _dp, _dp]
+        L.quad_oracle_rk4_sens.argtypes = [cp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp]
+        L.quad_oracle_solve_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
         L.quad_oracle_qp_debug.argtypes = [cp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]
 
-    def f(self, cfg, x, u):
+    def f(self, cfg, x, u, gpx=None):
+        """gpx: the GP-state parameter of a first node (features and rotation of the GP residual come from it), or None."""
         x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64); out = np.empty(QNX)
-        self.lib.quad_oracle_f(C.byref(cfg), _ptr(x), _ptr(u), _ptr(out))
+        g = None if gpx is None else np.ascontiguousarray(gpx, dtype=np.float64)
+        self.lib.quad_oracle_f(C.byref(cfg), _ptr(x), _ptr(u), _ptr(g) if g is not None else None, _ptr(out))
         return out
 
-    def rk4_sens(self, cfg, x, u, h):
+    def rk4_sens(self, cfg, x, u, h, gpx=None):
         x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+        g = None if gpx is None else np.ascontiguousarray(gpx, dtype=np.float64)
         phi = np.empty(QNX); A = np.empty((QNX, QNX)); B = np.empty((QNX, QNU))
-        self.lib.quad_oracle_rk4_sens(C.byref(cfg), _ptr(x), _ptr(u), float(h), _ptr(phi), _ptr(A), _ptr(B))
+        self.lib.quad_oracle_rk4_sens(C.byref(cfg), _ptr(x), _ptr(u), _ptr(g) if g is not None else None, float(h), _ptr(phi), _ptr(A), _ptr(B))
         return phi, A, B
 
-    def solve_batch(self, cfg, x0, yref, yref_e, xbar, ubar, nthreads=1):
-        """Returns (x, u, cost, status, iters); the arguments are not modified."""
+    def solve_batch(self, cfg, x0, yref, yref_e, xbar, ubar, nthreads=1, gp_state=None):
+        """Returns (x, u, cost, status, iters); the arguments are not modified.  gp_state [B,13]: the first node's GP state
+        (run_optimization's gp_regression_state); None: the initial state."""
         N = cfg.N
         x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, QNX); B = x0.shape[0]
         yref = np.ascontiguousarray(yref, dtype=np.float64).reshape(B, N, QNY); yref_e = np.ascontiguousarray(yref_e, dtype=np.float64).reshape(B, QNX)
         x = np.array(xbar, dtype=np.float64).reshape(B, N + 1, QNX).copy(); u = np.array(ubar, dtype=np.float64).reshape(B, N, QNU).copy()
         cost = np.empty(B); st = np.empty(B, dtype=np.int32); it = np.empty(B, dtype=np.int32)
-        self.lib.quad_oracle_solve_batch(C.byref(cfg), B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(x), _ptr(u), _ptr(cost), _ptr(st, _ip), _ptr(it, _ip), int(nthreads))
+        gs = None if gp_state is None else np.ascontiguousarray(gp_state, dtype=np.float64).reshape(B, QNX)
+        self.lib.quad_oracle_solve_batch(C.byref(cfg), B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(gs) if gs is not None else None, _ptr(x), _ptr(u), _ptr(cost), _ptr(st, _ip), _ptr(it, _ip), int(nthreads))
         return x, u, cost, st, it
 
     def qp_debug(self, cfg, x0, yref, yref_e, xbar, ubar):

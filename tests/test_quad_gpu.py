@@ -135,19 +135,19 @@ def test_quad_3d_optimizer_shim_against_oracle(qoracle):
     q = np.array([0.9, 0.1, -0.2, 0.3]); q /= np.linalg.norm(q)
     tgt = [[1.0, -2.0, 0.5], list(q), [0.5, 0.2, -0.1], [0, 0, 0]]
     opt.set_reference_state(tgt, [0.12] * 4)
-    np.testing.assert_allclose(opt.yref[3, 7:10], v_dot_q(tgt[2], quaternion_inverse(q)))      # the reference's body-frame quirk
+    np.testing.assert_allclose(opt.yref[0][3, 7:10], v_dot_q(tgt[2], quaternion_inverse(q)))      # the reference's body-frame quirk
     x0 = [0.2, 0.1, -0.3, 1, 0, 0, 0, 0.1, 0, 0, 0, 0, 0.1]
-    xi, ui = opt.x_iter.copy(), opt.u_iter.copy()
+    xi, ui = opt.x_iter[0].copy(), opt.u_iter[0].copy()
     for _ in range(2):
         w, x = opt.run_optimization(x0, return_x=True)
-        o = qoracle.solve_batch(opt.cfg, np.array(x0)[None], opt.yref[None], opt.yref_e[None], xi[None], ui[None])
+        o = qoracle.solve_batch(opt.cfg, np.array(x0)[None], opt.yref[0][None], opt.yref_e[0][None], xi[None], ui[None])
         assert o[3][0] == 0 and np.abs(w - o[1][0].reshape(-1)).max() <= 1e-8 and np.abs(x - o[0][0]).max() <= 1e-8
         xi, ui = o[0][0], o[1][0]
     # trajectory reference shorter than the horizon: padded with its last row; the terminal node takes the state only
     T = 6
     xt = [np.linspace(0, 1, T)[:, None] * np.ones((1, 3)), np.tile([1.0, 0, 0, 0], (T, 1)), np.zeros((T, 3)), np.zeros((T, 3))]
     opt.set_reference_trajectory(xt, np.full((T - 1, 4), 0.12))
-    assert (opt.yref[T:, :3] == 1.0).all() and (opt.yref_e[:3] == 1.0).all() and opt.yref.shape == (10, 17)
+    assert (opt.yref[0][T:, :3] == 1.0).all() and (opt.yref_e[0][:3] == 1.0).all() and opt.yref[0].shape == (10, 17)
     w = opt.run_optimization(x0)
     assert w.shape == (40,) and opt.status == 0
 
@@ -168,7 +168,7 @@ def test_quad_gp_residual_on_the_device(qoracle):
     phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
     for b in range(0, 96, 11):
         for k in (0, 4, 9):
-            po, Ao, Bo = qoracle.rk4_sens(cfg, s["xbar"][b, k], s["ubar"][b, k], cfg.Ts)
+            po, Ao, Bo = qoracle.rk4_sens(cfg, s["xbar"][b, k], s["ubar"][b, k], cfg.Ts, gpx=s["xbar"][b, 0] if k == 0 else None)   # node 0: GP-state parameter
             for got, ref in ((phi[b, k], po), (A[b, k], Ao), (Bm[b, k], Bo)):
                 assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
     g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
@@ -178,3 +178,132 @@ def test_quad_gp_residual_on_the_device(qoracle):
     base = qoracle.solve_batch(default_quad_config(), s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
     assert np.abs(base[1] - o[1]).max() > 1e-3
     eng.close()
+
+
+def test_first_node_gp_state_on_the_device(qoracle):
+    """quad_3d_optimizer.py:291-297, :546-552 on the device: the first node evaluates the GP residual at a per-instance PARAMETER
+    (admpc_quad_solve_batch_ex's gp_state; default: the initial state).  Shooting of node 0 with a foreign GP state against the oracle
+    (the state columns of A_0 carry no GP term), solves with gp_state = None / = x0 identical and equal to the oracle's, a different
+    gp_state follows the oracle's solve with that state -- identical iteration counts, 1e-8."""
+    import torch
+    from ad_mpc_amd.engine import QuadBatchSolver
+    from ad_mpc_amd.quad_config import set_quad_gp
+    from test_quad_oracle import quad_gps
+    cfg = default_quad_config(); set_quad_gp(cfg, quad_gps())
+    eng = QuadBatchSolver(cfg, device=0)
+    B = 64
+    s = random_quad_scenarios(B, cfg, seed=41)
+    rng = np.random.default_rng(2)
+    gs = s["x0"] + 0.5 * rng.standard_normal((B, QNX)); gs[:, 3:7] /= np.linalg.norm(gs[:, 3:7], axis=1, keepdims=True)
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    phi, A, Bm = eng.shoot(d(s["xbar"]), d(s["ubar"]), gp_state=d(gs))
+    torch.cuda.synchronize()
+    phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
+    nominal = default_quad_config()
+    for b in range(0, B, 9):
+        po, Ao, Bo = qoracle.rk4_sens(cfg, s["xbar"][b, 0], s["ubar"][b, 0], cfg.Ts, gpx=gs[b])
+        for got, ref in ((phi[b, 0], po), (A[b, 0], Ao), (Bm[b, 0], Bo)):
+            assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        assert np.abs(A[b, 0] - qoracle.rk4_sens(nominal, s["xbar"][b, 0], s["ubar"][b, 0], cfg.Ts)[1]).max() <= 1e-11
+        po, Ao, Bo = qoracle.rk4_sens(cfg, s["xbar"][b, 3], s["ubar"][b, 3], cfg.Ts)                  # later nodes: the integrated state
+        assert np.abs(A[b, 3] - Ao).max() <= 1e-11 * max(1.0, np.abs(Ao).max())
+    g0 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    g1 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], gp_state=s["x0"])
+    g2 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], gp_state=gs)
+    for a, b_ in zip(g0, g1):
+        np.testing.assert_array_equal(a, b_)
+    for g, kw in ((g0, {}), (g2, dict(gp_state=gs))):
+        o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8, **kw)
+        np.testing.assert_array_equal(g[3], o[3]); np.testing.assert_array_equal(g[4], o[4]); assert (o[3] == 0).all()
+        assert np.abs(g[1] - o[1]).max() <= 1e-8 and np.abs(g[0] - o[0]).max() <= 1e-8
+    assert np.abs(g0[1] - g2[1]).max() > 1e-6
+    eng.close()
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_linear_drag_on_the_device(qoracle, N):
+    """cfg.rdrv (quad_3d_optimizer.py:364-381): device shooting and solves with the drag term against the oracle, on the one-wave kernel
+    and on the two-wave kernel of the class's default horizon; the term really changes the answer."""
+    import torch
+    from ad_mpc_amd.engine import QuadBatchSolver
+    cfg = default_quad_config(N=N); cfg.rdrv[0], cfg.rdrv[1], cfg.rdrv[2] = -0.35, -0.25, -0.1
+    eng = QuadBatchSolver(cfg, device=0)
+    B = 48
+    s = random_quad_scenarios(B, cfg, seed=51)
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    phi, A, Bm = eng.shoot(d(s["xbar"]), d(s["ubar"]))
+    torch.cuda.synchronize()
+    phi, A, Bm = phi.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy()
+    for b in range(0, B, 7):
+        for k in (0, N // 2, N - 1):
+            po, Ao, Bo = qoracle.rk4_sens(cfg, s["xbar"][b, k], s["ubar"][b, k], cfg.Ts)
+            for got, ref in ((phi[b, k], po), (A[b, k], Ao), (Bm[b, k], Bo)):
+                assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    np.testing.assert_array_equal(g[3], o[3]); np.testing.assert_array_equal(g[4], o[4]); assert (o[3] == 0).all()
+    assert np.abs(g[1] - o[1]).max() <= 1e-8 and np.abs(g[0] - o[0]).max() <= 1e-8
+    base = qoracle.solve_batch(default_quad_config(N=N), s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
+    assert np.abs(base[1] - o[1]).max() > 1e-4
+    eng.close()
+
+
+def test_cluster_routing_of_the_quadrotor_ensemble(qoracle):
+    """One solver per GP cluster, chosen per solve from the reference state (quad_3d_optimizer.py:207, :446-452, :485-491; gp.py:738-770):
+    admpc_quad_select_cluster_batch against numpy's nearest centroid on the body-frame features (ties to the lower index), and
+    admpc_quad_solve_batch_routed: every instance equals the oracle's solve with the GPs of ITS cluster and differs from a neighbour's;
+    an out-of-range route fails with the iterate untouched.  The host class keeps one iterate per cluster as the reference's solvers do."""
+    import torch
+    from ad_mpc_amd.engine import QuadEnsembleBatchSolver
+    from ad_mpc_amd.quad_config import set_quad_gp
+    from ad_mpc_amd.quad_3d_optimizer import Quad3DOptimizer, QuadGPEnsemble, q_to_rot_mat
+    from test_quad_oracle import quad_gps
+    clusters = [quad_gps(seed=1), quad_gps(seed=2), quad_gps(seed=3)]
+    cent = np.array([[-1.0, 0.25], [0.5, 0.5], [2.0, 0.75]]); feats = [7, 13]          # body-frame v_x and the first rotor's input
+    cfg = default_quad_config()
+    ens = QuadEnsembleBatchSolver(cfg, clusters, cent, feats, device=0)
+    B = 96
+    s = random_quad_scenarios(B, cfg, seed=61)
+    rng = np.random.default_rng(6)
+    xs = s["x0"] + rng.standard_normal((B, QNX)); xs[:, 3:7] /= np.linalg.norm(xs[:, 3:7], axis=1, keepdims=True)
+    us = rng.uniform(0, 1, (B, QNU))
+    xs[0, 3:7] = [1, 0, 0, 0]; xs[0, 7] = -0.25; us[0, 0] = 0.375                    # equidistant from centroids 0 and 1: the lower index
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    route = ens.select(d(xs), d(us))
+    torch.cuda.synchronize()
+    route = route.cpu().numpy()
+    vb = np.array([q_to_rot_mat(xs[b, 3:7]).T @ xs[b, 7:10] for b in range(B)])
+    z = np.c_[vb[:, 0], us[:, 0]]
+    want = np.argmin(np.sqrt(((z[:, None, :] - cent[None]) ** 2).sum(2)), axis=1)
+    np.testing.assert_array_equal(route, want)
+    assert route[0] == 0 and len(np.unique(route)) == 3
+    r2 = route.copy(); r2[5] = 7; r2[6] = -1
+    xb, ub = d(s["xbar"]).clone(), d(s["ubar"]).clone()
+    cost = torch.empty(B, dtype=torch.float64, device="cuda"); st = torch.empty(B, dtype=torch.int32, device="cuda"); it = torch.empty_like(st)
+    ens.solve(d(r2.astype(np.int32)), d(s["x0"]), d(s["yref"]), d(s["yref_e"]), xb, ub, cost, st, it)
+    torch.cuda.synchronize()
+    xg, ug, stg, itg, cg = xb.cpu().numpy(), ub.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), cost.cpu().numpy()
+    assert stg[5] == 4 and stg[6] == 4 and np.isinf(cg[[5, 6]]).all() and np.array_equal(ug[[5, 6]], s["ubar"][[5, 6]]) and np.array_equal(xg[[5, 6]], s["xbar"][[5, 6]])
+    sol = []
+    for c in range(3):
+        cc = cfg.copy(); set_quad_gp(cc, clusters[c])
+        sol.append(qoracle.solve_batch(cc, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8))
+    ok = np.ones(B, dtype=bool); ok[[5, 6]] = False
+    for b in np.nonzero(ok)[0]:
+        o = sol[route[b]]
+        assert stg[b] == o[3][b] == 0 and itg[b] == o[4][b] and np.abs(ug[b] - o[1][b]).max() <= 1e-8 and np.abs(xg[b] - o[0][b]).max() <= 1e-8
+    other = np.array([np.abs(ug[b] - sol[(route[b] + 1) % 3][1][b]).max() for b in np.nonzero(ok)[0]])
+    assert np.median(other) > 1e-5
+    ens.close()
+    # the host class: set_reference_state returns the cluster of the target, run_optimization(use_model=...) runs that cluster's solver
+    opt = Quad3DOptimizer(None, t_horizon=1.0, n_nodes=10, gp_regressors=QuadGPEnsemble(clusters, cent, feats))
+    tgt = [[1.0, -2.0, 0.5], [1.0, 0, 0, 0], [2.2, 0.0, 0.0], [0, 0, 0]]
+    ind = opt.set_reference_state(tgt, [0.9, 0.2, 0.2, 0.2])
+    assert ind == 2
+    x0 = [0.2, 0.1, -0.3, 1, 0, 0, 0, 0.1, 0, 0, 0, 0, 0.1]
+    gst = [0.0, 0, 0, 1, 0, 0, 0, 0.6, -0.2, 0.1, 0, 0, 0]
+    w, x = opt.run_optimization(x0, use_model=ind, return_x=True, gp_regression_state=gst)
+    cc = cfg.copy(); set_quad_gp(cc, clusters[2])
+    o = qoracle.solve_batch(cc, np.array(x0)[None], opt.yref[2][None], opt.yref_e[2][None], np.zeros((1, 11, QNX)), np.zeros((1, 10, QNU)), gp_state=np.array(gst)[None])
+    assert opt.status == 0 and np.abs(w - o[1][0].reshape(-1)).max() <= 1e-8 and np.abs(x - o[0][0]).max() <= 1e-8
+    assert (opt.x_iter[0] == 0).all() and (opt.x_iter[2] != 0).any()                # the other clusters' iterates did not move

@@ -167,3 +167,72 @@ def test_quad_gp_residual_formula_and_sensitivities(qoracle):
             np.testing.assert_allclose(B[:, j], (qoracle.rk4_sens(cg, x, u + e, 0.1)[0] - qoracle.rk4_sens(cg, x, u - e, 0.1)[0]) / (2 * h), atol=5e-8)
     with pytest.raises(ValueError):
         set_quad_gp(default_quad_config(), [dict(feat=2, out=7, Z=[0.0], alpha=[0.0], length_scale=1.0)])      # position is not an offered feature
+
+
+def _fd_check(qoracle, cfg, x, u, gpx=None, atol=5e-8):
+    phi, A, B = qoracle.rk4_sens(cfg, x, u, 0.1, gpx=gpx)
+    h = 1e-6
+    for i in range(QNX):
+        e = np.zeros(QNX); e[i] = h
+        np.testing.assert_allclose(A[:, i], (qoracle.rk4_sens(cfg, x + e, u, 0.1, gpx=gpx)[0] - qoracle.rk4_sens(cfg, x - e, u, 0.1, gpx=gpx)[0]) / (2 * h), atol=atol)
+    for j in range(QNU):
+        e = np.zeros(QNU); e[j] = h
+        np.testing.assert_allclose(B[:, j], (qoracle.rk4_sens(cfg, x, u + e, 0.1, gpx=gpx)[0] - qoracle.rk4_sens(cfg, x, u - e, 0.1, gpx=gpx)[0]) / (2 * h), atol=atol)
+    return phi, A, B
+
+
+def test_linear_drag_term_formula_and_sensitivities(qoracle):
+    """quad_3d_optimizer.py:364-381 (rdrv_d_mat of the class; not in the shipped generated code, so pinned by a numpy restatement and
+    central differences): v' += R(q) D R(q)' v with D = diag(cfg.rdrv).  Zero D is the shipped model bit for bit."""
+    from ad_mpc_amd.quad_3d_optimizer import q_to_rot_mat
+    cfg = default_quad_config()
+    cd = default_quad_config(); cd.rdrv[0], cd.rdrv[1], cd.rdrv[2] = -0.3, -0.4, -0.1
+    rng = np.random.default_rng(4)
+    for trial in range(5):
+        x = rng.standard_normal(QNX); x[3:7] /= np.linalg.norm(x[3:7]); u = rng.uniform(0, 1, QNU)
+        R = q_to_rot_mat(x[3:7])
+        d = qoracle.f(cd, x, u) - qoracle.f(cfg, x, u)
+        assert np.abs(d[7:10] - R @ (np.diag([-0.3, -0.4, -0.1]) @ (R.T @ x[7:10]))).max() <= 1e-13 and np.abs(np.delete(d, [7, 8, 9])).max() == 0.0
+        _fd_check(qoracle, cd, x, u)
+    z = default_quad_config(); z.rdrv[0] = z.rdrv[1] = z.rdrv[2] = 0.0
+    assert np.array_equal(qoracle.rk4_sens(z, x, u, 0.1)[1], qoracle.rk4_sens(cfg, x, u, 0.1)[1])
+
+
+def test_first_node_gp_state_parameter(qoracle):
+    """quad_3d_optimizer.py:291-297, :546-552: at the first optimisation node the GP features and the rotation of the means come from a
+    PARAMETER (p = [gp_x, 1]; default: the initial state), at the other nodes from the integrated state.  (a) value: the residual is
+    R(q_gp) mu(z(gp_x, u)) whatever x is; (b) the ERK4 sensitivities with the parameter held fixed match central differences -- the state
+    columns lose the GP's contribution, the input columns keep it; (c) an RTI step of the oracle uses x0 as the default GP state and a
+    different gp_state changes the step; without GPs the argument is ignored."""
+    from ad_mpc_amd.quad_config import set_quad_gp
+    from ad_mpc_amd.quad_3d_optimizer import q_to_rot_mat
+    cfg = default_quad_config(); gps = quad_gps()
+    cg = default_quad_config(); set_quad_gp(cg, gps)
+    rng = np.random.default_rng(12)
+    for trial in range(4):
+        x = rng.standard_normal(QNX); x[3:7] /= np.linalg.norm(x[3:7]); u = rng.uniform(0, 1, QNU)
+        gx = rng.standard_normal(QNX); gx[3:7] /= np.linalg.norm(gx[3:7])
+        R = q_to_rot_mat(gx[3:7])
+        z = np.concatenate([gx[:7], R.T @ gx[7:10], gx[10:], u])
+        mu = np.zeros(3)
+        for g in gps:
+            feats = np.atleast_1d(g["feat"]); Z = np.asarray(g["Z"]).reshape(len(g["alpha"]), -1)
+            ell = np.broadcast_to(np.atleast_1d(g["length_scale"]), (len(feats),))
+            mu[g["out"] - 7] += g["sigma_f"] * np.exp(-0.5 * (((z[feats] - Z) / ell) ** 2).sum(1)) @ g["alpha"] + g["ymean"]
+        d = qoracle.f(cg, x, u, gpx=gx) - qoracle.f(cfg, x, u)
+        assert np.abs(d[7:10] - R @ mu).max() <= 1e-13 and np.abs(np.delete(d, [7, 8, 9])).max() == 0.0
+        assert np.array_equal(qoracle.f(cg, x, u, gpx=x), qoracle.f(cg, x, u))             # same value when the parameter is the state ...
+        _, A_p, B_p = _fd_check(qoracle, cg, x, u, gpx=gx)
+        _, A_s, _ = qoracle.rk4_sens(cg, x, u, 0.1)
+        _, A_n, B_n = qoracle.rk4_sens(cfg, x, u, 0.1)
+        assert np.abs(A_p - A_n).max() <= 1e-12 and np.abs(A_s - A_n).max() > 1e-6          # ... but no state sensitivity through the GP
+        assert np.abs(B_p - B_n).max() > 1e-6                                                # the input feature (u_0 of the second GP) stays
+    s = random_quad_scenarios(6, cg, seed=3)
+    base = qoracle.solve_batch(cg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    same = qoracle.solve_batch(cg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], gp_state=s["x0"])
+    other = s["x0"].copy(); other[:, 7:10] += 1.5
+    moved = qoracle.solve_batch(cg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], gp_state=other)
+    assert np.array_equal(base[1], same[1]) and np.abs(base[1] - moved[1]).max() > 1e-6
+    n0 = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    n1 = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], gp_state=other)
+    assert np.array_equal(n0[1], n1[1])
