@@ -61,6 +61,10 @@ __device__ __forceinline__ unsigned long long f20_now() { unsigned long long t; 
 #define F20_DECL() unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = f20_now(); unsigned long long ph_last = ph_t0
 #define F20_STAMP(k) do { const unsigned long long t_ = f20_now(); ph_acc[k] += t_ - ph_last; ph_last = t_; } while (0)
 #define F20_FLUSH() do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_f20_ticks[q_], ph_acc[q_]); atomicAdd(&g_f20_ticks[8], f20_now() - ph_t0); atomicMax(&g_f20_ticks[9], f20_now() - ph_t0); } } while (0)
+#elif defined(F20_MARKS)      // listing with phase markers for scripts/asm_phase_stats.py (hipcc -S -DF20_MARKS): the code after stamp k is phase k + 1
+#define F20_DECL() do { } while (0)
+#define F20_STAMP(k) asm volatile("; MARK_after" #k)
+#define F20_FLUSH() do { } while (0)
 #else
 #define F20_DECL() do { } while (0)
 #define F20_STAMP(k) do { } while (0)
@@ -129,6 +133,12 @@ struct FusedLds {
 #define F20_PRIO_IT1 2
 #define F20_PRIO_IT2 4
 #endif
+#ifndef F20_CLASS_PRIO
+#define F20_CLASS_PRIO 0
+#endif
+#ifndef F20_PAIR_REV
+#define F20_PAIR_REV 0
+#endif
 #define F20_NB 64
 #define F20_BINS0 64
 #define F20_HDR 128
@@ -166,6 +176,9 @@ __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig*
 // down.  First ticket = block index (2048 simultaneous atomics on one word queue up for ~20 us), later ones from the counter.
 __device__ __forceinline__ int f20_next(int* __restrict__ sched, int cap, bool first, int lane) {
     int t = blockIdx.x;
+#if F20_PAIR_REV        // experiment: the second wave of a SIMD takes the EASIEST of the first round's tickets (block b + G/2 shares the SIMD of block b)
+    if (t >= (int)gridDim.x / 2) t = (int)gridDim.x + (int)gridDim.x / 2 - 1 - t;
+#endif
     if (!first) {
         int v = 0;
         if (lane == 0) v = atomicAdd(sched, 1);
@@ -296,6 +309,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
     for (;;) {
         LAUNDER_LANE(lane0);
         const int inst = f20_next(sched, cap, first_ticket, lane0);
+#if F20_CLASS_PRIO
+        const bool first_class = first_ticket && (int)blockIdx.x < (int)gridDim.x / 2;
+#endif
         first_ticket = false;
         if (inst < 0) break;
         F20_TRACE_BEGIN();
@@ -808,9 +824,17 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 // An instance that is still iterating is on its way to becoming the batch's straggler: give its wave the issue slots of the
                 // SIMD it shares (the partner is a fresh instance of the second round, which is not on anybody's critical path)
 #ifndef F20_NO_PRIO
+#if F20_CLASS_PRIO == 1        // experiment: the first-round first wave of a SIMD (predicted hardest 1024) one level above its partner
+                if (first_class) { if (it == 0) __builtin_amdgcn_s_setprio(2); if (it == 2) __builtin_amdgcn_s_setprio(3); }
+                else { if (it == 0) __builtin_amdgcn_s_setprio(1); if (it == 3) __builtin_amdgcn_s_setprio(2); if (it == 6) __builtin_amdgcn_s_setprio(3); }
+#elif F20_CLASS_PRIO == 2      // experiment: first class at 3 from its first iteration, the others capped at 2
+                if (first_class) { if (it == 0) __builtin_amdgcn_s_setprio(3); }
+                else { if (it == 0) __builtin_amdgcn_s_setprio(1); if (it == 3) __builtin_amdgcn_s_setprio(2); }
+#else
                 if (it == F20_PRIO_IT0) __builtin_amdgcn_s_setprio(1);
                 if (it == F20_PRIO_IT1) __builtin_amdgcn_s_setprio(2);
                 if (it == F20_PRIO_IT2) __builtin_amdgcn_s_setprio(3);
+#endif
 #endif
                 int lz = lane;                          // laundered lane id: per-lane addresses / predicates derived from it are recomputed in
                 asm volatile("" : "+v"(lz));            // place instead of being hoisted out of the loops

@@ -82,6 +82,63 @@ def measured_traffic(N, B, dtype):
     return best
 
 
+def live_traffic(argv, timeout_s=150):
+    """HBM bytes of one step measured NOW, for this run's own workload: two child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE in passes of their own: the TCC counters share slots -- MI355X_MICROARCH.md, HBM section; FETCH_SIZE is
+    in KiB and doubled on gfx950, WRITE_SIZE in KiB), 3 steps each, no side measurements, summed over the kernels of a step and
+    divided by the number of steps.  Counters cannot be read inside the timed process.  None when rocprofv3 is missing or a pass fails
+    (the committed summary of the same workload is reported instead, labelled by `traffic_source`)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None
+    steps, warm = 3, 1
+    keep = [a for a in argv if a not in ("--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic")]
+    out = []
+    i = 0
+    while i < len(keep):                                   # drop --steps / --warmup (and their values) of the parent
+        if keep[i] in ("--steps", "--warmup"):
+            i += 2; continue
+        if keep[i].startswith(("--steps=", "--warmup=")):
+            i += 1; continue
+        out.append(keep[i]); i += 1
+    child = [sys.executable, os.path.abspath(__file__)] + out + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic"]
+    tmp = tempfile.mkdtemp(prefix="admpc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    total = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            # the program itself directly behind `--` (no env / shell hop: the profiler's preloaded library has initialised the GPU)
+            r = subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            per_kernel = {}                                # kernel -> dispatch -> value (a counter row per XCD / SE instance is summed)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row["Kernel_Name"]
+                        if "admpc_" not in name or row["Counter_Name"] != ctr:
+                            continue
+                        per_kernel.setdefault(name, {}).setdefault(row["Dispatch_Id"], 0.0)
+                        per_kernel[name][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            if not per_kernel:
+                return None
+            # every launch of every admpc kernel of the run (warm-up included: all steps are alike) / number of steps
+            total[ctr] = sum(sum(v.values()) for v in per_kernel.values()) / float(steps + warm)
+        return {"bytes": total["FETCH_SIZE"] * 1024.0 * 2.0 + total["WRITE_SIZE"] * 1024.0,
+                "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (%d steps each)" % (steps + warm)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(cfg, scen, target_seconds=12.0):
     """Time the CPU oracle (OpenMP build of oracle/admpc_oracle.c) on the same workload, bounded sample."""
     from oracle.oracle import Oracle, build
@@ -186,6 +243,9 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true",
                     help="skip the side measurement `two_in_flight` (an extra field, never `value`): the same K steps with two solver handles on two "
                          "streams, so that the tail of one step's interior-point kernel overlaps the next step (single-process runs only)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child passes of this command (single-process runs; about a minute); "
+                         "the committed PMC summary of the same workload is reported instead")
     ap.add_argument("--dry-collective", choices=("gloo",), default=None,
                     help="rehearse the N > 1 launcher / rendezvous / sharding / arg-min record path on CPU ranks (no solve, no GPU)")
     args = ap.parse_args()
@@ -332,7 +392,12 @@ def main():
         trial = cfg.ipm_try_unconstrained != 0.0
         flops = algorithmic_flops_per_solve(N, mean_iters, trial) * B
         byts = algorithmic_bytes_per_solve(N, elem) * B
-        traffic = None if (args.gp or args.dynamic) else measured_traffic(N, B, args.dtype)
+        traffic = None
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)      # already under a profiler (scripts/profile*.sh): no nested passes
+        if not launched and not args.no_live_traffic and not profiled:
+            traffic = live_traffic(sys.argv[1:])
+        if traffic is None and not (args.gp or args.dynamic):
+            traffic = measured_traffic(N, B, args.dtype)
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
         peak_tf = FP32_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS

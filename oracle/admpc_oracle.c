@@ -460,6 +460,9 @@ static void ipm_cold_start(const AdmpcConfig* c, const StageQP* qp, IpmState* s)
     }
 }
 
+/* scripts/ only (predictor studies): per-iteration trace of one solve -- mu at the start of the iteration, the step length taken */
+static _Thread_local double* g_trace = 0; static _Thread_local int g_trace_cap = 0;
+
 /* Mehrotra predictor-corrector primal-dual IPM in residual (Newton-step) form.
  * returns number of IPM iterations, negative on numerical failure */
 static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWork* w, RicFactor* F)
@@ -602,6 +605,7 @@ static int ipm_solve(const AdmpcConfig* c, const StageQP* qp, IpmState* s, IpmWo
             alpha_prev = 1; step = 1e300; rmax_prev = 0; rstat = -1;
             continue;
         }
+        if (g_trace && it < g_trace_cap) { g_trace[2 * it] = (double)mu; g_trace[2 * it + 1] = (double)alpha; }
         alpha_prev = alpha;
         rstat = (1 - alpha) * rstat;
         step = 0;
@@ -954,4 +958,25 @@ int oracle_nlp_residuals(const AdmpcConfig* c, const double* x0, const double* y
     for (int i = 0; i < 4; ++i) res[i] = (double)r[i];
     free(W);
     return ADMPC_OK;
+}
+
+/* scripts/ only: the interior-point trace of one RTI step of one instance: trace [cap][2] = (mu, alpha) per iteration; returns the iteration count */
+int oracle_ipm_trace(const AdmpcConfig* c, const double* x0, const double* yref, const double* yref_e, double p,
+                     const double* xbar_in, const double* ubar_in, double* trace, int cap)
+{
+    if (!c || c->N < 2 || c->N > MAXN) return -1;
+    const int N = c->N;
+    Workspace* W = (Workspace*)malloc(sizeof(Workspace));
+    double* xb = (double*)malloc(sizeof(double) * (N + 1) * NX);
+    double* ub = (double*)malloc(sizeof(double) * N * NU);
+    if (!W || !xb || !ub) { free(W); free(xb); free(ub); return -1; }
+    memcpy(xb, xbar_in, sizeof(double) * (N + 1) * NX);
+    memcpy(ub, ubar_in, sizeof(double) * N * NU);
+    for (int i = 0; i < 2 * cap; ++i) trace[i] = 0;
+    g_trace = trace; g_trace_cap = cap;
+    int it = 0;
+    (void)rti_step(c, W, x0, yref, yref_e, p, xb, ub, &it, 0);
+    g_trace = 0; g_trace_cap = 0;
+    free(W); free(xb); free(ub);
+    return it;
 }
