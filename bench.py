@@ -425,6 +425,8 @@ def main():
                                     if fused else "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
                                     if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than one round of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
                          "kernel_ms": kern_ms,
+                         **({"peak_unpacked": FP64_PEAK_TFLOPS, "frac_unpacked": ach_tf / FP64_PEAK_TFLOPS,
+                             "peak_note": "157.3 TFLOP/s is the packed (v_pk_fma_f32) vector rate; kernel R issues unpacked v_fmac_f32 (DPP operands), whose rate is 78.6"} if f32 else {}),
                          "note": ("%s; roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"
                                   % ("vector FMAs, the condensed Hessian alone on v_mfma_f64_16x16x4_f64 tiles (2 %% of the arithmetic; the fp64 matrix peak equals the vector peak: profiles/r3/mfma_condense_ab.txt)"
                                      if fused else "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt)", "fp32" if f32 else "fp64", peak_tf))},
