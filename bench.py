@@ -60,7 +60,7 @@ def algorithmic_flops_per_solve(N, mean_ipm_iters, trial):
     return N * 4360.0 + N * 1900.0 * (mean_ipm_iters + (0.7 if trial else 0.0))
 
 
-def measured_traffic(N, B, dtype):
+def measured_traffic(N, B, dtype, variant=""):
     """HBM bytes of one step from the committed PMC passes (profiles/rN/*pmc_summary.json, written by scripts/profile.sh on
     the same workload: separate --pmc runs for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as the microarchitecture guide
     prescribes for gfx950).  Counters cannot be read inside this process; None unless a profile of exactly this workload exists."""
@@ -77,7 +77,7 @@ def measured_traffic(N, B, dtype):
             continue
         w = js.get("_workload", {"horizon": 20, "batch": 4096, "dtype": "f64"})      # round-1 summaries carry no tag: configs[1]
         t = js.get("_step_traffic")
-        if t and (w.get("horizon"), w.get("batch"), w.get("dtype")) == (N, B, dtype):
+        if t and (w.get("horizon"), w.get("batch"), w.get("dtype"), w.get("variant", "")) == (N, B, dtype, variant):
             best = {"bytes": t["bytes"], "source": os.path.relpath(f, ROOT)}
     return best
 
@@ -396,8 +396,8 @@ def main():
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)      # already under a profiler (scripts/profile*.sh): no nested passes
         if not launched and not args.no_live_traffic and not profiled:
             traffic = live_traffic(sys.argv[1:])
-        if traffic is None and not (args.gp or args.dynamic):
-            traffic = measured_traffic(N, B, args.dtype)
+        if traffic is None and not args.dynamic:
+            traffic = measured_traffic(N, B, args.dtype, "gp" if args.gp else "")
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gbs = byts / (kern_ms * 1e-3) / 1e9
         peak_tf = FP32_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS

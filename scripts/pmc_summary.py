@@ -21,8 +21,11 @@ def short(name):
 def main(dirs):
     workload = None
     if dirs and dirs[0].startswith("--workload="):            # --workload=N,B,dtype : tags the summary so that bench.py can match it
-        n, b, dt = dirs[0].split("=", 1)[1].split(",")
+        parts = dirs[0].split("=", 1)[1].split(",")            # N,B,dtype[,variant]   (variant: "gp" for the GP-residual workload)
+        n, b, dt = parts[:3]
         workload = {"horizon": int(n), "batch": int(b), "dtype": dt}
+        if len(parts) > 3 and parts[3]:
+            workload["variant"] = parts[3]
         dirs = dirs[1:]
     acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))     # kernel -> counter -> dispatch -> value
     for d in dirs:

@@ -15,7 +15,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACT
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -- python3 $ARGS > $out/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -- python3 $ARGS > $out/pw.log 2>&1
 cp $(ls $out/kt/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
-python3 scripts/pmc_summary.py --workload=$N,$B,$DT $out/p1 $out/p2 $out/pf $out/pw > $out/pmc_summary.json
+case " $* " in *" --gp "*) VAR=gp;; *) VAR="";; esac
+python3 scripts/pmc_summary.py --workload=$N,$B,$DT,$VAR $out/p1 $out/p2 $out/pf $out/pw > $out/pmc_summary.json
 find $out -name '*.csv' -size +1M -delete
 rm -rf $out/kt $out/p1 $out/p2 $out/pf $out/pw
 cat $out/bench.json
