@@ -311,27 +311,50 @@ def main():
     # on a side stream behind an event of the solve, so that the all-gather's latency (~ 70 us, a quarter of an N = 20 step) overlaps the
     # next step's solve; the cost array and the gather buffer alternate between two copies (a solve must not overwrite the costs the
     # side stream is still reducing).  Every arg-min of the K timed steps completes inside the timed region (device-wide synchronise).
-    gathered = [torch.empty((world, 2), dtype=torch.float64, device=eng.device) for _ in range(2)]
-    costs = [cost, torch.empty_like(cost)]
-    red = torch.cuda.Stream(device=eng.device, priority=-1) if launched else None      # high priority: its three tiny operations run at once (0.550 -> 0.520 ms/step at 8192 per GPU)
-    solved = [torch.cuda.Event() for _ in range(2)]
-    reduced = [None, None]
+    # The persistent solve kernel holds every register of the chip until it drains, so the three small operations of step i only get
+    # to run in the drain of step i + 1 (or behind it): with two copies the solve of step i + 2 waited for them (+ 17 us per step on
+    # one rank); four copies keep the main stream from ever waiting on the side stream.
+    NRING = 4
+    gathered = [torch.empty((world, 2), dtype=torch.float64, device=eng.device) for _ in range(NRING)]
+    costs = [cost] + [torch.empty_like(cost) for _ in range(NRING - 1)]
+    red_prio = int(os.environ.get("ADMPC_BENCH_RED_PRIO", "-1"))
+    red = torch.cuda.Stream(device=eng.device, priority=red_prio) if launched else None      # high priority: its three tiny operations run as soon as a CU has room
+    solved = [torch.cuda.Event() for _ in range(NRING)]
+    reduced = [None] * NRING
 
     def step(i, timed_idx=None):
-        c = costs[i & 1] if launched else cost
-        if launched and reduced[i & 1] is not None:
-            torch.cuda.current_stream().wait_event(reduced[i & 1])      # the reduction two steps back has read this copy
+        q = i % NRING
+        c = costs[q] if launched else cost
+        if launched and reduced[q] is not None:
+            # the reduction NRING steps back has read this copy.  Waited for on the HOST (it has long happened; the host runs several steps
+            # ahead): a cross-stream wait packet in front of every solve cost the main stream several microseconds per step
+            if os.environ.get("ADMPC_BENCH_DEVICE_WAIT") == "1": torch.cuda.current_stream().wait_event(reduced[q])
+            else: reduced[q].synchronize()
         if timed_idx is not None: ev0[timed_idx].record()
         eng.solve(x0, yref, yref_e, p, xb[i], ub[i], c, status, iters)
         if timed_idx is not None: ev1[timed_idx].record()
         if launched:
-            solved[i & 1].record()
-            with torch.cuda.stream(red):
-                red.wait_event(solved[i & 1])
-                best = adist.global_argmin_device(eng, c.double() if f32 else c, index_offset=rank * B, gathered=gathered[i & 1])
-                ev = torch.cuda.Event(); ev.record(red); reduced[i & 1] = ev
+            if timed_idx is not None: solved[q] = ev1[timed_idx]      # the timing event behind the solve doubles as the side stream's trigger: one marker packet less
+            else: solved[q] = torch.cuda.Event(); solved[q].record()
+            # The reduction of step i is handed to the side stream one step LATER, behind the enqueue of solve i + 1: issued at once its
+            # three operations become runnable exactly at the boundary between two solves and hold up the next solve's start (+ 17 us per
+            # step measured on one rank); one step behind they are runnable while solve i + 1 runs and go into its drain.
+            best = reduce_pending()
+            pending.append((q, c))
             return best
         return None
+
+    pending = []
+
+    def reduce_pending():
+        if not pending:
+            return None
+        q, c = pending.pop(0)
+        with torch.cuda.stream(red):
+            red.wait_event(solved[q])
+            best = adist.global_argmin_device(eng, c.double() if f32 else c, index_offset=rank * B, gathered=gathered[q])
+            ev = torch.cuda.Event(); ev.record(red); reduced[q] = ev
+        return best
 
     ranks_seen = 1
     if launched:                                  # what the collective itself counts: every rank adds one
@@ -343,6 +366,7 @@ def main():
             sys.exit(3)
     for i in range(Wm):
         step(i)
+    if launched: reduce_pending()
     torch.cuda.synchronize()
     if launched: dist.barrier()
     torch.cuda.synchronize()
@@ -350,6 +374,7 @@ def main():
     best = None
     for i in range(K):
         best = step(Wm + i, i)
+    if launched: best = reduce_pending()      # the arg-min of the last step: every one of the K reductions completes inside the timed region
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (launch-bound if close to `elapsed`)
     torch.cuda.synchronize()
     if launched: dist.barrier()
