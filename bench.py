@@ -82,6 +82,20 @@ def measured_traffic(N, B, dtype, variant=""):
     return best
 
 
+def traffic_child_args(argv, steps, warm):
+    """Command line of a PMC child pass: the parent's workload arguments, its own step counts, no side measurements, no nested passes."""
+    keep = [a for a in argv if a not in ("--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic")]
+    out = []
+    i = 0
+    while i < len(keep):                                   # drop --steps / --warmup (and their values) of the parent
+        if keep[i] in ("--steps", "--warmup"):
+            i += 2; continue
+        if keep[i].startswith(("--steps=", "--warmup=")):
+            i += 1; continue
+        out.append(keep[i]); i += 1
+    return out + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic"]
+
+
 def live_traffic(argv, timeout_s=150):
     """HBM bytes of one step measured NOW, for this run's own workload: two child runs of this script under `rocprofv3 --pmc`
     (FETCH_SIZE and WRITE_SIZE in passes of their own: the TCC counters share slots -- MI355X_MICROARCH.md, HBM section; FETCH_SIZE is
@@ -97,16 +111,7 @@ def live_traffic(argv, timeout_s=150):
     if rp is None:
         return None
     steps, warm = 3, 1
-    keep = [a for a in argv if a not in ("--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic")]
-    out = []
-    i = 0
-    while i < len(keep):                                   # drop --steps / --warmup (and their values) of the parent
-        if keep[i] in ("--steps", "--warmup"):
-            i += 2; continue
-        if keep[i].startswith(("--steps=", "--warmup=")):
-            i += 1; continue
-        out.append(keep[i]); i += 1
-    child = [sys.executable, os.path.abspath(__file__)] + out + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic"]
+    child = [sys.executable, os.path.abspath(__file__)] + traffic_child_args(argv, steps, warm)
     tmp = tempfile.mkdtemp(prefix="admpc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     total = {}

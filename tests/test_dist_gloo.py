@@ -130,3 +130,18 @@ def test_bench_starts_its_own_ranks_and_never_reports_fewer():
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
         assert r.returncode == 3 and r.stdout.strip() == b"" and b"refusing" in r.stderr
+
+
+def test_bench_traffic_bookkeeping():
+    """bench.py's roofline.traffic plumbing (no GPU): the PMC child passes inherit the workload arguments and nothing else (own step
+    counts, no side measurements, no nested passes), and a committed summary only stands in for the workload it was taken on -- the GP
+    summary is tagged and never matches the plain N = 20 line (it once did: 73 MB reported for a 24 MB step)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    got = bench.traffic_child_args(["--steps", "20", "--warmup=5", "--horizon", "40", "--gp", "--no-cpu-baseline", "--batch-per-gpu", "8192"], 3, 1)
+    assert got == ["--horizon", "40", "--gp", "--batch-per-gpu", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic"]
+    plain, gp = bench.measured_traffic(20, 4096, "f64"), bench.measured_traffic(20, 4096, "f64", "gp")
+    assert plain and gp and "gp" not in os.path.basename(plain["source"]) and os.path.basename(gp["source"]).startswith("gp")
+    assert plain["bytes"] < 3 * 4096 * bench.algorithmic_bytes_per_solve(20) < gp["bytes"] * 3
+    assert bench.measured_traffic(20, 4097, "f64") is None
