@@ -101,9 +101,15 @@ IPM_THR0 = 0.1
 IPM_WARM_THR = 0.01
 IPM_WARM_RESTART = 0.1
 IPM_FALLBACK_ITER = 30.0
-IPM_TOL_COMP = 1e-10
-IPM_TOL_RES = 1e-9
-IPM_TOL_STEP = 1e-6
+# Stopping levels of the interior point.  Default: the reference's own -- it leaves the QP tolerances unset (acados_models/sim_car_acados_ocp.json:
+# qp_solver_tol_* null) and runs HPIPM in mode BALANCE (c_generated_code/acados_solver_sim_car.c:688): every residual norm, the
+# complementarity products included, <= 1e-8, and no test on the step.  TIGHT: the levels of rounds 1-2 (complementarity 1e-10, residual 1e-9,
+# last input step 1e-6), which take an instance with a nearly degenerate bound pair to within 1e-8 of the exact minimiser (the reference's
+# levels leave such an instance up to ~1e-4 away from it: the error of a degenerate pair is sqrt(mu)); `tight_ipm(cfg)` sets them.
+IPM_TOL_COMP = 1e-8
+IPM_TOL_RES = 1e-8
+IPM_TOL_STEP = 1e30
+IPM_TIGHT = (1e-10, 1e-9, 1e-6)
 
 
 def default_config(N=20, Ts=0.05, q=Q_DIAG_ROS, r=R_DIAG_ROS, terminal_scale=TERMINAL_SCALE, sqp_iters=1, sqp_tol=0.0):
@@ -164,3 +170,14 @@ def set_gp(cfg, gps):
         for i in range(GP_MAX_POINTS):
             s.alpha[i] = float(al[i]) if i < al.size else 0.0
     return cfg
+
+
+def tight_ipm(cfg):
+    """The interior point's stopping levels of rounds 1-2 (in place; returns cfg): every instance to within 1e-8 of the exact minimiser."""
+    cfg.ipm_tol_comp, cfg.ipm_tol_res, cfg.ipm_tol_step = IPM_TIGHT
+    return cfg
+
+
+def tight_config(*a, **kw):
+    """default_config with the tight stopping levels (tests that compare with exact minimisers, iteration-count tables of rounds 1-2)."""
+    return tight_ipm(default_config(*a, **kw))

@@ -1363,7 +1363,7 @@ int admpc_default_config(AdmpcConfig* c, int N, double Ts)
     c->mass = mass; c->L_F = Lw * (1 - f_mass / mass); c->L_R = Lw * (1 - r_mass / mass);
     c->Iz = c->L_F * c->L_R * (r_mass + f_mass);
     c->Cf = f_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195; c->Cr = r_mass * 0.5 * 9.81 * 0.165 * 180 / 3.14195;
-    c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9; c->ipm_tol_step = 1e-6;
+    c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-8; c->ipm_tol_res = 1e-8; c->ipm_tol_step = 1e30;      // HPIPM BALANCE's levels (the reference's setting), no step test; admpc.h
     c->ipm_try_unconstrained = 1.0; c->ipm_warm_thr = 0.01; c->ipm_warm_restart = 0.1; c->ipm_fallback_iter = 30.0;
     return ADMPC_OK;
 }

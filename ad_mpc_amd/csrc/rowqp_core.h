@@ -1006,7 +1006,10 @@ RQ_FN void rq_make_params(const Cfg& c, RqParams<T>& q)
     q.thr = (T)c.ipm_thr0; q.thw = (T)c.ipm_warm_thr; q.mu0 = (T)c.ipm_mu0;
     q.tol_comp = (T)(f32 && c.ipm_tol_comp < 1e-3 ? 1e-3 : c.ipm_tol_comp);
     q.tol_res = (T)(f32 && c.ipm_tol_res < 1e-2 ? 1e-2 : c.ipm_tol_res);
-    q.tol_step = (T)(f32 && c.ipm_tol_step < 1e-3 ? 1e-3 : c.ipm_tol_step);
+    // fp32 ALWAYS tests the step (its complementarity / residual levels are stop levels, not accuracy targets: the accuracy of the float
+    // path comes from the step test) -- at the configured level when that is looser than 1e-3 but a real level (<= 1), else at 1e-3;
+    // fp64: as configured (default: off, 1e30 -- HPIPM, whose BALANCE levels the defaults are, has none)
+    q.tol_step = (T)(f32 ? ((c.ipm_tol_step < 1e-3 || c.ipm_tol_step > 1.0) ? 1e-3 : c.ipm_tol_step) : c.ipm_tol_step);
     q.inv_nineq = (T)(1.0 / (double)(8 * c.N + 2 * (c.N - 1)));
     q.big = f32 ? (T)1e30 : (T)1e300;
     q.floor_ = f32 ? (T)1e-8 : (T)1e-40;

@@ -84,7 +84,7 @@ def measured_traffic(N, B, dtype, variant=""):
 
 def traffic_child_args(argv, steps, warm):
     """Command line of a PMC child pass: the parent's workload arguments, its own step counts, no side measurements, no nested passes."""
-    keep = [a for a in argv if a not in ("--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic")]
+    keep = [a for a in argv if a not in ("--no-cpu-baseline", "--no-two-in-flight", "--no-tight-stop", "--no-live-traffic")]
     out = []
     i = 0
     while i < len(keep):                                   # drop --steps / --warmup (and their values) of the parent
@@ -93,7 +93,7 @@ def traffic_child_args(argv, steps, warm):
         if keep[i].startswith(("--steps=", "--warmup=")):
             i += 1; continue
         out.append(keep[i]); i += 1
-    return out + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic"]
+    return out + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-two-in-flight", "--no-tight-stop", "--no-live-traffic"]
 
 
 def live_traffic(argv, timeout_s=150):
@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true",
                     help="skip the side measurement `two_in_flight` (an extra field, never `value`): the same K steps with two solver handles on two "
                          "streams, so that the tail of one step's interior-point kernel overlaps the next step (single-process runs only)")
+    ap.add_argument("--no-tight-stop", action="store_true", help="skip the side measurement `tight_stop` (the same steps at the tight stop levels of rounds 1-2)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child passes of this command (single-process runs; about a minute); "
                          "the committed PMC summary of the same workload is reported instead")
@@ -309,8 +310,9 @@ def main():
     cost = torch.empty(B, dtype=tdt, device=eng.device)
     status = torch.empty(B, dtype=torch.int32, device=eng.device)
     iters = torch.empty(B, dtype=torch.int32, device=eng.device)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    # HIP events around the timed region (on the launch stream): step time by the device's clock = elapsed / K.  (Two events PER STEP, as in
+    # rounds 1-2, put two marker packets between consecutive solves: 8 us of a 0.23 ms step.)
+    ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     # config 4: per-GPU arg-min, 16 B/rank all-gather over RCCL, second-level arg-min -- three device operations, no host sync.  They run
     # on a side stream behind an event of the solve, so that the all-gather's latency (~ 70 us, a quarter of an N = 20 step) overlaps the
@@ -335,12 +337,9 @@ def main():
             # ahead): a cross-stream wait packet in front of every solve cost the main stream several microseconds per step
             if os.environ.get("ADMPC_BENCH_DEVICE_WAIT") == "1": torch.cuda.current_stream().wait_event(reduced[q])
             else: reduced[q].synchronize()
-        if timed_idx is not None: ev0[timed_idx].record()
         eng.solve(x0, yref, yref_e, p, xb[i], ub[i], c, status, iters)
-        if timed_idx is not None: ev1[timed_idx].record()
         if launched:
-            if timed_idx is not None: solved[q] = ev1[timed_idx]      # the timing event behind the solve doubles as the side stream's trigger: one marker packet less
-            else: solved[q] = torch.cuda.Event(); solved[q].record()
+            solved[q].record()                                         # the side stream's trigger (the only marker packet of a step)
             # The reduction of step i is handed to the side stream one step LATER, behind the enqueue of solve i + 1: issued at once its
             # three operations become runnable exactly at the boundary between two solves and hold up the next solve's start (+ 17 us per
             # step measured on one rank); one step behind they are runnable while solve i + 1 runs and go into its drain.
@@ -377,8 +376,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     best = None
+    ev_begin.record()
     for i in range(K):
         best = step(Wm + i, i)
+    ev_end.record()
     if launched: best = reduce_pending()      # the arg-min of the last step: every one of the K reductions completes inside the timed region
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (launch-bound if close to `elapsed`)
     torch.cuda.synchronize()
@@ -390,7 +391,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    kern_ms = float(ev_begin.elapsed_time(ev_end)) / K      # the step's kernels and the gaps between them, by the device's clock
     it_host = iters.cpu().numpy(); st_host = status.cpu().numpy()
     two = None
     try:
@@ -415,6 +416,28 @@ def main():
           del eng2
     except Exception as e:                      # a side measurement: never a reason to lose the bench line
         two = {"error": repr(e)}
+    # the same K steps at the tight stop levels of rounds 1-2 (every instance to within 1e-8 of the exact minimiser): a side measurement
+    tight = None
+    try:
+        if not args.no_tight_stop and not launched:
+            from ad_mpc_amd.config import tight_ipm
+            engt = BatchSolver(tight_ipm(cfg.copy()), device=dev_index)
+            itt = torch.empty_like(iters); stt = torch.empty_like(status)
+            xbt = [xinit.clone() for _ in range(K + Wm)]; ubt = [uinit.clone() for _ in range(K + Wm)]
+            for i in range(Wm):
+                engt.solve(x0, yref, yref_e, p, xbt[i], ubt[i], cost, stt, itt)
+            torch.cuda.synchronize(); tt0 = time.perf_counter()
+            for i in range(Wm, Wm + K):
+                engt.solve(x0, yref, yref_e, p, xbt[i], ubt[i], cost, stt, itt)
+            torch.cuda.synchronize(); dtt = time.perf_counter() - tt0
+            ith = itt.cpu().numpy()
+            tight = {"ms_per_step": dtt / K * 1e3, "solves_per_s": B * K / dtt, "mean_ipm_iters": float(ith.mean()), "max_ipm_iters": int(ith.max()),
+                     "status_nonzero": int((stt.cpu().numpy() != 0).sum()),
+                     "max_abs_input_difference_to_the_timed_run": float((ubt[Wm + K - 1] - ub[Wm + K - 1]).abs().max()),
+                     "levels": "complementarity 1e-10, residuals 1e-9, last input step 1e-6"}
+            del engt
+    except Exception as e:
+        tight = {"error": repr(e)}
     mean_iters = float(it_host.mean())
     if rank == 0:
         total = world * B * K
@@ -447,6 +470,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl + ", one SQP-RTI step" + (", dynamic branch (blend 3/5)" if args.dynamic else ""),
                        "batch_per_gpu": B, "horizon": N, "seed": 1234,
+                       "qp_stop": "the reference's: HPIPM mode BALANCE, every residual norm and the complementarity products <= 1e-8, no step test "
+                                  "(acados_solver_sim_car.c:688; qp_solver_tol_* unset)" + ("; fp32: floored at 1e-2 / 1e-3 and a step test at 1e-3" if f32 else ""),
                        "collective": "RCCL all-gather arg-min (16 B/rank)" if launched else "none"},
             "roofline": {"bound": "fp32-valu" if f32 else "fp64-valu", "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": ach_tf / peak_tf, "traffic": (traffic or {}).get("bytes"),
@@ -455,6 +480,7 @@ def main():
                                     if fused else "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
                                     if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than one round of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
                          "kernel_ms": kern_ms,
+                         "kernel_ms_is": "HIP-event time over the K timed steps on the launch stream / K: the kernels of a step and the gaps between them (the dominant kernel's own average duration: the rocprofv3 kernel trace under profiles/)",
                          **({"peak_unpacked": FP64_PEAK_TFLOPS, "frac_unpacked": ach_tf / FP64_PEAK_TFLOPS,
                              "peak_note": "157.3 TFLOP/s is the packed (v_pk_fma_f32) vector rate; kernel R issues unpacked v_fmac_f32 (DPP operands), whose rate is 78.6"} if f32 else {}),
                          "note": ("%s; roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"
@@ -467,6 +493,8 @@ def main():
         }
         if two is not None:
             out["two_in_flight"] = two
+        if tight is not None:
+            out["tight_stop"] = tight
         if best is not None:
             bc, bidx = adist.unpack_pair(best)
             out["argmin"] = {"cost": bc, "index": bidx}

@@ -10,8 +10,11 @@ for a in "--gp" "--dynamic" "--batch-per-gpu 8192" "--batch-per-gpu 16384" "--ho
   timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 $a > "$out/bench_$(echo $a | tr -d ' -').json" 2>/dev/null
 done
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_launched_1rank.json 2> $out/bench_launched.err
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --batch-per-gpu 8192 > $out/bench_launched_1rank_b8192.json 2>> $out/bench_launched.err
+ADMPC_N20=split timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $out/bench_split_pipeline.json 2>/dev/null
 timeout -k 10 300 python3 scripts/bench_quad.py 4096 > $out/bench_quad.txt 2>&1
 timeout -k 10 900 python3 scripts/gpu_parity_census.py 5 > $out/census.txt 2>&1
+timeout -k 10 900 python3 scripts/gpu_parity_census.py 3 tight > $out/census_tight.txt 2>&1
 bash scripts/profile_r3.sh final/n20 20 4096 f64 > $out/n20_profile.log 2>&1
 python3 - <<'PY' > gpurun_out/final/gp40_diag.txt 2>&1
 # the one census family above the test tolerance: N = 40 with the GP residual -- where does max |dx| come from?

@@ -10,12 +10,17 @@ from ad_mpc_amd.engine import BatchSolver
 from ad_mpc_amd.scenarios import random_scenarios, grid_gp
 
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+TIGHT = len(sys.argv) > 2 and sys.argv[2] == "tight"       # the tight stop levels of rounds 1-2 instead of the default (the reference's HPIPM BALANCE levels)
+print("interior-point stop levels: %s" % ("tight (1e-10 / 1e-9 / step 1e-6)" if TIGHT else "default = the reference's (1e-8 / 1e-8 / no step test)"), flush=True)
 o = Oracle(omp=True)
 nth = min(64, os.cpu_count() or 8)
 total = 0
 for N, B, dt, gp in ((20, 4096, np.float64, False), (20, 4096, np.float64, True), (20, 8192, np.float64, False), (40, 4096, np.float64, False), (40, 4096, np.float64, True),
                      (40, 8192, np.float64, False), (80, 2048, np.float64, False), (80, 8192, np.float64, False), (128, 1024, np.float64, False), (80, 16384, np.float32, False)):
     cfg = default_config(N=N)
+    if TIGHT:
+        from ad_mpc_amd.config import tight_ipm
+        tight_ipm(cfg)
     if gp:
         set_gp(cfg, grid_gp())              # BASELINE configs[2]: GP residual-dynamics correction active
     eng = BatchSolver(cfg, device=0)

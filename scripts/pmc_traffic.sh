@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
 lib=$1; shift; export TMPDIR=/tmp
 out=gpurun_out/traffic_$lib; rm -rf $out; mkdir -p $out
-ARGS="scripts/bench_lib.py $lib --steps 5 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-live-traffic $*"
+ARGS="scripts/bench_lib.py $lib --steps 5 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-tight-stop --no-live-traffic $*"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -- python3 $ARGS > $out/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -- python3 $ARGS > $out/pw.log 2>&1
 python3 scripts/pmc_summary.py $out/pf $out/pw | python3 -c "

@@ -7,7 +7,7 @@
 set -e
 tag=$1; N=$2; B=$3; DT=$4; shift 4
 out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-live-traffic --horizon $N --batch-per-gpu $B --dtype $DT $*"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-tight-stop --no-live-traffic --horizon $N --batch-per-gpu $B --dtype $DT $*"
 python3 bench.py --steps 20 --warmup 5 --no-live-traffic --horizon $N --batch-per-gpu $B --dtype $DT $* > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $ARGS > $out/kt.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/p1 -- python3 $ARGS > $out/p1.log 2>&1

@@ -140,7 +140,7 @@ def test_bench_traffic_bookkeeping():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     got = bench.traffic_child_args(["--steps", "20", "--warmup=5", "--horizon", "40", "--gp", "--no-cpu-baseline", "--batch-per-gpu", "8192"], 3, 1)
-    assert got == ["--horizon", "40", "--gp", "--batch-per-gpu", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-two-in-flight", "--no-live-traffic"]
+    assert got == ["--horizon", "40", "--gp", "--batch-per-gpu", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-two-in-flight", "--no-tight-stop", "--no-live-traffic"]
     plain, gp = bench.measured_traffic(20, 4096, "f64"), bench.measured_traffic(20, 4096, "f64", "gp")
     assert plain and gp and "gp" not in os.path.basename(plain["source"]) and os.path.basename(gp["source"]).startswith("gp")
     assert plain["bytes"] < 3 * 4096 * bench.algorithmic_bytes_per_solve(20) < gp["bytes"] * 3

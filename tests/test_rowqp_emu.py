@@ -5,7 +5,7 @@ The linearisation fed to it is packed from the oracle's RK4 exactly as the linea
 import numpy as np
 import pytest
 
-from ad_mpc_amd.config import default_config
+from ad_mpc_amd.config import tight_config, default_config
 from ad_mpc_amd.scenarios import random_scenarios, straight_scenario, assemble
 
 
@@ -67,17 +67,17 @@ def test_emulated_kernel_abandons_a_blocked_warm_start(emu, oracle):
     (b) the default 0.1 on the N = 80 instances it exists for -- they restart (the oracle needs fewer iterations than with the rule
     off) and the emulated kernel follows iteration for iteration."""
     for N, B in ((20, 48), (40, 24)):
-        c = default_config(N=N); c.ipm_warm_restart = 0.99
+        c = tight_config(N=N); c.ipm_warm_restart = 0.99
         s = random_scenarios(B, N=N, seed=21, blend=(3.0, 5.0))
         g, o = _both(emu, oracle, c, s)
-        off = default_config(N=N); off.ipm_warm_restart = 0.0
+        off = tight_config(N=N); off.ipm_warm_restart = 0.0
         assert (oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])[4] != o[4]).sum() >= 5   # the rule really fires
         _strict(g, o, 1e-8 if N <= 32 else 1e-7)
     N = 80
     s = random_scenarios(2048, N=N, seed=1234)
     idx = [107, 119, 223, 924, 103, 5]
     s = {k: v[idx] for k, v in s.items()}
-    c = default_config(N=N); off = c.copy(); off.ipm_warm_restart = 0.0
+    c = tight_config(N=N); off = c.copy(); off.ipm_warm_restart = 0.0
     assert c.ipm_warm_restart == 0.1
     g, o = _both(emu, oracle, c, s)
     slow = oracle.solve_batch(off, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
@@ -100,17 +100,17 @@ def test_emulated_kernel_fallback_mode(emu, oracle):
     term) on a short and a long horizon -- rows of one wave enter the mode at different times or not at all; (b) the default 30 on
     the instances it exists for: without it they cycle until iter_max, with it they converge to the minimiser a conservative run finds."""
     for N, B in ((20, 48), (40, 24)):
-        c = default_config(N=N); c.ipm_fallback_iter = 3.0
+        c = tight_config(N=N); c.ipm_fallback_iter = 3.0
         s = random_scenarios(B, N=N, seed=33, blend=(3.0, 5.0))
         g, o = _both(emu, oracle, c, s)
         assert (o[4] > 3).sum() >= B // 4 and (o[4] <= 3).sum() >= 1
-        ref = oracle.solve_batch(default_config(N=N), s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        ref = oracle.solve_batch(tight_config(N=N), s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
         assert np.abs(ref[1] - o[1]).max() <= 1e-7                 # the same minimiser by the other route
         _strict(g, o, 1e-8 if N <= 32 else 1e-7)
     for N, B, kw, seed, idx, its in CYCLING[:2]:
         s = random_scenarios(B, N=N, seed=seed, **kw)
         s = {k: v[[idx, 3]] for k, v in s.items()}
-        c = default_config(N=N); assert c.ipm_fallback_iter == 30.0
+        c = tight_config(N=N); assert c.ipm_fallback_iter == 30.0
         g, o = _both(emu, oracle, c, s)
         assert o[4][0] == its and o[4][1] < 30
         off = c.copy(); off.ipm_fallback_iter = 0.0
