@@ -907,7 +907,7 @@ void admpc_quad_default_config(AdmpcQuadConfig* c)
     const double h = cos(M_PI / 4) * (0.47 / 2);
     const double xf[4] = { h, -h, -h, h }, yf[4] = { -h, -h, h, h }, zt[4] = { -0.013, 0.013, -0.013, 0.013 };
     for (int i = 0; i < 4; ++i) { c->x_f[i] = xf[i]; c->y_f[i] = yf[i]; c->z_l_tau[i] = zt[i]; }
-    c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-10; c->ipm_tol_res = 1e-9;
+    c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-8; c->ipm_tol_res = 1e-8;      // HPIPM mode BALANCE, the reference's setting
 }
 
 int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** out)

@@ -45,7 +45,8 @@ def default_quad_config(N=10, t_horizon=1.0):
     h = math.cos(math.pi / 4) * (0.47 / 2)
     for i, (xf, yf, zt) in enumerate(zip((h, -h, -h, h), (-h, -h, h, h), (-0.013, 0.013, -0.013, 0.013))):
         c.x_f[i], c.y_f[i], c.z_l_tau[i] = xf, yf, zt
-    c.ipm_mu0, c.ipm_thr0, c.ipm_tol_comp, c.ipm_tol_res = 1.0, 0.1, 1e-10, 1e-9
+    c.ipm_mu0, c.ipm_thr0 = 1.0, 0.1
+    c.ipm_tol_comp, c.ipm_tol_res = 1e-8, 1e-8      # the reference's levels: HPIPM mode BALANCE (acados_models/my_quad_acados_ocp.json leaves qp_solver_tol_* unset); tight_quad_ipm: 1e-10 / 1e-9
     return c
 
 
@@ -65,3 +66,13 @@ def set_quad_gp(cfg, gps):
         C.memmove(C.byref(cfg.gp[g]), C.byref(tmp.gp[g]), C.sizeof(AdmpcGp))
     cfg.n_gp = len(gps)
     return cfg
+
+
+def tight_quad_ipm(cfg):
+    """The stop levels of earlier rounds (complementarity 1e-10, residual 1e-9), in place; returns cfg."""
+    cfg.ipm_tol_comp, cfg.ipm_tol_res = 1e-10, 1e-9
+    return cfg
+
+
+def tight_quad_config(*a, **kw):
+    return tight_quad_ipm(default_quad_config(*a, **kw))

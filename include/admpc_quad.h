@@ -57,7 +57,8 @@ typedef struct AdmpcQuadConfig {
     double  g;                    /* 9.81                                                                          */
     double  rdrv[3];              /* diagonal of Faessler's linear rotor-drag matrix D (quad_3d_optimizer.py:364-381, rdrv_d_mat of the
                                    * class): v' += R(q) D R(q)' v.  Zeros (the shipped generated code, default): no drag term.     */
-    double  ipm_mu0, ipm_thr0, ipm_tol_comp, ipm_tol_res; /* interior point: start and stop levels                 */
+    double  ipm_mu0, ipm_thr0, ipm_tol_comp, ipm_tol_res; /* interior point: start and stop levels (defaults 1e-8 / 1e-8: HPIPM
+                                                           * mode BALANCE, what the reference runs; 1e-10 / 1e-9 for the exact minimiser) */
     /* GP residual of the acceleration (quad_3d_optimizer.py:289-327): the features are taken from z = [x with the velocity in the
      * BODY frame; u] (feat[] indexes these 17 entries; 7..16 are offered: body-frame velocity, body rates, inputs), gp[g].out in {7, 8, 9} names the body-frame acceleration component the mean
      * is added to; the sum is rotated back to the world frame:  v' += R(q) mu(z).  n_gp = 0: nominal model (the shipped code). */

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from ad_mpc_amd.quad_config import default_quad_config, QNX, QNU
+from ad_mpc_amd.quad_config import default_quad_config, tight_quad_config, QNX, QNU
 from ad_mpc_amd.quad_scenarios import random_quad_scenarios
 
 pytestmark = pytest.mark.gpu
@@ -71,7 +71,7 @@ def test_quad_fallback_mode_on_the_device(qoracle, monkeypatch, generic):
     cycling instance (3012; 47 iterations with the fallback) -- every instance, iteration for iteration with the oracle."""
     from ad_mpc_amd.engine import QuadBatchSolver
     monkeypatch.setenv("ADMPC_QUAD_GENERIC", generic)
-    cfg = default_quad_config()
+    cfg = tight_quad_config()
     eng = QuadBatchSolver(cfg, device=0)
     s = random_quad_scenarios(4096, cfg, seed=202)
     if generic == "1":

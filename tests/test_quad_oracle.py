@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from ad_mpc_amd.quad_config import default_quad_config, QNX, QNU
+from ad_mpc_amd.quad_config import default_quad_config, tight_quad_config, QNX, QNU
 from ad_mpc_amd.quad_scenarios import random_quad_scenarios, hover_input
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quad_shooting.json")
@@ -58,7 +58,7 @@ def test_condensed_qp_and_its_minimiser(qoracle):
     """H, g against an independent numpy condensing (matrix form); du against scipy's BVLS on the equivalent bounded least-squares
     problem; KKT: stationarity with multipliers of the right sign, feasibility."""
     from scipy.optimize import lsq_linear
-    cfg = default_quad_config()
+    cfg = tight_quad_config()
     s = random_quad_scenarios(24, cfg, seed=3)
     nact = 0
     for b in range(24):
@@ -117,7 +117,7 @@ def test_fallback_mode_ends_the_remaining_limit_cycle(qoracle):
     even with the centring safeguard; with the fallback it starts over after 30 iterations without the second-order term, converges
     (47 iterations in all) and agrees with the exact active-set solution.  Nothing else of the batch gets near the threshold."""
     from scipy.optimize import lsq_linear
-    cfg = default_quad_config()
+    cfg = tight_quad_config()
     s = random_quad_scenarios(4096, cfg, seed=202)
     x, u, cost, st, it = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=8)
     b = 3012
