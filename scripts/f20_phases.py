@@ -9,6 +9,10 @@ from ad_mpc_amd.engine import BatchSolver
 from ad_mpc_amd.scenarios import random_scenarios
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cfg = default_config(N=20); s = random_scenarios(B, N=20, seed=1234)
+if os.environ.get('F20_GP') == '1':                    # BASELINE configs[2]: GP residual in the shooting
+    from ad_mpc_amd.config import set_gp
+    from ad_mpc_amd.scenarios import grid_gp
+    set_gp(cfg, grid_gp())
 eng = BatchSolver(cfg, device=0); d = eng.to_device
 a = [d(s[k]) for k in ("x0", "yref", "yref_e", "p")]; x0b, u0b = d(s["xbar"]), d(s["ubar"])
 cost = torch.empty(B, dtype=torch.float64, device="cuda"); st = torch.empty(B, dtype=torch.int32, device="cuda"); it = torch.empty_like(st)
