@@ -356,8 +356,8 @@ def test_full_size_shard_8192_every_instance(gpu_engine_factory, oracle_omp):
 
 def test_fp32_config5_full_size(gpu_engine_factory, oracle_omp):
     """BASELINE configs[4]: N = 80, B = 16384, fp32 storage and arithmetic, against the fp64 oracle: identical status, every
-    instance converged before iter_max, |u - u_oracle| and |x - x_oracle| <= 2e-3 absolute (inputs range over [-10, 5],
-    states over tens of metres: about 2e-4 relative), costs to 1e-3 relative; bit-wise repeatable."""
+    instance converged before iter_max, |u - u_oracle| <= 1.5e-3 absolute at worst and <= 5e-4 for 99 % of the instances (inputs range over
+    [-10, 5], states over tens of metres), costs to 1e-3 relative; bit-wise repeatable."""
     N, B = 80, 16384
     cfg = default_config(N=N)
     s = random_scenarios(B, N=N, seed=1234)
@@ -370,8 +370,12 @@ def test_fp32_config5_full_size(gpu_engine_factory, oracle_omp):
     np.testing.assert_array_equal(g[3], o[3])
     assert (g[3] == 0).all()
     assert g[4].max() < cfg.ipm_iter_max and o[4].max() < cfg.ipm_iter_max
-    assert np.abs(g[1] - o[1]).max() <= 2e-3, np.abs(g[1] - o[1]).max()
-    assert np.abs(g[0] - o[0]).max() <= 2e-3, np.abs(g[0] - o[0]).max()
+    # measured on this batch: max 7.1e-4, 99.9 % of the instances within 4.9e-4, 99 % within 2.3e-4 (inputs), states 2.2e-4 -- asserted with a
+    # factor 2; over twelve more batches of the same size (scripts/census_f32_margin.py, 196 608 instances) the quantiles are the same and
+    # the single worst instance is 1.78e-3, which is what the 2.5e-3 of DESIGN section 9 bounds with 40 % to spare
+    du = np.abs(g[1] - o[1]).max(axis=(1, 2))
+    assert du.max() <= 1.5e-3 and np.quantile(du, 0.999) <= 1e-3 and np.quantile(du, 0.99) <= 5e-4, (du.max(), np.quantile(du, 0.999), np.quantile(du, 0.99))
+    assert np.abs(g[0] - o[0]).max() <= 1e-3, np.abs(g[0] - o[0]).max()
     np.testing.assert_allclose(g[2], o[2], rtol=1e-3)
     np.testing.assert_array_equal(g[0][:, 0, :], s["x0"].astype(np.float32))          # x_0 pinned to the measured state
     assert np.abs(g[0][:, 1:N, 6]).max() <= 0.52 + 2e-3                                # steering inside its hard bound
