@@ -139,59 +139,7 @@ struct FusedLds {
 #ifndef F20_PAIR_REV
 #define F20_PAIR_REV 0
 #endif
-#define F20_NB 64
-#define F20_BINS0 64
-#define F20_HDR 128
-__global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig* __restrict__ cfg, int B, const double* __restrict__ x0g,
-                                                               const double* __restrict__ yrefeg, int* __restrict__ sched, int cap)
-{
-    // Bin counts are aggregated per block in LDS and reach the global counters as ONE atomic per (block, bin): 2000 of 4096 config-2
-    // instances share bin 0, and one global atomic each on that word took 22 us -- a tenth of the step.
-    __shared__ int cnt[F20_NB], base[F20_NB];
-    if (threadIdx.x < F20_NB) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    int q = -1, rank = 0;
-    if (b < B) {
-        const double* x0 = x0g + (size_t)b * NX;
-        const double* ye = yrefeg + (size_t)b * NX;
-        const double T = cfg->Ts * (double)cfg->N;
-        double sn, cs;
-        sincos(x0[2], &sn, &cs);
-        const double along = cs * (ye[0] - x0[0]) + sn * (ye[1] - x0[1]);
-        const double areq = 2.0 * (along - x0[3] * T) / (T * T);
-        const double lb = cfg->lbu[0], ub = cfg->ubu[0];
-        const double ov = fmax(areq - ub, lb - areq) / (ub - lb);          // < 0: that far inside the box
-        q = 0;
-        if (ov == ov && ov > -0.125) q = 1 + (int)fmin(fmax((ov + 0.125) * 32.0, 0.0), (double)(F20_NB - 2));
-        rank = atomicAdd(&cnt[q], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x < F20_NB) base[threadIdx.x] = cnt[threadIdx.x] > 0 ? atomicAdd(sched + F20_BINS0 + threadIdx.x, cnt[threadIdx.x]) : 0;
-    __syncthreads();
-    if (q >= 0) sched[F20_HDR + (size_t)q * cap + base[q] + rank] = b;
-}
-
-// next instance for a persistent wave (wave-uniform), -1 when the batch is drained: tickets walk the bins from the most expensive
-// down.  First ticket = block index (2048 simultaneous atomics on one word queue up for ~20 us), later ones from the counter.
-__device__ __forceinline__ int f20_next(int* __restrict__ sched, int cap, bool first, int lane) {
-    int t = blockIdx.x;
-#if F20_PAIR_REV        // experiment: the second wave of a SIMD takes the EASIEST of the first round's tickets (block b + G/2 shares the SIMD of block b)
-    if (t >= (int)gridDim.x / 2) t = (int)gridDim.x + (int)gridDim.x / 2 - 1 - t;
-#endif
-    if (!first) {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(sched, 1);
-        t = (int)gridDim.x + __builtin_amdgcn_readfirstlane(v);
-    }
-    const int c = sched[F20_BINS0 + F20_NB - 1 - lane];
-    const int incl = wave_scan_incl_int(c);
-    const unsigned long long m = __ballot(incl > t);
-    if (m == 0ull) return -1;
-    const int l = __ffsll((long long)m) - 1;
-    const int base = __builtin_amdgcn_readlane(incl - c, l);
-    return __builtin_amdgcn_readfirstlane(sched[F20_HDR + (size_t)(F20_NB - 1 - l) * cap + (t - base)]);
-}
+#include "work_order.h"
 
 template <int QMASK>
 __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfig* __restrict__ cfg, int B,

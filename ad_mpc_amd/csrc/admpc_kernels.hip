@@ -1281,6 +1281,7 @@ struct AdmpcSolver {
     int use_dense;           // condensed dense-Cholesky QP kernel available for this horizon (N == 20) and not disabled
     int dense_lds_bytes;
     int n20_fused;           // N = 20 fp64 steps run the fused persistent kernel (admpc_fused20.hip); 0: the four-kernel pipeline (ADMPC_N20=split)
+    int use_seg;             // N = 40 / 60 / 80 fp64 steps run the segmented condensed kernel (admpc_seg.hip); ADMPC_QP=riccati: kernel R
     int* d_tick;             // [128 + 64 cap_fused] tickets, exit counter and work-order bins of the fused kernel (zeroed at allocation; the kernel re-arms them)
     int cap_fused;
     double* d_slot;          // per-wave slot buffers of the fused kernel (the linearisation across the interior point), allocated at its first launch
@@ -1340,6 +1341,11 @@ extern "C" void admpc_fused20_launch(int num_cu, hipStream_t st, const AdmpcConf
         double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* slotbuf);
 extern "C" size_t admpc_fused20_slot_doubles(int num_cu);
 extern "C" size_t admpc_fused20_sched_ints(int cap);
+// segmented condensed step, N = 40 / 60 / 80 fp64 (admpc_seg.hip)
+extern "C" int admpc_seg_supports(int N);
+extern "C" void admpc_seg_launch(int N, int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
+        const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap);
 
 extern "C" {
 
@@ -1420,6 +1426,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         // ADMPC_N20=split keeps the four-kernel pipeline (linearise, condense, interior point, expand) for A/B runs and tests
         const char* m = getenv("ADMPC_N20");
         s->n20_fused = !(m && strcmp(m, "split") == 0);
+        s->use_seg = admpc_seg_supports(cfg->N) && !(e && strcmp(e, "riccati") == 0);
     }
     hipError_t e = hipMalloc((void**)&s->d_cfg, sizeof(AdmpcConfig));
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -1527,9 +1534,9 @@ static int ensure_dense(AdmpcSolver* s, int B)                  // four-kernel N
     return ADMPC_OK;
 }
 static int ensure_fused(AdmpcSolver* s, int B)                  // fused N = 20 step: one slot buffer per resident wave, the work-order lists
-{
+{                                                                // (segmented kernel: the work-order lists only)
     // slot buffers only where parking the linearisation beats recomputing it: with GP residuals in the model (see admpc_fused20.hip)
-    if (!s->d_slot && s->cfg.n_gp > 0) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
+    if (!s->d_slot && s->cfg.n_gp > 0 && !s->use_seg) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
     if (B <= s->cap_fused) return ADMPC_OK;
     HIPCHK(hipDeviceSynchronize());
     s->cap_fused = 0;
@@ -1579,6 +1586,7 @@ int admpc_reserve(AdmpcSolver* s, int B)
     int rc = ensure_status(s, B); if (rc) return rc;
     const bool tol_on = s->cfg.sqp_iters > 1 && s->cfg.sqp_tol > 0.0;  // such solves run on the row kernel at every horizon (solve_impl)
     if (s->use_dense && s->n20_fused && !tol_on) return ensure_fused(s, B);      // no per-instance workspace
+    if (s->use_seg && !tol_on) return ensure_fused(s, B);
     if (s->use_dense && !tol_on) return ensure_dense(s, B);
     const int chunk = rowqp_chunk(s, s->cfg.N, 8);
     rc = ensure_row(s, B < chunk ? B : chunk, 8); if (rc) return rc;
@@ -1676,6 +1684,14 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
     }
     hipStream_t st = (hipStream_t)stream;
     int32_t* stat = status ? status : s->d_status;
+    if (s->use_seg && !snap && !(nsqp > 1 && s->cfg.sqp_tol > 0.0)) {
+        // N = 40 / 60 / 80: S cooperating waves per instance, each condensing 20 stages; no workspace, no kernel boundary (admpc_seg.hip)
+        int rc = ensure_fused(s, B); if (rc) return rc;
+        for (int sq = 0; sq < nsqp; ++sq)
+            admpc_seg_launch(N, s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (sq == 0 && !routed) ? 1 : 0, s->d_tick, s->cap_fused);
+        HIPCHK(hipGetLastError());
+        return ADMPC_OK;
+    }
     if (!dense) {      // every horizon but N = 20, and every solve that asks for multipliers: kernel A + kernel R, in chunks if need be
         int rc = solve_rows<double>(s, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, pi, ineq, st, routed); if (rc) return rc;
         if (nsqp > 1 && s->cfg.sqp_tol > 0.0)

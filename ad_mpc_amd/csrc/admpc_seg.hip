@@ -1,0 +1,1320 @@
+// admpc_seg.hip -- the fp64 SQP-RTI step for horizons N = 20 S (S = 2: the reference's shipped N = 40, launch/gp_ad_mpc.launch:6-7,
+// acados_solver_sim_car.h:66; S = 3, 4: N = 60, 80) as ONE persistent kernel for gfx950: S cooperating wavefronts per MPC instance.
+//
+// The horizon is cut into S segments of 20 stages.  Wave s owns segment s from its inputs to its outputs with the machinery of the fused
+// N = 20 kernel (admpc_fused20.hip): ERK4 + forward sensitivities of its stages (H0/H1, ad_3d_optimizer.py:280-310), condensing of its
+// stages onto its 40 inputs (H2-H4, acados FULL_CONDENSING_HPIPM acados_solver_sim_car.c:145 -- per segment), the dense 40 x 40 LDL' of
+// its Newton matrix with row i in the registers of lane i (H5, HPIPM :688-692), expansion and full step of its states (H6, :647-648).
+// What couples the segments is the 7-vector at each cut, z_s = dx at the first stage of segment s (z_0 = x0 - xbar_0 is data):
+//     z_{s+1} = Bbar_s U_s + Abar_s z_s + c_s          (multiplier nu_{s+1})
+// The states of segment s are functions of (z_s, U_s): its condensing carries 7 more columns (Phi_k = d x_k / d z_s, lanes 40..46), its
+// cost has the blocks Huu (40 x 40), Hzu (7 x 40), Hzz (7 x 7).  Per interior-point iteration every wave factorises its OWN Newton matrix
+// M_s = Huu + barrier terms with the border rows C_s = [Qzu_s ; Bbar_s] riding along in lanes 40.. (a right-looking LDL' updates whatever
+// rows the lanes hold: L_b = C L^-T D^-1 costs no instruction), the Schur blocks C M^-1 C' = L_b D L_b' come out of ten
+// v_mfma_f64_16x16x4_f64, the border lanes of the forward substitution deliver the reduced right-hand sides, and wave 0 couples the
+// segments by a backward / forward recursion over the S - 1 cuts in 7 x 7 blocks (Gaussian elimination with partial pivoting on
+// Lambda = I + Pbb Pi); every wave then back-substitutes its own inputs.  All waves work at once; seven workgroup barriers per iteration.
+// The Newton steps are the ones of the stage-wise Riccati oracle (oracle/admpc_oracle.c: ipm_solve) in another elimination order; the
+// executable statement of the algebra is tests/seg_spec.py, checked against the oracle on the CPU (tests/test_seg_spec.py).
+//
+// Nothing but the algorithmic inputs and outputs crosses HBM (no workspace): the linearisation is recomputed in front of the expansion.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/admpc.h"
+
+#define NX ADMPC_NX
+#define NU ADMPC_NU
+#define NY ADMPC_NY
+#define WAVE 64
+#define IPM_FLOOR 1e-40
+#define GTS 42           // values per stage of the packed linearisation (see kernel A in admpc_kernels.hip)
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#include "model_dev.h"
+#include "dense40.h"
+#include "cond_common.h"
+#include "work_order.h"
+
+#define LDG(p) (*(p))
+#define STG(p, v) (*(p) = (v))
+
+// Cross-WAVE exchange through LDS: inline-assembly LDS stores are invisible to the compiler's wait-count tracking, so the barrier
+// waits for everything this wave has in flight first.
+#define XSYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+
+// ---- bring-up dumps (build with -DSEG_DEBUG: `make variant`-style, scripts/seg_debug.py): instance SEG_DEBUG_INST leaves its LDS regions and
+//      a few per-lane values in a global buffer at two points (P1: behind the condensing, P2: behind the unconstrained trial)
+#ifdef SEG_DEBUG
+#define SEG_DBG_W 16384
+__device__ double g_seg_dbg[4 * 2 * SEG_DBG_W];
+__device__ int g_seg_dbg_inst = 0;
+__device__ __forceinline__ void seg_dbg_copy(double* dst, const double* src, int cnt, int lane) { for (int i = lane; i < cnt; i += 64) dst[i] = src[i]; }
+#endif
+
+// dq[k][c] = xbar[k][c] - (k < 20 ? yref[k][c] : yre[c]), k = 0..20, for the 21 stage rows a segment touches
+__device__ __forceinline__ void stage_dq_seg(double* __restrict__ dq, const double* __restrict__ xb, const double* __restrict__ yr,
+                                             const double* __restrict__ yre, const int lane) {
+    constexpr int NN = 20, CNT = (NN + 1) * NX, IT = (CNT + WAVE - 1) / WAVE;
+    double xv[IT], yv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1;
+        const int k = div7(i), c = i - 7 * k;
+        xv[it] = LDG(xb + i);
+        yv[it] = k < NN ? LDG(yr + k * 9 + c) : LDG(yre + c);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
+}
+
+// LDS map (doubles).  Per wave: what the interior point of its segment needs -- H (packed lower rows of Huu), Hb (the constant border
+// rows: Hzu, Bbar), L (unit factor), Lb (border rows of the factor), parked per-lane constants, exchange buffers (cb, invd, sb, sb2 in
+// the relative layout dense40.h's col_head assumes), wv (border unknowns of the back substitution).  Phases A, C, E alias it as in
+// admpc_fused20.hip.  Per segment an interface block (IF_*) that the other waves read; one word block per workgroup.
+template <int S>
+struct SegLds {
+    static constexpr int N = 20, NTRI = 820;
+    static constexpr int NB = S == 2 ? 7 : 14;                         // border rows per segment
+    static constexpr int NR = 40 + NB;                                 // lanes that carry rows of the bordered matrix
+    static constexpr int oH = 0, oHb = oH + NTRI, oL = oHb + NB * 40, oLb = oL + NTRI, oPark = oLb + NB * 40, oCb = oPark + 5 * 64;
+    static constexpr int oWv = oCb + 4 * 64;
+    static constexpr int seg = oWv + 16;
+    static constexpr int JTS = 24, JTK = 4 * JTS + 2;
+    static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
+    static_assert(oBlA + N * NX <= seg && oGTC + N * GTS <= oDqC && oGam + (NX + 1) * 64 <= oPark, "LDS aliases");
+    // interface block of a segment
+    static constexpr int IF_SC = 0;              // [14][14] C M^-1 C' of this iteration
+    static constexpr int IF_HZZ = 196;           // [7][8]   Hzz (cost part)
+    static constexpr int IF_ABAR = 252;          // [7][8]   Abar_s = Phi at the segment's end
+    static constexpr int IF_C = 308;             // [8]      c_s = free response at the segment's end
+    static constexpr int IF_ZB = 316;            // [16]     reduced right-hand side of the border rows (forward substitution)
+    static constexpr int IF_Z = 332;             // [8]      z_s of the interior point's iterate
+    static constexpr int IF_ZC = 340;            // [8]      z_s of the cold start (the free chain)
+    static constexpr int IF_DZ = 348;            // [8]      Newton step of z_s
+    static constexpr int IF_NU = 356;            // [8]      multiplier of the cut in front of this segment
+    static constexpr int IF_RED = 364;           // [4][8]   partial reductions, one slot per barrier phase
+    static constexpr int IF_BU = 396;            // [8]      Bbar_s U_s + c_s of the returned inputs
+    static constexpr int IF_PI = 404;            // [7][8]   Pi_s (backward recursion over the cuts)
+    static constexpr int IF_ETA = 460;           // [8]
+    static constexpr int IF_X = 468;             // [7][8]   Lambda_s^-1 Ahat_s
+    static constexpr int IF_XR = 524;            // [8]      Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1})
+    static constexpr int IF_G56 = 532;           // [2]      sum of the delta-box barrier ratios of the segment
+    static constexpr int IFS = 536;
+    static constexpr int oIF = S * seg, oWG = oIF + S * IFS;
+    static constexpr int total = oWG + 8;
+};
+
+// ---- 7 x 7 blocks of the interface recursion (wave 0).  Matrices live in LDS, row-major with stride 8; "lane = column": lane c holds
+// column c of a matrix (or a right-hand side) in seven registers.
+struct Col7 { double v[7]; };
+
+// out = A * col (A[r][k] at A + r * sa + k * ka: uniform LDS reads)
+__device__ __forceinline__ Col7 mat_col(const double* A, const int sa, const int ka, const Col7& x) {
+    Col7 o;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a = fma(A[r * sa + k * ka], x.v[k], a);
+        o.v[r] = a;
+    }
+    return o;
+}
+
+// Gaussian elimination with partial pivoting: lanes 0..6 hold the columns of a 7 x 7 matrix, any other lane a right-hand side; on return
+// every right-hand-side lane holds its solution.  Row operations are lane-parallel; pivots and multipliers are wave-uniform (v_readlane).
+__device__ __forceinline__ void ge7_solve(Col7& c) {
+    static_for<0, 7>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        double best = fabs(rdlane(c.v[p], p));
+        int bi = p;
+        static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            const double v = fabs(rdlane(c.v[r], p));
+            if (v > best) { best = v; bi = r; }
+        });
+        static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            if (bi == r) { const double t = c.v[p]; c.v[p] = c.v[r]; c.v[r] = t; }
+        });
+        const double pinv = rcp_nr(rdlane(c.v[p], p));
+        static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            const double m = rdlane(c.v[r], p) * pinv;
+            c.v[r] = fma(-m, c.v[p], c.v[r]);
+        });
+    });
+    static_for<0, 7>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int r = 6 - decltype(qc)::value;
+        double a = c.v[r];
+        static_for<r + 1, 7>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int k = decltype(cc)::value;
+            a = fma(-rdlane(c.v[r], k), c.v[k], a);
+        });
+        c.v[r] = a * rcp_nr(rdlane(c.v[r], r));
+    });
+}
+
+// The coupling of the S segments (wave 0, between two workgroup barriers).  Per segment s, from its interface block:
+//   Pzz_s = Hzz_s + e6 e6' sum(G56) - Sc_zz,  Pzb_s = Sc_zb,  Pbb_s = Sc_bb,  Ahat_s = Abar_s - Pzb_s',
+//   yhat_s = zb[z rows] (reduced stationarity of z_s),  dhat_s = -zb[Bbar rows]
+// Backward over the cuts:  nu_s = eta_s - Pi_s dz_s  with  Pi_{S-1} = Pzz, eta_{S-1} = yhat;  Lambda_s = I + Pbb_s Pi_{s+1},
+//   Pi_s = Pzz_s + Ahat_s' Pi_{s+1} Lambda_s^-1 Ahat_s,   eta_s = yhat_s + Ahat_s' (eta_{s+1} - Pi_{s+1} Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1}))
+// Forward:  dz_{s+1} = Lambda_s^-1 (Ahat_s dz_s + dhat_s + Pbb_s eta_{s+1}),  nu_{s+1} = eta_{s+1} - Pi_{s+1} dz_{s+1}.
+// (tests/seg_spec.py: newton()).  Matrices and vectors are recomputed in both solves of an iteration: the blocks are tiny.
+template <int S>
+__device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const int lane) {
+    using LD = SegLds<S>;
+    const int l49 = lane < 49 ? lane : 48;
+    const int er = div7(l49), ec = l49 - 7 * er;                    // element (er, ec) for the element-wise steps
+    const int c7 = lane < 7 ? lane : 0;
+    // ---- the last segment: Pi = Pzz, eta = yhat
+    {
+        double* F = ifb + (S - 1) * LD::IFS;
+        const double v = F[LD::IF_HZZ + er * 8 + ec] + ((er == 6 && ec == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + er * 14 + ec];
+        if (lane < 49) F[LD::IF_PI + er * 8 + ec] = v;
+        if (lane < 7) F[LD::IF_ETA + lane] = F[LD::IF_ZB + lane];
+    }
+    WSYNC();
+    // ---- middle segments, backward
+#pragma unroll 1
+    for (int s = S - 2; s >= 1; --s) {
+        double* F = ifb + s * LD::IFS;
+        const double* Fn = ifb + (s + 1) * LD::IFS;
+        const double* Pbb = F + LD::IF_SC + 7 * 14 + 7;            // [r * 14 + c]
+        // lanes 0..6: columns of Pi_{s+1}; lane 7: eta_{s+1}; lanes 8..14: columns of Ahat_s (right-hand sides as they are)
+        Col7 col;
+        const int ac = (lane >= 8 && lane < 15) ? lane - 8 : 0;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const double pv = Fn[LD::IF_PI + r * 8 + c7], ev = Fn[LD::IF_ETA + r];
+            col.v[r] = lane < 7 ? pv : ev;
+        }
+        Col7 T = mat_col(Pbb, 14, 1, col);
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const double ah = F[LD::IF_ABAR + r * 8 + ac] - F[LD::IF_SC + ac * 14 + 7 + r];      // Ahat[r][ac] = Abar[r][ac] - Pzb[ac][r]
+            const double dh = -F[LD::IF_ZB + 7 + r];
+            T.v[r] = lane < 7 ? T.v[r] + (r == lane ? 1.0 : 0.0) : (lane == 7 ? T.v[r] + dh : ah);
+        }
+        ge7_solve(T);                                              // lane 7: xr; lanes 8..14: columns of X = Lambda^-1 Ahat
+        if (lane == 7) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) F[LD::IF_XR + r] = T.v[r];
+        }
+        if (lane >= 8 && lane < 15) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) F[LD::IF_X + r * 8 + ac] = T.v[r];
+        }
+        // Y = Pi_{s+1} v  (lane 7: eta_{s+1} - Pi_{s+1} xr), Z = Ahat' Y
+        Col7 Y = mat_col(Fn + LD::IF_PI, 8, 1, T);
+#pragma unroll
+        for (int r = 0; r < 7; ++r) Y.v[r] = lane == 7 ? Fn[LD::IF_ETA + r] - Y.v[r] : Y.v[r];
+        Col7 Z;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * 14 + 7 + k], Y.v[k], a);      // Ahat[k][r]
+            Z.v[r] = a;
+        }
+        WSYNC();
+        if (lane == 7) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) F[LD::IF_ETA + r] = F[LD::IF_ZB + r] + Z.v[r];
+        }
+        if (lane >= 8 && lane < 15) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+                F[LD::IF_PI + r * 8 + ac] = F[LD::IF_HZZ + r * 8 + ac] + ((r == 6 && ac == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + r * 14 + ac] + Z.v[r];
+        }
+        WSYNC();
+    }
+    // ---- segment 0 (its border rows 0..6 are Bbar_0): dz_1 = Lambda_0^-1 (dhat_0 + Pbb_0 eta_1)
+    {
+        double* F = ifb;
+        double* Fn = ifb + LD::IFS;
+        Col7 col;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const double pv = Fn[LD::IF_PI + r * 8 + c7], ev = Fn[LD::IF_ETA + r];
+            col.v[r] = lane < 7 ? pv : ev;
+        }
+        Col7 T = mat_col(F + LD::IF_SC, 14, 1, col);
+#pragma unroll
+        for (int r = 0; r < 7; ++r) T.v[r] = lane < 7 ? T.v[r] + (r == lane ? 1.0 : 0.0) : T.v[r] - F[LD::IF_ZB + r];
+        ge7_solve(T);
+        if (lane == 7) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) Fn[LD::IF_DZ + r] = T.v[r];
+        }
+    }
+    WSYNC();
+    // ---- forward over the cuts: lanes 0..6 = rows
+#pragma unroll 1
+    for (int s = 1; s < S; ++s) {
+        double* F = ifb + s * LD::IFS;
+        if (s > 1) {
+            const double* Fp = ifb + (s - 1) * LD::IFS;             // dz_s = X_{s-1} dz_{s-1} + xr_{s-1}
+            double a = Fp[LD::IF_XR + c7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a = fma(Fp[LD::IF_X + c7 * 8 + k], Fp[LD::IF_DZ + k], a);
+            if (lane < 7) F[LD::IF_DZ + lane] = a;
+            WSYNC();
+        }
+        double a = F[LD::IF_ETA + c7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a = fma(-F[LD::IF_PI + c7 * 8 + k], F[LD::IF_DZ + k], a);
+        if (lane < 7) F[LD::IF_NU + lane] = a;
+        WSYNC();
+    }
+}
+
+template <int S, int QMASK>
+__global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfig* __restrict__ cfg, int B,
+                                                                const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                                const double* __restrict__ yrefeg, const double* __restrict__ pg,
+                                                                double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                                double* __restrict__ costg, int32_t* __restrict__ statusg,
+                                                                int32_t* __restrict__ itersg, int first_pass, int* __restrict__ sched, int cap)
+{
+    using LD = SegLds<S>;
+    constexpr int N = 20, n = 40, NT = N * S, NB = LD::NB, NR = LD::NR;
+    extern __shared__ double lds_raw[];
+    const int wv_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // segment of this wave (uniform)
+    const bool first = wv_ == 0, last = wv_ == S - 1;
+    const int k0 = wv_ * N;                                      // first stage of the segment
+    const int bslot = first ? 0 : 7;                             // border rows [bslot, bslot + 7) hold Bbar (the first segment has no z rows)
+    double* const lds_seg = lds_raw + wv_ * LD::seg;
+    double* const ifb = lds_raw + LD::oIF;                       // interface blocks of all segments
+    double* const IFm = ifb + wv_ * LD::IFS;                     // this segment's
+    int* const wgw = reinterpret_cast<int*>(lds_raw + LD::oWG);  // workgroup words: [0] instance of this round
+    double* const Hp = lds_seg + LD::oH;
+    double* const Hb = lds_seg + LD::oHb;
+    double* const Lp = lds_seg + LD::oL;
+    double* const Lb = lds_seg + LD::oLb;
+    double* const park = lds_seg + LD::oPark;
+    double* const cb = lds_seg + LD::oCb;
+    double* const invd = cb + 64;
+    double* const sb = invd + 64;
+    double* const sb2 = sb + 64;
+    double* const wvec = lds_seg + LD::oWv;
+    double* const JT = lds_seg + LD::oJT;
+    double* const GT = lds_seg + LD::oGTC;
+    double* const bl = lds_seg + LD::oBlA;
+    double* const dqC = lds_seg + LD::oDqC;
+    double* const gam = lds_seg + LD::oGam;
+    double* const dqE = lds_seg + LD::oDqC;
+    double* const dus = lds_seg + LD::oGam;
+#define PK_DL   park[0 * 64 + lane]
+#define PK_DUU  park[1 * 64 + lane]
+#define PK_G0   park[2 * 64 + lane]
+#define PK_DDL  park[3 * 64 + lane]
+#define PK_DDU  park[4 * 64 + lane]
+#define LAUNDER_LANE(v) int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(v))
+#define LAUNDER_CFG(c) int c##_z = 0; asm volatile("" : "+s"(c##_z)); const AdmpcConfig* __restrict__ c = cfg + c##_z
+    // partial reductions of the S waves: slot `ph` of every segment, combined in segment order by every wave (same bits everywhere)
+#define RED(s_, ph_, i_) ifb[(s_) * LD::IFS + LD::IF_RED + (ph_) * 8 + (i_)]
+
+    // LDS byte address of the row this lane holds: packed row of H / L (lanes < 40), border row (lanes 40 .. NR-1), else row 0
+    auto row_addr = [&](double* tri, double* brd, const int lz_) __attribute__((always_inline)) -> unsigned {
+        const int lb = lz_ - n;
+        return lds_byte_addr(lz_ < n ? tri + lz_ * (lz_ + 1) / 2 : (lz_ < NR ? brd + lb * n : tri));
+    };
+
+    // Factorisation of the bordered Newton matrix: M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) = L D L' with the
+    // border rows (lanes 40 .. NR-1: Hb, plus the delta-box barrier on the z6 row when zbar) riding along -> Lb = C L^-T D^-1.
+    auto factorise = [&](const double dbar_, const double sodd_, const int lz_, const bool zbar, const double h_) __attribute__((always_inline)) {
+        double a[n];
+        newton_row_40_b<NR>(a, row_addr(Hp, Hb, lz_), dbar_, sodd_);
+        if (zbar) {
+            // row z6 (lane 46) of Qzu: + h * (sum of the barrier ratios of the stages behind the column's stage), odd columns; sb2[k] holds that sum
+            const double hz = lz_ == 46 ? h_ : 0.0;
+            static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                a[2 * k + 1] = fma(hz, sb2[k], a[2 * k + 1]);
+            });
+        }
+        const unsigned lrow = row_addr(Lp, Lb, lz_);
+        const unsigned pub_wr = lds_byte_addr(cb + lz_), pub_rd = lds_byte_addr(cb + (lz_ & 15));
+        auto chain = [&](auto jc, double& nln) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const double dj = rdlane(a[j], j);
+            const double dinv = rcp_nr(dj);
+            const double lu = a[j] * dinv;
+            invd[j] = dinv;
+            asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
+                         : : "v"(lrow), "v"(lu), "n"(NR - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
+            nln = -lu;
+        };
+        double Rb[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, nlb[2] = {0.0, 0.0};
+        cb[lz_] = a[0];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) Rb[0][m] = cb[16 * m + (lz_ & 15)];
+        chain(std::integral_constant<int, 0>{}, nlb[0]);
+        static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            // NR = 47: every row beyond the columns sits in the third 16-lane row -- the schedule of the 40-row factorisation (columns
+            // j >= 31 come from the lanes' own registers); NR = 54: rows in the fourth 16-lane row need every column through LDS
+            constexpr bool wide = NR > 48;
+            constexpr bool own = !wide && (j + 1) / 16 == 2;
+            constexpr bool pub = wide ? (j + 2 < n) : (j + 2 < n && (j + 2) / 16 < 2);
+            constexpr int mlo = (j + 2) / 16 < 2 ? (j + 2) / 16 : 2;
+            double (&R)[3] = Rb[j & 1];
+            double (&Rn)[3] = Rb[(j + 1) & 1];
+            double& nl = nlb[j & 1];
+            double& nln = nlb[(j + 1) & 1];
+            col_head<j + 1, mlo, pub, own>(a[j + 1], R, nl, Rn, pub_wr, pub_rd);
+            if constexpr (!pub) Rn[2] = a[j + 1];
+            chain(std::integral_constant<int, j + 1>{}, nln);
+            constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;
+            static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
+                constexpr int jj = decltype(c)::value;
+                if constexpr (own) fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
+                else fmac_rowbc_ld<jj % 16>(a[jj], R[jj / 16], nl);
+            });
+            static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
+                constexpr int jj = 4 * decltype(c)::value;
+                if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+                else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
+            });
+        });
+        WSYNC();
+    };
+    // Schur blocks of the border: Sc = Lb D Lb' (NB x NB) in ten v_mfma_f64_16x16x4_f64: A[i][k] = Lb[i][c] d_c, B[k][j] = Lb[j][c], c = 4 t + k
+    auto schur = [&](const int lane) __attribute__((always_inline)) {
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int rb = r16 < NB ? r16 : 0;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int c = 4 * t + kq;
+            const double lb = Lb[rb * n + c];
+            const double dc = rcp_nr(invd[c]);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb * dc, lb, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = kq + 4 * v;                             // C/D layout of the 16 x 16 x 4 tile: register v of lane (kq, r16) is element (kq + 4 v, r16)
+            if (i < NB && r16 < NB) IFm[LD::IF_SC + i * 14 + r16] = acc[v];
+        }
+    };
+    // The coupled Newton solve for one right-hand side: y on the input lanes, the reduced stationarity of z_s on the z lanes (0 on
+    // the Bbar lanes).  Returns the step of this lane's input; dz_s / nu_{s+1} are in the interface blocks afterwards.
+    auto coupled_solve = [&](double y, const int lz_) __attribute__((always_inline)) -> double {
+        const bool uz_ = lz_ < n;
+        const unsigned pub = lds_byte_addr(cb + (lz_ & 15));
+        fwd_subst_40_b<NR>(y, row_addr(Lp, Lb, lz_), pub);
+        if (lz_ >= n && lz_ < NR) IFm[LD::IF_ZB + lz_ - n] = y;
+        XSYNC();
+        if (wv_ == 0) interface_solve<S>(ifb, lz_);
+        XSYNC();
+        // unknowns of the border rows: dz_s on the z rows, -nu_{s+1} on the Bbar rows
+        if (lz_ < 16) {
+            const int b = lz_;
+            double w = 0.0;
+            if (!first && b < 7) w = IFm[LD::IF_DZ + b];
+            if (!last && b >= bslot && b < bslot + 7) w = -ifb[(wv_ + 1) * LD::IFS + LD::IF_NU + b - bslot];
+            wvec[b] = w;
+        }
+        WSYNC();
+        double x = y * invd[uz_ ? lz_ : 0];
+        {
+            const int li = uz_ ? lz_ : 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) x = fma(-Lb[b * n + li], wvec[b], x);
+        }
+        bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)), pub);
+        return x;
+    };
+
+    bool first_ticket = true;
+    for (;;) {
+        {
+            LAUNDER_LANE(lane0);
+            if (wv_ == 0) {
+                const int t_ = f20_next(sched, cap, first_ticket, lane0);
+                if (lane0 == 0) wgw[0] = t_;
+            }
+            first_ticket = false;
+            XSYNC();
+        }
+        const int inst = __builtin_amdgcn_readfirstlane(wgw[0]);
+        if (inst < 0) break;
+        if (!first_pass && statusg[inst] != 0) { XSYNC(); continue; }      // failed / converged in an earlier SQP iteration of this call
+        double* const xbg = xbarg + (size_t)inst * (NT + 1) * NX;
+        double* const ubg = ubarg + (size_t)inst * NT * NU;
+        const double* yrg = yrefg + (size_t)inst * NT * NY;
+        double* const xbs = xbg + (size_t)k0 * NX;                  // the segment's rows
+        double* const ubs = ubg + (size_t)k0 * NU;
+        const double* yrs = yrg + (size_t)k0 * NY;
+        const double* yre = last ? yrefeg + (size_t)inst * NX : yrs + N * NY;      // row 20 of the segment's references (unused unless last)
+
+        double du = 0.0;
+        bool failed = false;
+        int it = 0;
+        int npass = 2; asm volatile("" : "+s"(npass));
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) {
+        // =================================================================================================================
+        // phase A (H0/H1): ERK4 + forward sensitivities of the segment's 20 stages (text of admpc_fused20.hip, stage offset k0)
+        // =================================================================================================================
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const double h = cf->Ts;
+            const int tsk = lane < 3 * N ? lane : 3 * N - 1;
+            const int k = (int)(((unsigned)tsk * 21846u) >> 16), g = tsk - 3 * k;
+            const bool live = lane < 3 * N;
+            {
+                const double pin = pg[inst];
+                double x[NX], u[NU], xn1[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { x[i] = LDG(xbs + k * NX + i); xn1[i] = LDG(xbs + (k + 1) * NX + i); }
+                u[0] = LDG(ubs + k * NU); u[1] = LDG(ubs + k * NU + 1);
+                double kx[NX], accx[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { kx[i] = 0.0; accx[i] = 0.0; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double cs = (s == 0) ? 0.0 : (s == 3 ? 1.0 : 0.5);
+                    const double ws = (s == 0 || s == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
+                    double X[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) X[i] = x[i] + cs * h * kx[i];
+                    ModelEvalT<double> e;
+                    model_eval<double>(cf, X, u, pin, e);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { kx[i] = e.f[i]; accx[i] += ws * e.f[i]; }
+                    if (live && g == 0) {
+                        double2* jt = reinterpret_cast<double2*>(JT + k * LD::JTK + s * LD::JTS);
+                        jt[0] = make_double2(e.j0[0], e.j0[1]); jt[1] = make_double2(e.j0[2], e.j1[0]); jt[2] = make_double2(e.j1[1], e.j1[2]);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { jt[3 + 2 * r] = make_double2(e.a[r][0], e.a[r][1]); jt[4 + 2 * r] = make_double2(e.a[r][2], e.a[r][3]); }
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) jt[9 + r] = make_double2(e.bu[r][0], e.bu[r][1]);
+                    }
+                }
+                if (live && g == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) bl[k * NX + i] = (x[i] + h * accx[i]) - xn1[i];
+                }
+            }
+            WSYNC();
+            {
+                const int xcol0 = g == 0 ? 2 : 5;
+                double kS[3][NX], accS[3][NX];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { kS[cc][i] = 0.0; accS[cc][i] = 0.0; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double cs = (s == 0) ? 0.0 : (s == 3 ? 1.0 : 0.5);
+                    const double ws = (s == 0 || s == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
+                    double Sx[3][NX];
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) {
+                            const double id = (g < 2 && i == xcol0 + cc) ? 1.0 : 0.0;
+                            Sx[cc][i] = id + cs * h * kS[cc][i];
+                        }
+                    ModelEvalT<double> e;
+                    {
+                        const double2* jt = reinterpret_cast<const double2*>(JT + k * LD::JTK + s * LD::JTS);
+                        double2 q;
+                        q = jt[0]; e.j0[0] = q.x; e.j0[1] = q.y; q = jt[1]; e.j0[2] = q.x; e.j1[0] = q.y; q = jt[2]; e.j1[1] = q.x; e.j1[2] = q.y;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { q = jt[3 + 2 * r]; e.a[r][0] = q.x; e.a[r][1] = q.y; q = jt[4 + 2 * r]; e.a[r][2] = q.x; e.a[r][3] = q.y; }
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { q = jt[9 + r]; e.bu[r][0] = q.x; e.bu[r][1] = q.y; }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        sens_rhs<double>(e, Sx[cc], g == 2 ? cc : -1, kS[cc]);
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) accS[cc][i] += ws * kS[cc][i];
+                    }
+                }
+                const int c0 = g == 0 ? 0 : (g == 1 ? 3 : 5);
+                const int nc = g == 0 ? 3 : 2;
+                WSYNC();                                   // GT overlays the Jacobian tables: every lane has read its tables before the first store
+                double* Gk = GT + k * GTS;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    if (live && cc < nc)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const double id = (g < 2 && i == xcol0 + cc) ? 1.0 : 0.0;
+                            Gk[(c0 + cc) * 6 + i] = id + h * accS[cc][i];
+                        }
+            }
+            WSYNC();
+        }
+        if (pass != 0) break;
+
+        // =================================================================================================================
+        // phase C (H2-H4): condensing of the segment.  Lane i < 40 <-> input i = 2k + j carries column i of Gamma_k = d x_k / d U_s,
+        // lanes 40..46 (segments behind the first) the columns of Phi_k = d x_k / d z_s; all lanes the free response xhat_k
+        // (from z_s = 0; the first segment: from dx_0).  H = [Huu Huz; Hzu Hzz] on six v_mfma_f64_16x16x4_f64 tiles.
+        // =================================================================================================================
+        double g0, xh6_own = 0.0, rsx = 0.0;
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ki = lane >> 1, ji = lane & 1;
+            const bool uact = lane < n;
+            const int sc = uact ? lane : 0;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            stage_dq_seg(dqC, xbs, yrs, yre, lane);
+            const double ubar_i = ubs[sc];
+            const double r_i = uact ? Rj * (ubar_i - yrs[(sc >> 1) * 9 + 7 + (sc & 1)]) : 0.0;
+            double Qd[NX], Qe[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cf->W[i]; Qe[i] = cf->We[i]; }
+            double xh[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) xh[c] = first ? x0g[(size_t)inst * NX + c] - xbg[c] : 0.0;      // uniform
+            WSYNC();
+            double g[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) g[c] = (!first && lane == n + c) ? 1.0 : 0.0;
+            constexpr int NCOMP = ((QMASK >> 0) & 1) + ((QMASK >> 1) & 1) + ((QMASK >> 2) & 1) + ((QMASK >> 3) & 1) + ((QMASK >> 4) & 1) + ((QMASK >> 5) & 1) + ((QMASK >> 6) & 1);
+            constexpr int NSTEP = (NCOMP + 3) / 4;
+            const int r16 = lane & 15, kq = lane >> 4;
+            int crow[NSTEP]; double wq_l[NSTEP], we_l[NSTEP];
+            {
+                int seen = 0;
+#pragma unroll
+                for (int st_ = 0; st_ < NSTEP; ++st_) { crow[st_] = 7; wq_l[st_] = 0.0; we_l[st_] = 0.0; }
+                static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr ((QMASK >> c) & 1) {
+                        const int st_ = seen >> 2, kk = seen & 3;
+#pragma unroll
+                        for (int q_ = 0; q_ < NSTEP; ++q_) if (q_ == st_ && kq == kk) { crow[q_] = c; wq_l[q_] = Qd[c]; we_l[q_] = Qe[c]; }
+                        ++seen;
+                    }
+                });
+            }
+            gam[7 * 64 + lane] = 0.0;
+            d4 acc[3][3];
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J < 3; ++J) acc[I][J] = d4{0.0, 0.0, 0.0, 0.0};
+            g0 = r_i;
+            static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int lim = 2 * k < n ? 2 * k : n;
+                constexpr int nblk = (lim + 15) / 16;             // 16-lane blocks of Gamma that are non-zero at this stage (first segment)
+                int tok = B; asm volatile("" : "+s"(tok));         // one stage = one basic block (see admpc_fused20.hip)
+                if (tok > 0) {
+                // the tracking cost of stage k0 + k belongs to this segment unless it is the fixed first stage of the horizon or the
+                // first stage of the next segment; stage NT carries the terminal weights
+                const bool cost_k = k == 0 ? !first : (k == N ? last : true);
+                double wg[NX];
+                double blk[NSTEP][3];
+                if constexpr (k < N) { if (lane == k) xh6_own = xh[6]; }
+                if (cost_k) {
+                    static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr ((QMASK >> c) & 1) {
+                            const double w = k < N ? Qd[c] : Qe[c];
+                            wg[c] = w * g[c];
+                            g0 += wg[c] * (xh[c] + dqC[k * 7 + c]);
+                            gam[c * 64 + lane] = g[c];
+                        }
+                    });
+#pragma unroll
+                    for (int st_ = 0; st_ < NSTEP; ++st_)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            if (m < nblk || !first) blk[st_][m] = gam[crow[st_] * 64 + 16 * m + r16];
+                            else blk[st_][m] = 0.0;
+                        }
+                }
+                double xn[NX], gn[NX];
+                if constexpr (k < N) {
+                    const double* Gk = GT + k * GTS;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) { xn[r] = bl[k * 7 + r] + (r < 2 ? xh[r] : 0.0); gn[r] = r < 2 ? g[r] : 0.0; }
+                    xn[6] = bl[k * 7 + 6] + xh[6]; gn[6] = g[6];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+#pragma unroll
+                        for (int r = 0; r < 6; r += 2) {
+                            const double2 a = *reinterpret_cast<const double2*>(Gk + c * 6 + r);
+                            xn[r] += a.x * xh[c + 2]; xn[r + 1] += a.y * xh[c + 2];
+                            gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
+                        }
+                    }
+                    const bool mine = ki == k;
+                    double bb[12];
+#pragma unroll
+                    for (int r = 0; r < 12; r += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(Gk + 5 * 6 + r);
+                        bb[r] = v.x; bb[r + 1] = v.y;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) asm volatile("" : "+v"(bb[r]));
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) gn[r] = mine ? (ji ? bb[6 + r] : bb[r]) : gn[r];
+                    gn[6] = mine ? (ji ? h : 0.0) : gn[6];
+                }
+                if (cost_k) {
+#pragma unroll
+                    for (int st_ = 0; st_ < NSTEP; ++st_) {
+                        const double wl = k < N ? wq_l[st_] : we_l[st_];
+                        static_for<0, 3>([&](auto Ic) __attribute__((always_inline)) {
+                            constexpr int I = decltype(Ic)::value;
+                            const double a = wl * blk[st_][I];
+                            static_for<0, I + 1>([&](auto Jc) __attribute__((always_inline)) {
+                                constexpr int J = decltype(Jc)::value;
+                                if constexpr (I < nblk) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, blk[st_][J], acc[I][J], 0, 0, 0);
+                                else { if (!first) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, blk[st_][J], acc[I][J], 0, 0, 0); }
+                            });
+                        });
+                    }
+                }
+                if constexpr (k < N) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; }
+                }
+                }
+            });
+            // ---- the cut behind the segment: Abar_s (columns in lanes 40..46), c_s; then the free chain z^cold of the cold start
+            if (!last) {
+                if (!first && lane >= n && lane < n + 7) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) IFm[LD::IF_ABAR + r * 8 + lane - n] = g[r];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) IFm[LD::IF_C + r] = xh[r];
+                }
+            }
+            XSYNC();
+            // z^cold_1 = c_0, z^cold_{t+1} = Abar_t z^cold_t + c_t: lanes 0..6 = components (every wave runs the chain up to its own cut)
+            double zc = 0.0;
+            if (!first) {
+                const int r7 = lane < 7 ? lane : 0;
+                zc = ifb[LD::IF_C + r7];
+#pragma unroll 1
+                for (int t = 1; t < wv_; ++t) {
+                    cb[lane] = zc;
+                    WSYNC();
+                    const double* Ft = ifb + t * LD::IFS;
+                    double a = Ft[LD::IF_C + r7];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) a = fma(Ft[LD::IF_ABAR + r7 * 8 + c], cb[c], a);
+                    WSYNC();
+                    zc = a;
+                }
+                if (lane < 7) { IFm[LD::IF_ZC + lane] = zc; IFm[LD::IF_Z + lane] = zc; }
+            }
+            // ---- stationarity rows of the states at the cold start, | w (dx_k + xbar_k - xref_k) | over the segment's cost stages
+            // (component 6 of the stages that carry a delta box is evaluated with its multipliers in phase D): the start value of the
+            // tracked residual of the stopping test (oracle ipm_solve: rstat; rowqp_core.h: pass_init).  Lane r < 7 <-> component r,
+            // dx through the linearised dynamics with zero inputs (text of the expansion, phase E).
+            {
+                const int r6 = lane < 6 ? lane : 0, r7 = lane < NX ? lane : 0;
+                const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
+                double dx = lane < NX ? (first ? x0g[(size_t)inst * NX + r7] - xbg[r7] : zc) : 0.0;
+                double m = 0.0;
+                static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    const bool cost_k = k == 0 ? !first : (k == N ? last : true);
+                    const double e = dx + dqC[k * 7 + r7];
+                    const bool row_here = lane < NX && cost_k && (k == N || lane != 6);
+                    m = fmax(m, row_here ? fabs((k < N ? wq : wqe) * e) : 0.0);
+                    if constexpr (k < N) {
+                        const double* Gk = GT + k * GTS;
+                        double a = bl[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                        double gg[5];
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) gg[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
+                        fmac_rowbc<2>(a, dx, gg[0]); fmac_rowbc<3>(a, dx, gg[1]); fmac_rowbc<4>(a, dx, gg[2]);
+                        fmac_rowbc<5>(a, dx, gg[3]); fmac_rowbc<6>(a, dx, gg[4]);
+                        dx = lane < NX ? a : 0.0;
+                    }
+                });
+                rsx = wave_reduce<OpMaxNan>(m);
+            }
+            WSYNC();
+            // ---- the tiles into the packed rows: rows < 40 -> H (lower triangle), rows 40..46 -> Hzu (border rows 0..6) and Hzz
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * I + kq + 4 * v, col = 16 * J + r16;
+                        if (row < n && col <= row) Hp[row * (row + 1) / 2 + col] = acc[I][J][v];
+                        if (I == 2 && !first && row >= n && row < n + 7) {
+                            if (col < n) Hb[(row - n) * n + col] = acc[I][J][v];
+                            else if (col < n + 7) IFm[LD::IF_HZZ + (row - n) * 8 + col - n] = acc[I][J][v];
+                        }
+                    }
+            // Bbar_s: column i of Gamma at the segment's end is in lane i -> border rows bslot .. bslot + 6; unused border rows: zero
+            if (uact) {
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    if (!last) Hb[(bslot + r) * n + lane] = g[r];
+                    if (NB == 14 && (first || last)) Hb[(7 + r) * n + lane] = 0.0;
+                }
+            }
+            WSYNC();
+            if (uact) Lp[(lane * (lane + 1)) / 2 + lane] = 0.0;         // diagonal slots of the packed factor (see admpc_fused20.hip)
+            WSYNC();
+        }
+
+#ifdef SEG_DEBUG
+        if (inst == g_seg_dbg_inst) {
+            LAUNDER_LANE(ld_);
+            double* D = g_seg_dbg + (size_t)(wv_ * 2 + 0) * SEG_DBG_W;
+            seg_dbg_copy(D, lds_seg, LD::seg, ld_);
+            seg_dbg_copy(D + 4000, IFm, LD::IFS, ld_);
+            D[5000 + ld_] = g0; D[5064 + ld_] = xh6_own; D[5128 + ld_] = rsx;
+        }
+#endif
+        // =================================================================================================================
+        // phase D (H5): unconstrained trial + interior point, segments coupled through the cuts
+        // =================================================================================================================
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ki = lane >> 1, ji = lane & 1;
+            const bool uact = lane < n;
+            const bool dact = lane < N && (lane >= 1 || !first);
+            const bool zact = !first && lane >= n && lane < n + 7;
+            const int sc = uact ? lane : 0;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            const double rho_l = Ts * cf->zl, rho_u = Ts * cf->zu;
+            const double thr = cf->ipm_thr0, mu0 = cf->ipm_mu0;
+            const double tol_comp = cf->ipm_tol_comp, tol_res = cf->ipm_tol_res, tol_step = cf->ipm_tol_step;
+            const int itmax = cf->ipm_iter_max;
+            const bool try_unc = cf->ipm_try_unconstrained != 0.0;
+            const double thw = cf->ipm_warm_thr, wrest = cf->ipm_warm_restart;
+            const int fbit = (int)cf->ipm_fallback_iter;
+            const double inv_nineq = 1.0 / (double)(8 * NT + 2 * (NT - 1));
+            const double ubar_i = ubs[sc];
+            const double dl_i = cf->lbu[ji] - ubar_i, duu_i = cf->ubu[ji] - ubar_i;
+            const double z6c = first ? 0.0 : IFm[LD::IF_ZC + 6];
+            double t[4], lam[4], sl = thr, su = thr;
+            {
+                const double r0[4] = { thr - dl_i, thr + duu_i, thr, thr };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
+            }
+            double Dt[2] = {1.0, 1.0}, Dlam[2] = {0.0, 0.0}, Ddl = 0.0, Ddu = 0.0, dx6 = 0.0;
+            if (dact) {
+                const double x6 = xbs[lane * 7 + 6];
+                Ddl = cf->lbx_delta - x6; Ddu = cf->ubx_delta - x6;
+                dx6 = z6c + xh6_own;
+                const double r0[2] = { dx6 - Ddl, Ddu - dx6 };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
+            }
+            PK_DL = dl_i; PK_DUU = duu_i; PK_G0 = g0; PK_DDL = Ddl; PK_DDU = Ddu;
+            WSYNC();
+
+            // z part of the cost gradient at the current z_s (segments behind the first): the input lanes get Hzu' z, the z lanes Hzz z
+            auto zgrad = [&](const int lz_) __attribute__((always_inline)) -> double {
+                double a = 0.0;
+                if (!first) {
+                    const bool uz_ = lz_ < n;
+                    const double* base = uz_ ? Hb + lz_ : IFm + LD::IF_HZZ + ((lz_ >= n && lz_ < n + 7) ? lz_ - n : 0) * 8;
+                    const int stride = uz_ ? n : 1;
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) a = fma(base[c * stride], IFm[LD::IF_Z + c], a);
+                }
+                return a;
+            };
+
+            double rmax_prev = 0.0, step = 1e300, stp_local = 1e300, alpha_prev = 1.0, rstat = -1.0;
+            bool solved = false, warmed = false, cons = false;
+            if (try_unc) {
+                int lt = lane; asm volatile("" : "+v"(lt));
+                factorise(uact ? Rj : 1.0, 0.0, lt, false, h);
+                if (S > 1) { schur(lt); if (lt == 0) IFm[LD::IF_G56] = 0.0; }
+                const double zg = zgrad(lt);
+                const double xt = coupled_solve(uact ? -(g0 + zg) : (zact ? -(g0 + zg) : 0.0), lt);
+                const double duc = uact ? xt : 0.0;
+#ifdef SEG_DEBUG
+                if (inst == g_seg_dbg_inst) {
+                    double* D = g_seg_dbg + (size_t)(wv_ * 2 + 1) * SEG_DBG_W;
+                    seg_dbg_copy(D, lds_seg, LD::seg, lane);
+                    seg_dbg_copy(D + 4000, IFm, LD::IFS, lane);
+                    D[5000 + lane] = duc; D[5064 + lane] = zg; D[5128 + lane] = g0;
+                }
+#endif
+                cb[lane] = duc;
+                WSYNC();
+                const double dz6 = first ? 0.0 : IFm[LD::IF_DZ + 6];
+                const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
+                const double pre = wave_scan_incl<OpSum>(du1_stage);
+                const double dx6c = z6c + dz6 + xh6_own + h * (pre - du1_stage);
+                const bool ok = (!uact || (duc >= dl_i && duc <= duu_i)) && (!dact || (dx6c >= Ddl && dx6c <= Ddu));
+                WSYNC();
+                const bool wok = __all(ok);
+                if (lane == 0) RED(wv_, 1, 0) = wok ? 1.0 : 0.0;
+                XSYNC();
+                bool allok = true;
+#pragma unroll
+                for (int s = 0; s < S; ++s) allok = allok && RED(s, 1, 0) != 0.0;
+                if (allok) { du = duc; solved = true; }
+                else if (thw > 0.0) {
+                    warmed = true;
+                    du = duc;
+                    if (!first && lane < 7) IFm[LD::IF_Z + lane] += IFm[LD::IF_DZ + lane];
+                    sl = fmax(dl_i - duc, 0.0) + thw; su = fmax(duc - duu_i, 0.0) + thw;
+                    const double r0[4] = { duc + sl - dl_i, su + duu_i - duc, sl, su };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thw ? r0[i] : thw; lam[i] = mu0 * rcp_nr(t[i]); }
+                    if (dact) {
+                        dx6 = dx6c;
+                        const double q0[2] = { dx6 - Ddl, Ddu - dx6 };
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { Dt[i] = q0[i] > thw ? q0[i] : thw; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
+                    }
+                    WSYNC();
+                }
+            }
+            auto cold_start = [&]() __attribute__((always_inline)) {
+                const double dlc = PK_DL, duc2 = PK_DUU;
+                du = 0.0; sl = thr; su = thr;
+                const double r0[4] = { thr - dlc, thr + duc2, thr, thr };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[i] = r0[i] > thr ? r0[i] : thr; lam[i] = mu0 * rcp_nr(t[i]); }
+                if (!first && lane < 7) IFm[LD::IF_Z + lane] = IFm[LD::IF_ZC + lane];
+                dx6 = dact ? z6c + xh6_own : 0.0;
+                const double q0[2] = { dx6 - PK_DDL, PK_DDU - dx6 };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { Dt[i] = dact ? (q0[i] > thr ? q0[i] : thr) : 1.0; Dlam[i] = dact ? mu0 * rcp_nr(Dt[i]) : 0.0; }
+                alpha_prev = 1.0; stp_local = 1e300;
+                WSYNC();
+            };
+            if (!solved)
+            for (; it < itmax + (cons ? fbit : 0); ++it) {
+                if (it == 0) __builtin_amdgcn_s_setprio(1);
+                if (it == 2) __builtin_amdgcn_s_setprio(2);
+                if (it == 4) __builtin_amdgcn_s_setprio(3);
+                int lz = lane;
+                asm volatile("" : "+v"(lz));
+                const bool uz = lz < n;
+                double ru, mu, Dbar, S_i, dlam_tot, g56_tot;
+                {
+                    double musum = 0.0, cmax = 0.0, rineq = 0.0;
+                    double G0, G1, G2, G3;
+                    {
+                        const double i0 = rcp_nr(t[0]), i1 = rcp_nr(t[1]), i2_ = rcp_nr(t[2]), i3 = rcp_nr(t[3]);
+                        G0 = lam[0] * i0; G1 = lam[1] * i1; G2 = lam[2] * i2_; G3 = lam[3] * i3;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const double rci = t[i] * lam[i]; musum += uact ? rci : 0.0; cmax = fmax(cmax, uact ? rci : 0.0); }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { const double rci = Dt[i] * Dlam[i]; musum += dact ? rci : 0.0; cmax = fmax(cmax, dact ? rci : 0.0); }
+                    const double G56 = Dlam[0] * rcp_nr(Dt[0]) + Dlam[1] * rcp_nr(Dt[1]);
+                    Dbar = uact ? Rj + G0 * G2 * rcp_nr(G0 + G2) + G1 * G3 * rcp_nr(G1 + G3) : 1.0;
+                    cb[lane] = uact ? du : 0.0;
+                    const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
+                    dlam_tot = rdlane(dlam_pref, 63);
+                    sb[lane] = dlam_tot - dlam_pref;                         // suffix over stages > lane
+                    const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? G56 : 0.0);
+                    g56_tot = rdlane(Ssuf_incl, 63);
+                    sb2[lane] = g56_tot - Ssuf_incl;
+                    WSYNC();
+                    double hdu = 0.0;
+                    {
+                        double Rd3[3];
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) Rd3[m] = cb[16 * m + (lane & 15)];
+                        double hv[n];
+                        sym_row_40_b<NR>(hv, row_addr(Hp, Hb, lz), lds_byte_addr(Hp + (uz ? lz : 0)));
+                        static_for<0, n>([&](auto cc) __attribute__((always_inline)) {
+                            constexpr int c = decltype(cc)::value;
+                            fmac_rowbc_ld<c % 16>(hdu, Rd3[c / 16], hv[c]);
+                        });
+                    }
+                    hdu += zgrad(lz);
+                    // stationarity of the inputs / of z_s with the dynamics multipliers of the cuts left out (the primal Newton step does
+                    // not depend on them: rowqp_core.h); the Bbar lanes carry the linear coupling row, whose residual is zero
+                    ru = uact ? hdu + Rj * du + PK_G0 - lam[0] + lam[1] + (ji ? h * sb[ki] : 0.0)
+                              : (zact ? hdu + PK_G0 + (lane == n + 6 ? dlam_tot : 0.0) : 0.0);
+                    S_i = h * h * sb2[uact ? ki : 0];
+                    double rnan;
+                    {
+                        const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+                        const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
+                        const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
+                        double ra = OpMaxNan::f(fabs(rsl), fabs(rsu));
+                        ra = OpMaxNan::f(ra, fabs(rd0)); ra = OpMaxNan::f(ra, fabs(rd1));
+                        const double rb = OpMaxNan::f(fabs(Drd0), fabs(Drd1));
+                        rineq = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
+                        rnan = OpMaxNan::f(fabs(ru), uact ? OpMaxNan::f(fabs(rd2), fabs(rd3)) : 0.0);      // anything non-finite anywhere is a failure
+                    }
+                    // start value of the tracked stationarity residual (only at a start point: rstat < 0)
+                    double rs0 = 0.0;
+                    if (rstat < 0.0) {
+                        if (warmed) {
+                            rs0 = OpMaxNan::f(uact ? fabs(lam[1] - lam[0]) : 0.0, dact ? fabs(Dlam[1] - Dlam[0]) : 0.0);
+                        } else {
+                            const double r_i = Rj * (ubar_i - yrs[(sc >> 1) * 9 + 7 + (sc & 1)]);
+                            const int ks = lane < N ? lane : 0;
+                            const double g6 = Ts * cf->W[6] * (dx6 + xbs[ks * 7 + 6] - yrs[ks * 9 + 6]);
+                            rs0 = OpMaxNan::f(uact ? fabs(r_i - lam[0] + lam[1]) : 0.0, dact ? fabs(g6 - Dlam[0] + Dlam[1]) : 0.0);
+                            rs0 = OpMaxNan::f(rs0, rsx);
+                        }
+                    }
+                    const double mus_w = wave_reduce<OpSum>(musum);
+                    const double cmx_w = wave_reduce<OpMax>(cmax);
+                    const double rin_w = wave_reduce<OpMaxNan>(rineq);
+                    const double stp_w = wave_reduce<OpMax>(stp_local);
+                    const double rs0_w = wave_reduce<OpMaxNan>(rs0);
+                    const double nan_w = wave_reduce<OpMaxNan>(rnan);
+                    if (lane == 0) {
+                        RED(wv_, 0, 0) = mus_w; RED(wv_, 0, 1) = cmx_w; RED(wv_, 0, 2) = rin_w; RED(wv_, 0, 3) = stp_w; RED(wv_, 0, 4) = rs0_w; RED(wv_, 0, 5) = nan_w;
+                    }
+                    XSYNC();
+                    double msum = 0.0, cmx = 0.0, rin = 0.0, stp = -INFINITY, rs0a = 0.0, rna = 0.0;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        msum += RED(s, 0, 0); cmx = fmax(cmx, RED(s, 0, 1)); rin = OpMaxNan::f(rin, RED(s, 0, 2));
+                        stp = fmax(stp, RED(s, 0, 3)); rs0a = OpMaxNan::f(rs0a, RED(s, 0, 4)); rna = OpMaxNan::f(rna, RED(s, 0, 5));
+                    }
+                    mu = msum * inv_nineq; step = stp;
+                    if (rstat < 0.0) rstat = rs0a;
+                    const double rmax = OpMaxNan::f(rin, rstat);
+                    if (!(mu == mu) || !(rmax == rmax) || !(rna == rna)) { failed = true; break; }
+                    if (cmx <= tol_comp && step <= tol_step &&
+                        (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev && rmax <= ADMPC_IPM_FLOOR_CAP * tol_res))) break;      // admpc.h: stopping test
+                    rmax_prev = rmax;
+                }
+                if (fbit > 0 && !cons && it >= fbit) {
+                    cons = true; warmed = false;
+                    cold_start();
+                    rmax_prev = 0.0; rstat = -1.0;
+                    --it;
+                    continue;
+                }
+                factorise(Dbar, (uz && ji) ? S_i : 0.0, lz, !first, h);
+                schur(lz);
+                if (lz == 0) IFm[LD::IF_G56] = g56_tot;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(t[i]), "+v"(lam[i]));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(Dt[i]), "+v"(Dlam[i]));
+                double it_[4], il_[4], rc[4], Dit[2], Dil[2], Drc[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { it_[i] = rcp_nr(t[i]); il_[i] = rcp_nr(lam[i]); rc[i] = t[i] * lam[i]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { Dit[i] = rcp_nr(Dt[i]); Dil[i] = rcp_nr(Dlam[i]); Drc[i] = Dt[i] * Dlam[i]; }
+                const double G0 = lam[0] * it_[0], G1 = lam[1] * it_[1], G2 = lam[2] * it_[2], G3 = lam[3] * it_[3];
+                const double iG02 = rcp_nr(G0 + G2), iG13 = rcp_nr(G1 + G3);
+                const double G5 = Dlam[0] * Dit[0], G6 = Dlam[1] * Dit[1];
+                const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
+                const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
+                const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
+
+                double mu_aff = 0.0, dsl = 0.0, dsu = 0.0, ddu = 0.0, dt[4], dlam[4], Ddt[2], Ddlam[2];
+                bool restarted = false;
+#pragma unroll 1
+                for (int ps = 0; ps < 2; ++ps) {
+                    const double c0 = rc[0] * it_[0], c1 = rc[1] * it_[1], c2 = rc[2] * it_[2], c3 = rc[3] * it_[3];
+                    const double e1 = rsl + c0 + c2 + G0 * rd0 + G2 * rd2;
+                    const double e2 = rsu + c1 + c3 + G1 * rd1 + G3 * rd3;
+                    const double etal = c0 + G0 * rd0 - G0 * e1 * iG02;
+                    const double etau = -c1 - G1 * rd1 + G1 * e2 * iG13;
+                    const double ek = dact ? (Drc[0] * Dit[0] + G5 * Drd0) - (Drc[1] * Dit[1] + G6 * Drd1) : 0.0;
+                    const double epref = wave_scan_incl<OpSum>(ek);
+                    const double ek_tot = rdlane(epref, 63);
+                    sb[lane] = ek_tot - epref;
+                    WSYNC();
+                    const double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : (zact ? -(ru + (lane == n + 6 ? ek_tot : 0.0)) : 0.0);
+                    const double x = coupled_solve(y, lz);
+                    ddu = uact ? x : 0.0;
+                    cb[lane] = ddu;
+                    WSYNC();
+                    const double dz6 = first ? 0.0 : IFm[LD::IF_DZ + 6];
+                    const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
+                    const double pre = wave_scan_incl<OpSum>(du1_stage);
+                    const double ddx6 = dz6 + h * (pre - du1_stage);
+                    dsl = -(e1 + G0 * ddu) * iG02;
+                    dsu = -(e2 - G1 * ddu) * iG13;
+                    dt[0] = ddu + dsl + rd0; dt[1] = -ddu + dsu + rd1; dt[2] = dsl + rd2; dt[3] = dsu + rd3;
+                    const double Gs[4] = { G0, G1, G2, G3 };
+                    double rr = 0.0, sdd = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dlam[i] = -rc[i] * it_[i] - Gs[i] * dt[i];
+                        rr = fmax(rr, uact ? fmax(-dt[i] * it_[i], -dlam[i] * il_[i]) : 0.0);
+                        sdd += uact ? dt[i] * dlam[i] : 0.0;
+                    }
+                    Ddt[0] = ddx6 + Drd0;  Ddlam[0] = -Drc[0] * Dit[0] - G5 * Ddt[0];
+                    Ddt[1] = -ddx6 + Drd1; Ddlam[1] = -Drc[1] * Dit[1] - G6 * Ddt[1];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        rr = fmax(rr, dact ? fmax(-Ddt[i] * Dit[i], -Ddlam[i] * Dil[i]) : 0.0);
+                        sdd += dact ? Ddt[i] * Ddlam[i] : 0.0;
+                    }
+                    const double rr_w = wave_reduce<OpMax>(rr);
+                    const double sdd_w = wave_reduce<OpSum>(sdd);
+                    if (lane == 0) { RED(wv_, 2 + ps, 0) = rr_w; RED(wv_, 2 + ps, 1) = sdd_w; }
+                    XSYNC();
+                    double rra = 0.0, sdda = 0.0;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) { rra = fmax(rra, RED(s, 2 + ps, 0)); sdda += RED(s, 2 + ps, 1); }
+                    const double amax = rra > 1.0 ? rcp_nr(rra) : 1.0;
+                    if (ps == 0) {
+                        // complementarity after the affine step: sum (t + a dt)(lam + a dlam) = (1 - a) sum t lam + a^2 sum dt dlam (the
+                        // predictor's right-hand side is t lam, so t dlam + lam dt = -t lam exactly: rowqp_core.h uses the same identity)
+                        mu_aff = ((1.0 - amax) * mu * (double)(8 * NT + 2 * (NT - 1)) + amax * amax * sdda) * inv_nineq;
+                        double sigma = mu_aff * rcp_nr(mu); sigma = sigma * sigma * sigma;
+                        if (alpha_prev < ADMPC_IPM_BLOCKED_STEP) sigma = 1.0;
+                        const double smu = fmax(sigma * mu, ADMPC_IPM_MU_FLOOR * tol_comp);
+                        if (!cons) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] + dt[i] * dlam[i] - smu;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] + Ddt[i] * Ddlam[i] - smu;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rc[i] = t[i] * lam[i] - smu;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) Drc[i] = Dt[i] * Dlam[i] - smu;
+                        }
+                    } else {
+                        double tau = 1.0 - mu_aff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+                        const double alpha = fmin(tau * amax, 1.0);
+                        if (it == 0 && warmed && alpha < wrest) {
+                            warmed = false;
+                            cold_start();
+                            restarted = true;
+                        } else {
+                        alpha_prev = alpha;
+                        rstat = (1.0 - alpha) * rstat;
+                        stp_local = uact ? fabs(alpha * ddu) : 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { t[i] = fmax(t[i] + alpha * dt[i], IPM_FLOOR); lam[i] = fmax(lam[i] + alpha * dlam[i], IPM_FLOOR); }
+                        du += alpha * ddu; sl += alpha * dsl; su += alpha * dsu;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            Dt[i] = dact ? fmax(Dt[i] + alpha * Ddt[i], IPM_FLOOR) : 1.0;
+                            Dlam[i] = dact ? fmax(Dlam[i] + alpha * Ddlam[i], IPM_FLOOR) : 1.0;
+                        }
+                        dx6 += dact ? alpha * ddx6 : 0.0;
+                        if (!first && lane < 7) IFm[LD::IF_Z + lane] += alpha * IFm[LD::IF_DZ + lane];
+                        }
+                    }
+                    WSYNC();
+                }
+                if (restarted) { rmax_prev = 0.0; rstat = -1.0; }
+            }
+        }
+        if (failed) break;
+        // ---- the cut states of the returned inputs: Bbar_s U_s + c_s per segment (Hb is still in place), chained below
+        if (S > 1 && !last) {
+            LAUNDER_LANE(lane);
+            const bool uact = lane < n;
+            const double duv = uact ? du : 0.0;
+            const int li = uact ? lane : 0;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const double v = wave_reduce<OpSum>(Hb[(bslot + r) * n + li] * duv);
+                if (lane == 0) IFm[LD::IF_BU + r] = v + IFm[LD::IF_C + r];
+            }
+        }
+        XSYNC();
+        }   // pass
+        { LAUNDER_LANE(lw); if (wv_ == 0 && lw == 0 && itersg) itersg[inst] = it; }
+        if (failed) {
+            // non-finite QP data: acados returns before the update -- the iterate stays as it is, status 4, cost +inf
+            { LAUNDER_LANE(lw); if (wv_ == 0 && lw == 0) { statusg[inst] = ADMPC_STATUS_QP_FAILURE; if (costg) costg[inst] = INFINITY; } }
+            XSYNC();
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
+
+        // =================================================================================================================
+        // phase E (H6): expansion of the segment's states from its cut state, full step, cost, status
+        // =================================================================================================================
+        {
+            LAUNDER_LANE(lane); LAUNDER_CFG(cf);
+            const int ji = lane & 1;
+            const bool uact = lane < n;
+            const int sc = uact ? lane : 0;
+            const double Ts = cf->Ts, h = cf->Ts;
+            const double Rj = Ts * cf->W[NX + ji];
+            const double rho_l = Ts * cf->zl, rho_u = Ts * cf->zu;
+            const int r6 = lane < 6 ? lane : 0;
+            const int r7 = lane < NX ? lane : 0;
+            const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
+            // z_1 = (Bbar U + c)_0, z_{t+1} = Abar_t z_t + (Bbar U + c)_t: lanes 0..6 = components
+            double zs = 0.0;
+            if (!first) {
+                zs = ifb[LD::IF_BU + r7];
+#pragma unroll 1
+                for (int t_ = 1; t_ < wv_; ++t_) {
+                    cb[lane] = zs;
+                    WSYNC();
+                    const double* Ft = ifb + t_ * LD::IFS;
+                    double a = Ft[LD::IF_BU + r7];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) a = fma(Ft[LD::IF_ABAR + r7 * 8 + c], cb[c], a);
+                    WSYNC();
+                    zs = a;
+                }
+            }
+            WSYNC();
+            stage_dq_seg(dqE, xbs, yrs, yre, lane);
+            du = uact ? du : 0.0;
+            dus[lane] = du;
+            const double ubar_i = ubs[sc];
+            const double uref_i = yrs[(sc >> 1) * 9 + 7 + (sc & 1)];
+            double dx = lane < NX ? (first ? x0g[(size_t)inst * NX + r7] - xbg[r7] : zs) : 0.0;
+            WSYNC();
+            bool bad = false;
+            double J = 0.0;
+            static_for<0, N + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const double e = dx + dqE[k * 7 + r7];
+                if (k < N || last) J += 0.5 * (k < N ? wq : wqe) * e * e;      // stage k0 + 20 is the next segment's
+                if (!(fabs(dx) <= 1e300)) bad = true;
+                if (lane < NX) dqE[k * 7 + lane] = dx;
+                if constexpr (k < N) {
+                    const double* Gk = GT + k * GTS;
+                    const double u0 = dus[2 * k], u1 = dus[2 * k + 1];
+                    double acc = bl[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                    double gg[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) gg[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
+                    const double b0 = lane < 6 ? Gk[5 * 6 + r6] : 0.0, b1 = lane < 6 ? Gk[6 * 6 + r6] : (lane == 6 ? h : 0.0);
+                    acc += b0 * u0 + b1 * u1;
+                    fmac_rowbc<2>(acc, dx, gg[0]); fmac_rowbc<3>(acc, dx, gg[1]); fmac_rowbc<4>(acc, dx, gg[2]);
+                    fmac_rowbc<5>(acc, dx, gg[3]); fmac_rowbc<6>(acc, dx, gg[4]);
+                    dx = lane < NX ? acc : 0.0;
+                }
+            });
+            const double unew = ubar_i + du;
+            if (uact && !(fabs(unew) <= 1e300)) bad = true;
+            double Ju = 0.0;
+            if (uact) {
+                const double e = unew - uref_i;
+                Ju = 0.5 * Rj * e * e;
+                if (unew < cf->lbu[ji]) Ju += rho_l * (cf->lbu[ji] - unew);
+                if (unew > cf->ubu[ji]) Ju += rho_u * (unew - cf->ubu[ji]);
+            }
+            const double Jt = wave_reduce<OpSum>(J + Ju);
+            const bool anyb = __any(bad);
+            if (lane == 0) { RED(wv_, 1, 0) = Jt; RED(wv_, 1, 1) = anyb ? 1.0 : 0.0; }
+            XSYNC();                                        // every wave has read what it needs of xbar (the rows at the cuts are shared)
+            double Jall = 0.0; bool badall = false;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { Jall += RED(s, 1, 0); badall = badall || RED(s, 1, 1) != 0.0; }
+            const int status = badall ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
+            if (status == 0) {
+                // rows k0 + 1 .. k0 + 20 (the first segment: row 0 as well); the row at the cut is written by the segment in front of it
+                const int lo = first ? 0 : NX;
+#pragma unroll
+                for (int i0 = 0; i0 < (N + 1) * NX; i0 += WAVE) { const int i = i0 + lane; if (i >= lo && i < (N + 1) * NX) STG(xbs + i, LDG(xbs + i) + dqE[i]); }
+                if (uact) STG(ubs + lane, unew);
+            }
+            if (wv_ == 0 && lane == 0) {
+                if (costg) costg[inst] = status == 0 ? Jall : INFINITY;
+                statusg[inst] = status;
+            }
+            XSYNC();
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    // ---- every workgroup has drawn exactly one ticket beyond the batch; the last one to leave clears tickets and bins for the next launch
+    if (wv_ == 0) {
+        LAUNDER_LANE(lane0);
+        int gone = 0;
+        if (lane0 == 0) gone = atomicAdd(sched + 1, 1);
+        gone = __builtin_amdgcn_readfirstlane(gone);
+        if (gone == (int)gridDim.x - 1) { sched[lane0] = 0; sched[64 + lane0] = 0; __threadfence(); }
+    }
+#undef PK_DL
+#undef PK_DUU
+#undef PK_G0
+#undef PK_DDL
+#undef PK_DDU
+#undef RED
+}
+
+}  // namespace
+
+template <int S>
+static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
+        const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap)
+{
+    const int lds = SegLds<S>::total * (int)sizeof(double);
+    // persistent grid: as many workgroups per CU as LDS (160 KB) and wave slots (two per SIMD) allow
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 8 / S) per_cu = 8 / S;
+    if (per_cu < 1) per_cu = 1;
+    int grid = num_cu * per_cu; if (grid > B) grid = B;
+    static bool prepared = false;
+    if (!prepared) {
+        (void)hipFuncSetAttribute((const void*)admpc_seg_kernel<S, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)admpc_seg_kernel<S, 127>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        prepared = true;
+    }
+    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref_e, sched, cap);
+    if (qmask == 7)
+        hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap);
+    else
+        hipLaunchKernelGGL((admpc_seg_kernel<S, 127>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap);
+}
+
+// ---- host side (called by solve_impl in admpc_kernels.hip)
+extern "C" {
+
+// bring-up builds only: copy the dump buffer (4 waves x 2 points x 16384 doubles) to the host; 1 when the build carries none
+int admpc_debug_seg(double* out, int inst)
+{
+#ifdef SEG_DEBUG
+    if (out) {
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seg_dbg), sizeof(double) * 4 * 2 * SEG_DBG_W) != hipSuccess) return -1;
+    } else if (hipMemcpyToSymbol(HIP_SYMBOL(g_seg_dbg_inst), &inst, sizeof(int)) != hipSuccess) return -1;
+    return 0;
+#else
+    (void)out; (void)inst;
+    return 1;
+#endif
+}
+
+// horizons this unit serves (fp64): N = 20 S, S = 2, 3, 4
+__attribute__((visibility("hidden"))) int admpc_seg_supports(int N) { return N == 40 || N == 60 || N == 80; }
+
+__attribute__((visibility("hidden"))) int admpc_seg_lds_bytes(int N)
+{
+    switch (N / 20) {
+        case 2: return SegLds<2>::total * (int)sizeof(double);
+        case 3: return SegLds<3>::total * (int)sizeof(double);
+        default: return SegLds<4>::total * (int)sizeof(double);
+    }
+}
+
+// grid: persistent workgroups of S waves; sched: admpc_fused20_sched_ints(cap) ints, zeroed at allocation (the kernel re-arms them)
+__attribute__((visibility("hidden"))) void admpc_seg_launch(int N, int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
+        const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap)
+{
+    switch (N / 20) {
+        case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap); break;
+        case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap); break;
+        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap); break;
+    }
+}
+
+}

@@ -26,7 +26,7 @@ def _rows(n):
     return [(16 * r, min(16 * r + 15, n - 1)) for r in range((n + 15) // 16)]
 
 
-def _subst_blocked(n, forward):
+def _subst_blocked(n, forward, nrows=None):
     """Blocked triangular substitution without v_readlane (see the module docstring for the register contract).
 
     The wave's 16-lane rows are the blocks.  Inside a block a step is ONE instruction: the multiplier y_j reaches the lanes of
@@ -39,16 +39,23 @@ def _subst_blocked(n, forward):
     EXEC masks (s_bfm_b64) as predicates, immediate offsets off one base register.
       forward : L z = y   (unit lower L, lane i reads L[i][j] at row base + 8 j)
       backward: L' x = z  (lane i reads L[j][i] at column base + 8 j (j + 1) / 2)"""
-    rows = _rows(n)
+    # nrows > n (forward only): BORDER rows ride along -- lanes n .. nrows-1 hold rows of a second matrix C (row address in the same
+    # register, entries at row base + 8 j) and receive y_b -= sum_j C[b][j] z_j, i.e. on return they hold y_b - C L^-T... (C L^-1-applied):
+    # the reduced right-hand side of the bordered system (admpc_seg.hip)
+    nrows = n if nrows is None else nrows
+    assert forward or nrows == n
+    rows = _rows(nrows)
     off = (lambda j: 8 * j) if forward else (lambda j: 8 * (j * (j + 1) // 2))
     out = ["s_mov_b64 s[%d:%d], exec" % (SAVE, SAVE + 1)]
     order = rows if forward else rows[::-1]
     # in-block steps, in execution order: (j, lo, hi) with lanes lo..hi enabled (targets + the source lane j)
     inblk = []
+    nin = []                                       # in-block steps per row block
     for (r0, r1) in order:
-        js = range(r0, r1) if forward else range(r1, r0, -1)
+        js = [j for j in range(r0, r1) if j < n] if forward else list(range(r1, r0, -1))
         for j in js:
             inblk.append((j, j, r1) if forward else (j, r0, j))
+        nin.append(len(js))
     issued = []
     cur_exec = [None]
     def set_exec(lo, hi):
@@ -71,7 +78,7 @@ def _subst_blocked(n, forward):
     s = 0
     WAIT_EVERY = 4
     for bi, (r0, r1) in enumerate(order):
-        nsteps = (r1 - r0)
+        nsteps = nin[bi]
         waited_through = s - 1
         for _ in range(nsteps):
             j, lo, hi = inblk[s]
@@ -87,12 +94,13 @@ def _subst_blocked(n, forward):
                 load_in(s + D)
             s += 1
         rest = order[bi + 1:]
-        if not rest:
+        if not rest or r0 >= n:
             break
         # publish the block, read it back into every row, update the remaining rows
         tlo, thi = min(r[0] for r in rest), max(r[0] for r in rest) + 15      # WHOLE rows: a DPP source lane must be enabled, also beyond n
-        cols = list(range(r0, r1 + 1)) if forward else list(range(r1, r0 - 1, -1))
-        out.append("s_bfm_b64 exec, %d, %d" % (r1 - r0 + 1, r0))
+        c1 = min(r1, n - 1)                                                    # last COLUMN of the block (border rows have no columns)
+        cols = list(range(r0, c1 + 1)) if forward else list(range(r1, r0 - 1, -1))
+        out.append("s_bfm_b64 exec, %d, %d" % (c1 - r0 + 1, r0))
         out.append("s_nop 0")
         out.append("ds_write_b64 v%d, v[%d:%d] offset:%d" % (PUB, Y, Y + 1, 8 * r0))
         out.append("s_bfm_b64 exec, %d, %d" % (thi - tlo + 1, tlo))
@@ -115,15 +123,15 @@ def _subst_blocked(n, forward):
     return out
 
 
-def fwd(n):
-    return _subst_blocked(n, True)
+def fwd(n, nrows=None):
+    return _subst_blocked(n, True, nrows)
 
 
 def bwd(n):
     return _subst_blocked(n, False)
 
 
-def rowbuild(n, lo, hi):
+def rowbuild(n, lo, hi, nrows=None):
     """Newton-matrix row of this lane, columns lo..hi-1: a[c] = (c <= lane ? H[lane][c] : 0) + (c odd ? s_odd : 0) + (c == lane ? dbar : 0).
     Operands: %0..%(hi-lo-1) the row entries (outputs), then the lane's row address in LDS, dbar, s_odd.  Predicates are
     EXEC masks (s_bfm_b64), all loads are in flight together, one wait."""
@@ -133,7 +141,7 @@ def rowbuild(n, lo, hi):
         out.append("v_mov_b64 %%%d, 0" % q)
     for q in range(cnt):
         c = lo + q
-        out.append("s_bfm_b64 exec, %d, %d" % (n - c, c))                      # lanes c .. n-1
+        out.append("s_bfm_b64 exec, %d, %d" % ((nrows or n) - c, c))           # lanes c .. n-1 (.. nrows-1: border rows are full rows)
         out.append("ds_read_b64 %%%d, %%%d offset:%d" % (q, A, 8 * c))
     out.append("s_mov_b64 exec, s[%d:%d]" % (SAVE, SAVE + 1))
     out.append("s_waitcnt lgkmcnt(0)")
@@ -161,7 +169,7 @@ def rowstore(n, lo, hi):
     return out
 
 
-def symrow(n, lo, hi):
+def symrow(n, lo, hi, nrows=None):
     """Row of the symmetric matrix stored as packed lower-triangular rows, columns lo..hi-1, for the mat-vec: lanes >= c read
     H[lane][c] (row address + 8 c), lanes < c read H[c][lane] (column address + 8 c (c + 1) / 2) -- two EXEC-masked loads per
     column into the same register, all in flight together.  Operands: %0..%(hi-lo-1) outputs, then row address, column address.
@@ -172,7 +180,7 @@ def symrow(n, lo, hi):
         out.append("v_mov_b64 %%%d, 0" % q)
     for q in range(cnt):
         c = lo + q
-        out.append("s_bfm_b64 exec, %d, %d" % (n - c, c))
+        out.append("s_bfm_b64 exec, %d, %d" % ((nrows or n) - c, c))           # border rows (lanes n .. nrows-1) read their full rows
         out.append("ds_read_b64 %%%d, %%%d offset:%d" % (q, RA, 8 * c))
         if c > 0:
             out.append("s_bfm_b64 exec, %d, 0" % c)
@@ -195,6 +203,11 @@ def main():
     txt += emit("ADMPC_ROWBUILD_ASM_%d_A" % n, rowbuild(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWBUILD_ASM_%d_B" % n, rowbuild(n, n // 2, n)) + "\n"
     txt += emit("ADMPC_ROWSTORE_ASM_%d_A" % n, rowstore(n, 0, n // 2)) + "\n" + emit("ADMPC_ROWSTORE_ASM_%d_B" % n, rowstore(n, n // 2, n)) + "\n"
     txt += emit("ADMPC_SYMROW_ASM_%d_A" % n, symrow(n, 0, n // 2)) + "\n" + emit("ADMPC_SYMROW_ASM_%d_B" % n, symrow(n, n // 2, n)) + "\n"
+    # bordered variants (admpc_seg.hip): lanes n .. nrows-1 carry full rows of a border matrix through the row build and the forward substitution
+    for nr in (47, 54):
+        txt += emit("ADMPC_FWD_SUBST_ASM_%d_R%d" % (n, nr), fwd(n, nr)) + "\n"
+        txt += emit("ADMPC_ROWBUILD_ASM_%d_A_R%d" % (n, nr), rowbuild(n, 0, n // 2, nr)) + "\n" + emit("ADMPC_ROWBUILD_ASM_%d_B_R%d" % (n, nr), rowbuild(n, n // 2, n, nr)) + "\n"
+        txt += emit("ADMPC_SYMROW_ASM_%d_A_R%d" % (n, nr), symrow(n, 0, n // 2, nr)) + "\n" + emit("ADMPC_SYMROW_ASM_%d_B_R%d" % (n, nr), symrow(n, n // 2, n, nr)) + "\n"
     txt += "#define ADMPC_SUBST_CLOBBERS %s, \"memory\"\n" % clob
     open(sys.argv[1] if len(sys.argv) > 1 else "subst_asm.inc", "w").write(txt)
 
