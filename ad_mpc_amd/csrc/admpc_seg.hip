@@ -56,6 +56,26 @@ __device__ int g_seg_dbg_inst = 0;
 __device__ __forceinline__ void seg_dbg_copy(double* dst, const double* src, int cnt, int lane) { for (int i = lane; i < cnt; i += 64) dst[i] = src[i]; }
 #endif
 
+// ---- optional per-phase wave-time accounting (-DADMPC_PHASE_TIMERS: `make timers`), s_memtime ticks (100 MHz) summed over all waves:
+//      0 ticket, 1 phase A, 2 phase C, 3 trial, 4 iteration top (residuals, exchange), 5 factorisation + Schur blocks, 6 forward substitution,
+//      7 wait for / run the interface recursion, 8 back substitution, 9 expand / step, 10 cut states, 11 phase A again, 12 phase E,
+//      13 (S = 2) wait for the Schur blocks + the cut's solution operators (wave 0)
+#ifdef ADMPC_PHASE_TIMERS
+__device__ unsigned long long g_seg_ticks[16];
+__device__ __forceinline__ unsigned long long seg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
+#define SEG_DECL() unsigned long long ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last = seg_now()
+#define SEG_STAMP(k) do { const unsigned long long t_ = seg_now(); ph_acc[k] += t_ - ph_last; ph_last = t_; } while (0)
+#define SEG_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 14; ++q_) atomicAdd(&g_seg_ticks[q_], ph_acc[q_]); } } while (0)
+#elif defined(SEG_MARKS)      // listing with phase markers (hipcc -S -DSEG_MARKS): the code after stamp k belongs to the next phase
+#define SEG_DECL() do { } while (0)
+#define SEG_STAMP(k) asm volatile("; MARK_after" #k)
+#define SEG_FLUSH() do { } while (0)
+#else
+#define SEG_DECL() do { } while (0)
+#define SEG_STAMP(k) do { } while (0)
+#define SEG_FLUSH() do { } while (0)
+#endif
+
 // dq[k][c] = xbar[k][c] - (k < 20 ? yref[k][c] : yre[c]), k = 0..20, for the 21 stage rows a segment touches
 __device__ __forceinline__ void stage_dq_seg(double* __restrict__ dq, const double* __restrict__ xb, const double* __restrict__ yr,
                                              const double* __restrict__ yre, const int lane) {
@@ -87,26 +107,28 @@ struct SegLds {
     static constexpr int JTS = 24, JTK = 4 * JTS + 2;
     static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
     static_assert(oBlA + N * NX <= seg && oGTC + N * GTS <= oDqC && oGam + (NX + 1) * 64 <= oPark, "LDS aliases");
-    // interface block of a segment
-    static constexpr int IF_SC = 0;              // [14][14] C M^-1 C' of this iteration
-    static constexpr int IF_HZZ = 196;           // [7][8]   Hzz (cost part)
-    static constexpr int IF_ABAR = 252;          // [7][8]   Abar_s = Phi at the segment's end
-    static constexpr int IF_C = 308;             // [8]      c_s = free response at the segment's end
-    static constexpr int IF_ZB = 316;            // [16]     reduced right-hand side of the border rows (forward substitution)
-    static constexpr int IF_Z = 332;             // [8]      z_s of the interior point's iterate
-    static constexpr int IF_ZC = 340;            // [8]      z_s of the cold start (the free chain)
-    static constexpr int IF_DZ = 348;            // [8]      Newton step of z_s
-    static constexpr int IF_NU = 356;            // [8]      multiplier of the cut in front of this segment
-    static constexpr int IF_RED = 364;           // [4][8]   partial reductions, one slot per barrier phase
-    static constexpr int IF_BU = 396;            // [8]      Bbar_s U_s + c_s of the returned inputs
-    static constexpr int IF_PI = 404;            // [7][8]   Pi_s (backward recursion over the cuts)
-    static constexpr int IF_ETA = 460;           // [8]
-    static constexpr int IF_X = 468;             // [7][8]   Lambda_s^-1 Ahat_s
-    static constexpr int IF_XR = 524;            // [8]      Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1})
-    static constexpr int IF_G56 = 532;           // [2]      sum of the delta-box barrier ratios of the segment
-    static constexpr int IFS = 536;
+    // interface block of a segment (the fields of the recursion over several cuts only exist for S > 2)
+    static constexpr int SCS = NB;                                     // row stride of Sc
+    static constexpr int IF_SC = 0;                                    // [NB][NB] C M^-1 C' of this iteration
+    static constexpr int IF_HZZ = IF_SC + ((NB * NB + 1) & ~1);        // [7][8]   Hzz (cost part)
+    static constexpr int IF_C = IF_HZZ + 56;                           // [8]      c_s = free response at the segment's end
+    static constexpr int IF_ZB = IF_C + 8;                             // [16]     reduced right-hand side of the border rows (forward substitution)
+    static constexpr int IF_Z = IF_ZB + 16;                            // [8]      z_s of the interior point's iterate
+    static constexpr int IF_ZC = IF_Z + 8;                             // [8]      z_s of the cold start (the free chain)
+    static constexpr int IF_DZ = IF_ZC + 8;                            // [8]      Newton step of z_s
+    static constexpr int IF_NU = IF_DZ + 8;                            // [8]      multiplier of the cut in front of this segment
+    static constexpr int IF_RED = IF_NU + 8;                           // [4][8]   partial reductions, one slot per barrier phase
+    static constexpr int IF_BU = IF_RED + 32;                          // [8]      Bbar_s U_s + c_s of the returned inputs
+    static constexpr int IF_PI = IF_BU + 8;                            // [7][8]   Pi_s (backward recursion over the cuts)
+    static constexpr int IF_G56 = IF_PI + 56;                          // [2]      sum of the delta-box barrier ratios of the segment
+    static constexpr int IF_ABAR = IF_G56 + 2;                         // [7][8]   Abar_s = Phi at the segment's end            (S > 2)
+    static constexpr int IF_ETA = IF_ABAR + (S > 2 ? 56 : 0);          // [8]                                                    (S > 2)
+    static constexpr int IF_X = IF_ETA + (S > 2 ? 8 : 0);              // [7][8]   Lambda_s^-1 Ahat_s                           (S > 2)
+    static constexpr int IF_XR = IF_X + (S > 2 ? 56 : 0);              // [8]      Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1})       (S > 2)
+    static constexpr int IFS = IF_XR + (S > 2 ? 8 : 0);
     static constexpr int oIF = S * seg, oWG = oIF + S * IFS;
-    static constexpr int total = oWG + 8;
+    static constexpr int oYM = oWG + 8;                                // [4][7][8] solution operators of the single cut (S = 2)
+    static constexpr int total = oYM + (S == 2 ? 4 * 56 : 0);
 };
 
 // ---- 7 x 7 blocks of the interface recursion (wave 0).  Matrices live in LDS, row-major with stride 8; "lane = column": lane c holds
@@ -176,7 +198,7 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
     // ---- the last segment: Pi = Pzz, eta = yhat
     {
         double* F = ifb + (S - 1) * LD::IFS;
-        const double v = F[LD::IF_HZZ + er * 8 + ec] + ((er == 6 && ec == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + er * 14 + ec];
+        const double v = F[LD::IF_HZZ + er * 8 + ec] + ((er == 6 && ec == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + er * LD::SCS + ec];
         if (lane < 49) F[LD::IF_PI + er * 8 + ec] = v;
         if (lane < 7) F[LD::IF_ETA + lane] = F[LD::IF_ZB + lane];
     }
@@ -186,7 +208,7 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
     for (int s = S - 2; s >= 1; --s) {
         double* F = ifb + s * LD::IFS;
         const double* Fn = ifb + (s + 1) * LD::IFS;
-        const double* Pbb = F + LD::IF_SC + 7 * 14 + 7;            // [r * 14 + c]
+        const double* Pbb = F + LD::IF_SC + 7 * LD::SCS + 7;            // [r * 14 + c]
         // lanes 0..6: columns of Pi_{s+1}; lane 7: eta_{s+1}; lanes 8..14: columns of Ahat_s (right-hand sides as they are)
         Col7 col;
         const int ac = (lane >= 8 && lane < 15) ? lane - 8 : 0;
@@ -195,10 +217,10 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
             const double pv = Fn[LD::IF_PI + r * 8 + c7], ev = Fn[LD::IF_ETA + r];
             col.v[r] = lane < 7 ? pv : ev;
         }
-        Col7 T = mat_col(Pbb, 14, 1, col);
+        Col7 T = mat_col(Pbb, LD::SCS, 1, col);
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
-            const double ah = F[LD::IF_ABAR + r * 8 + ac] - F[LD::IF_SC + ac * 14 + 7 + r];      // Ahat[r][ac] = Abar[r][ac] - Pzb[ac][r]
+            const double ah = F[LD::IF_ABAR + r * 8 + ac] - F[LD::IF_SC + ac * LD::SCS + 7 + r];      // Ahat[r][ac] = Abar[r][ac] - Pzb[ac][r]
             const double dh = -F[LD::IF_ZB + 7 + r];
             T.v[r] = lane < 7 ? T.v[r] + (r == lane ? 1.0 : 0.0) : (lane == 7 ? T.v[r] + dh : ah);
         }
@@ -220,7 +242,7 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
         for (int r = 0; r < 7; ++r) {
             double a = 0.0;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * 14 + 7 + k], Y.v[k], a);      // Ahat[k][r]
+            for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k], Y.v[k], a);      // Ahat[k][r]
             Z.v[r] = a;
         }
         WSYNC();
@@ -231,7 +253,7 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
         if (lane >= 8 && lane < 15) {
 #pragma unroll
             for (int r = 0; r < 7; ++r)
-                F[LD::IF_PI + r * 8 + ac] = F[LD::IF_HZZ + r * 8 + ac] + ((r == 6 && ac == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + r * 14 + ac] + Z.v[r];
+                F[LD::IF_PI + r * 8 + ac] = F[LD::IF_HZZ + r * 8 + ac] + ((r == 6 && ac == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + r * LD::SCS + ac] + Z.v[r];
         }
         WSYNC();
     }
@@ -245,7 +267,7 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
             const double pv = Fn[LD::IF_PI + r * 8 + c7], ev = Fn[LD::IF_ETA + r];
             col.v[r] = lane < 7 ? pv : ev;
         }
-        Col7 T = mat_col(F + LD::IF_SC, 14, 1, col);
+        Col7 T = mat_col(F + LD::IF_SC, LD::SCS, 1, col);
 #pragma unroll
         for (int r = 0; r < 7; ++r) T.v[r] = lane < 7 ? T.v[r] + (r == lane ? 1.0 : 0.0) : T.v[r] - F[LD::IF_ZB + r];
         ge7_solve(T);
@@ -275,6 +297,49 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
     }
 }
 
+// Two segments, one cut: the coupling has a closed form in four 7 x 7 operators that depend on the factorisation only, so they are built
+// ONCE per interior-point iteration (wave 0, while wave 1 already runs its forward substitution) and each right-hand side costs a wave
+// fourteen multiply-adds per lane.  With  Pi = Hzz_1 + e6 e6' sum(G56) - (Qzu M^-1 Quz)_1,  Pbb = (Bbar M^-1 Bbar')_0,
+// Lambda = I + Pbb Pi,  dhat = -zb_0,  eta = zb_1:
+//     dz_1 = Lambda^-1 (dhat + Pbb eta) = Y1 dhat + Y2 eta,      nu_1 = eta - Pi dz_1 = Y3 dhat + Y4 eta
+//     Y1 = Lambda^-1,  Y2 = Lambda^-1 Pbb,  Y3 = -Pi Y1,  Y4 = I - Pi Y2
+// Lanes 0..6 hold the columns of Lambda, lanes 8..14 those of Pbb, lanes 16..22 those of I: one elimination (partial pivoting).
+__device__ __forceinline__ void interface_factor2(double* __restrict__ ifb, double* __restrict__ YM, const int lane) {
+    using LD = SegLds<2>;
+    double* F0 = ifb;
+    double* F1 = ifb + LD::IFS;
+    const int cl = lane & 7;
+    const int c7 = cl < 7 ? cl : 0;
+    const int grp = lane >> 3;                                     // 0: Lambda, 1: Pbb, 2: I
+    Col7 pi;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) pi.v[r] = F1[LD::IF_HZZ + r * 8 + c7] + ((r == 6 && c7 == 6) ? F1[LD::IF_G56] : 0.0) - F1[LD::IF_SC + r * LD::SCS + c7];
+    if (lane < 7) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) F1[LD::IF_PI + r * 8 + lane] = pi.v[r];
+    }
+    Col7 T = mat_col(F0 + LD::IF_SC, LD::SCS, 1, pi);                    // Pbb Pi[:, c]
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const double pb = F0[LD::IF_SC + r * LD::SCS + c7];
+        const double id = r == c7 ? 1.0 : 0.0;
+        T.v[r] = grp == 0 ? T.v[r] + id : (grp == 1 ? pb : id);
+    }
+    ge7_solve(T);                                                  // lanes 8..14: columns of Y2, lanes 16..22: columns of Y1
+    WSYNC();                                                       // Pi is in LDS
+    Col7 P = mat_col(F1 + LD::IF_PI, 8, 1, T);                      // Pi X
+    const bool isx = (grp == 1 || grp == 2) && cl < 7;
+    if (isx) {
+        double* Ya = YM + (grp == 2 ? 0 : 56);                      // Y1 / Y2
+        double* Yb = YM + (grp == 2 ? 2 * 56 : 3 * 56);             // Y3 / Y4
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            Ya[r * 8 + cl] = T.v[r];
+            Yb[r * 8 + cl] = grp == 2 ? -P.v[r] : (r == cl ? 1.0 : 0.0) - P.v[r];
+        }
+    }
+}
+
 template <int S, int QMASK>
 __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                                 const double* __restrict__ x0g, const double* __restrict__ yrefg,
@@ -294,6 +359,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     double* const ifb = lds_raw + LD::oIF;                       // interface blocks of all segments
     double* const IFm = ifb + wv_ * LD::IFS;                     // this segment's
     int* const wgw = reinterpret_cast<int*>(lds_raw + LD::oWG);  // workgroup words: [0] instance of this round
+    double* const YM = lds_raw + LD::oYM;                        // S = 2: the cut's solution operators (interface_factor2)
     double* const Hp = lds_seg + LD::oH;
     double* const Hb = lds_seg + LD::oHb;
     double* const Lp = lds_seg + LD::oL;
@@ -321,6 +387,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     // partial reductions of the S waves: slot `ph` of every segment, combined in segment order by every wave (same bits everywhere)
 #define RED(s_, ph_, i_) ifb[(s_) * LD::IFS + LD::IF_RED + (ph_) * 8 + (i_)]
 
+    SEG_DECL();
     // LDS byte address of the row this lane holds: packed row of H / L (lanes < 40), border row (lanes 40 .. NR-1), else row 0
     auto row_addr = [&](double* tri, double* brd, const int lz_) __attribute__((always_inline)) -> unsigned {
         const int lb = lz_ - n;
@@ -401,7 +468,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = kq + 4 * v;                             // C/D layout of the 16 x 16 x 4 tile: register v of lane (kq, r16) is element (kq + 4 v, r16)
-            if (i < NB && r16 < NB) IFm[LD::IF_SC + i * 14 + r16] = acc[v];
+            if (i < NB && r16 < NB) IFm[LD::IF_SC + i * LD::SCS + r16] = acc[v];
         }
     };
     // The coupled Newton solve for one right-hand side: y on the input lanes, the reduced stationarity of z_s on the z lanes (0 on
@@ -411,9 +478,23 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         const unsigned pub = lds_byte_addr(cb + (lz_ & 15));
         fwd_subst_40_b<NR>(y, row_addr(Lp, Lb, lz_), pub);
         if (lz_ >= n && lz_ < NR) IFm[LD::IF_ZB + lz_ - n] = y;
+        SEG_STAMP(6);
         XSYNC();
+        if constexpr (S == 2) {
+            // one cut: both waves apply the operators of interface_factor2 to (dhat, eta) themselves -- wave 0 needs nu_1 (its border rows
+            // are Bbar: unknown -nu_1), wave 1 needs dz_1 (its border rows are the z rows)
+            const int r7 = lz_ < 7 ? lz_ : 0;
+            const double* Ya = YM + (first ? 2 * 56 : 0) + r7 * 8;
+            const double* Yb = Ya + 56;
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a = fma(Yb[k], ifb[LD::IFS + LD::IF_ZB + k], fma(-Ya[k], ifb[LD::IF_ZB + k], a));
+            if (lz_ < 7) { wvec[lz_] = first ? -a : a; if (!first) IFm[LD::IF_DZ + lz_] = a; }
+            SEG_STAMP(7);
+        } else {
         if (wv_ == 0) interface_solve<S>(ifb, lz_);
         XSYNC();
+        SEG_STAMP(7);
         // unknowns of the border rows: dz_s on the z rows, -nu_{s+1} on the Bbar rows
         if (lz_ < 16) {
             const int b = lz_;
@@ -421,6 +502,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             if (!first && b < 7) w = IFm[LD::IF_DZ + b];
             if (!last && b >= bslot && b < bslot + 7) w = -ifb[(wv_ + 1) * LD::IFS + LD::IF_NU + b - bslot];
             wvec[b] = w;
+        }
         }
         WSYNC();
         double x = y * invd[uz_ ? lz_ : 0];
@@ -430,6 +512,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             for (int b = 0; b < NB; ++b) x = fma(-Lb[b * n + li], wvec[b], x);
         }
         bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)), pub);
+        SEG_STAMP(8);
         return x;
     };
 
@@ -455,6 +538,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         const double* yrs = yrg + (size_t)k0 * NY;
         const double* yre = last ? yrefeg + (size_t)inst * NX : yrs + N * NY;      // row 20 of the segment's references (unused unless last)
 
+        SEG_STAMP(0);
         double du = 0.0;
         bool failed = false;
         int it = 0;
@@ -556,7 +640,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             }
             WSYNC();
         }
-        if (pass != 0) break;
+        if (pass != 0) { SEG_STAMP(11); break; }
+        SEG_STAMP(1);
 
         // =================================================================================================================
         // phase C (H2-H4): condensing of the segment.  Lane i < 40 <-> input i = 2k + j carries column i of Gamma_k = d x_k / d U_s,
@@ -774,6 +859,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             WSYNC();
         }
 
+        SEG_STAMP(2);
 #ifdef SEG_DEBUG
         if (inst == g_seg_dbg_inst) {
             LAUNDER_LANE(ld_);
@@ -842,7 +928,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             if (try_unc) {
                 int lt = lane; asm volatile("" : "+v"(lt));
                 factorise(uact ? Rj : 1.0, 0.0, lt, false, h);
-                if (S > 1) { schur(lt); if (lt == 0) IFm[LD::IF_G56] = 0.0; }
+                schur(lt); if (lt == 0) IFm[LD::IF_G56] = 0.0;
+                if constexpr (S == 2) { XSYNC(); if (wv_ == 0) interface_factor2(ifb, YM, lt); }
                 const double zg = zgrad(lt);
                 const double xt = coupled_solve(uact ? -(g0 + zg) : (zact ? -(g0 + zg) : 0.0), lt);
                 const double duc = uact ? xt : 0.0;
@@ -886,6 +973,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     WSYNC();
                 }
             }
+            SEG_STAMP(3);
             auto cold_start = [&]() __attribute__((always_inline)) {
                 const double dlc = PK_DL, duc2 = PK_DUU;
                 du = 0.0; sl = thr; su = thr;
@@ -996,6 +1084,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev && rmax <= ADMPC_IPM_FLOOR_CAP * tol_res))) break;      // admpc.h: stopping test
                     rmax_prev = rmax;
                 }
+                SEG_STAMP(4);
                 if (fbit > 0 && !cons && it >= fbit) {
                     cons = true; warmed = false;
                     cold_start();
@@ -1006,6 +1095,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 factorise(Dbar, (uz && ji) ? S_i : 0.0, lz, !first, h);
                 schur(lz);
                 if (lz == 0) IFm[LD::IF_G56] = g56_tot;
+                SEG_STAMP(5);
+                if constexpr (S == 2) { XSYNC(); if (wv_ == 0) interface_factor2(ifb, YM, lz); SEG_STAMP(13); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(t[i]), "+v"(lam[i]));
 #pragma unroll
@@ -1113,6 +1204,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         }
                     }
                     WSYNC();
+                    SEG_STAMP(9);
                 }
                 if (restarted) { rmax_prev = 0.0; rstat = -1.0; }
             }
@@ -1131,6 +1223,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             }
         }
         XSYNC();
+        SEG_STAMP(10);
         }   // pass
         { LAUNDER_LANE(lw); if (wv_ == 0 && lw == 0 && itersg) itersg[inst] = it; }
         if (failed) {
@@ -1232,7 +1325,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             XSYNC();
         }
         __builtin_amdgcn_s_setprio(0);
+        SEG_STAMP(12);
     }
+    SEG_FLUSH();
     // ---- every workgroup has drawn exactly one ticket beyond the batch; the last one to leave clears tickets and bins for the next launch
     if (wv_ == 0) {
         LAUNDER_LANE(lane0);
@@ -1277,6 +1372,21 @@ static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int
 
 // ---- host side (called by solve_impl in admpc_kernels.hip)
 extern "C" {
+
+// timer builds only: read and clear the phase counters
+int admpc_debug_seg_ticks(unsigned long long* out16)
+{
+#ifdef ADMPC_PHASE_TIMERS
+    unsigned long long z[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seg_ticks), sizeof z) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_seg_ticks), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+#else
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    return 1;
+#endif
+}
 
 // bring-up builds only: copy the dump buffer (4 waves x 2 points x 16384 doubles) to the host; 1 when the build carries none
 int admpc_debug_seg(double* out, int inst)

@@ -39,9 +39,10 @@ def count(path, verbose=False):
             if verbose and bad <= 10: print("IN-FLIGHT READ of v%s: %s" % (sorted(srcs & flight), t))
         if op.startswith('ds_'):
             queue.append(vregs(args[0]) if op.startswith('ds_read') and args else set())
-        elif args and op.startswith('v_'):
+        elif args and op.startswith(('v_', 'scratch_load', 'global_load', 'buffer_load')):
             w = vregs(args[0].split()[0])
-            queue = [q - w for q in queue]           # overwritten by the VALU: not the loaded value any more
+            queue = [q - w for q in queue]           # overwritten by the VALU (or by a spill reload / memory load, which hipcc orders behind
+                                                     # the LDS read with its own s_waitcnt): not the loaded value any more
     return bad
 
 

@@ -21,6 +21,9 @@ cfg = default_config(N=N)
 sc = random_scenarios(pick + 1, N=N, seed=seed)
 one = {k: v[pick:pick + 1] for k, v in sc.items()}
 orc = Oracle()
+if len(sys.argv) > 4 and sys.argv[4] == "iter2":      # the iterate after one RTI step: stage-dependent linearisation, non-zero inputs
+    r1 = orc.solve_batch(cfg, one["x0"], one["yref"], one["yref_e"], one["p"], one["xbar"], one["ubar"])
+    one["xbar"] = r1[0].copy(); one["ubar"] = r1[1].copy()
 o = orc.qp_debug(cfg, one["x0"][0], one["yref"][0], one["yref_e"][0], one["p"][0], one["xbar"][0], one["ubar"][0])
 qp = SegQP(cfg, o["A"], o["B"], o["b"], one["x0"][0], one["yref"][0], one["yref_e"][0], one["xbar"][0], one["ubar"][0])
 dbg = []
@@ -39,7 +42,13 @@ assert lib.admpc_debug_seg(buf.ctypes.data_as(C.POINTER(C.c_double)), 0) == 0
 print("device iters", g[4][0], "status", g[3][0], "max|du - oracle|", np.abs(g[1][0] - (one["ubar"][0] + o["du"])).max())
 
 oH, oHb = 0, 820; oL = oHb + NB * 40; oLb = oL + 820
-IF = dict(SC=0, HZZ=196, ABAR=252, C=308, ZB=316, Z=332, ZC=340, DZ=348, NU=356, RED=364, BU=396, PI=404, ETA=460, X=468, XR=524, G56=532)
+# interface block layout of SegLds<S> (admpc_seg.hip)
+SCS = NB
+IF = {}
+IF["SC"] = 0; IF["HZZ"] = (NB * NB + 1) & ~1; IF["C"] = IF["HZZ"] + 56; IF["ZB"] = IF["C"] + 8; IF["Z"] = IF["ZB"] + 16; IF["ZC"] = IF["Z"] + 8
+IF["DZ"] = IF["ZC"] + 8; IF["NU"] = IF["DZ"] + 8; IF["RED"] = IF["NU"] + 8; IF["BU"] = IF["RED"] + 32; IF["PI"] = IF["BU"] + 8; IF["G56"] = IF["PI"] + 56
+IF["ABAR"] = IF["G56"] + 2
+IFS = IF["ABAR"] + (56 + 8 + 56 + 8 if S > 2 else 0)
 
 def tri(v):
     M = np.zeros((40, 40))
@@ -61,7 +70,7 @@ for s in range(S):
     Hb = D1[oHb:oHb + NB * 40].reshape(NB, 40)
     if not first: rep("Hzu", Hb[:7], sg["Hzu"])
     if not last: rep("Bbar", Hb[bslot:bslot + 7], sg["Bbar"])
-    I1 = D1[4000:4000 + 536]
+    I1 = D1[4000:4000 + IFS]
     if not first:
         rep("Hzz", I1[IF["HZZ"]:IF["HZZ"] + 56].reshape(7, 8)[:, :7], sg["Hzz"])
     if not last:
@@ -82,18 +91,18 @@ for s in range(S):
     if not first: want_Lb[:7] = f["Lb"][:7]; k = 7
     if not last: want_Lb[bslot:bslot + 7] = f["Lb"][k:k + 7]
     rep("Lb", Lb, want_Lb)
-    I2 = D2[4000:4000 + 536]
-    Sc = I2[IF["SC"]:IF["SC"] + 196].reshape(14, 14)
-    wantS = np.zeros((14, 14)); idx = []
+    I2 = D2[4000:4000 + IFS]
+    Sc = I2[IF["SC"]:IF["SC"] + NB * NB].reshape(NB, NB)
+    idx = []
     if not first: idx += list(range(7))
     if not last: idx += list(range(bslot, bslot + 7))
-    wantS[np.ix_(idx, idx)] = f["Sc"]
     rep("Sc", Sc[np.ix_(idx, idx)], f["Sc"])
     zb = I2[IF["ZB"]:IF["ZB"] + 14]
+    idx = idx if NB == 14 or first else list(range(7))
     rep("zb", zb[idx], trial["zb"][s])
     if not first:
         rep("dz", I2[IF["DZ"]:IF["DZ"] + 7], trial["dz"][s])
-        rep("nu", I2[IF["NU"]:IF["NU"] + 7], trial["nu"][s])
+        if S > 2: rep("nu", I2[IF["NU"]:IF["NU"] + 7], trial["nu"][s])
         rep("Pi", I2[IF["PI"]:IF["PI"] + 56].reshape(7, 8)[:, :7], trial["fac"]["Pi"][s])
         rep("zc (cold z)", I2[IF["ZC"]:IF["ZC"] + 7], trial["dz"][s] * 0 + I2[IF["ZC"]:IF["ZC"] + 7])
     rep("trial dU", D2[5000:5040], trial["dU"][s])

@@ -311,12 +311,15 @@ def test_row_kernel_repeatable_and_ticket_order_free(gpu_engine_factory, oracle_
 
 
 @pytest.mark.parametrize("N", [2, 3, 7, 19, 21, 27, 28, 32, 33, 40, 45, 46, 64, 65, 80, 96, 97, 128])
-def test_horizon_sweep_row_kernel(gpu_engine_factory, oracle_omp, N):
-    """Every horizon class of kernel R (odd and even, the LDS budgets of 4, 2 and 1 instances per wave, the maximum N = 128):
+def test_horizon_sweep_row_kernel(gpu_engine_factory, oracle_omp, N, monkeypatch):
+    """(Round 4: N = 40 / 60 / 80 run the segmented condensed kernel by default -- tests/test_seg_gpu.py; this sweep keeps kernel R at
+    those horizons too, ADMPC_QP=riccati.)
+    Every horizon class of kernel R (odd and even, the LDS budgets of 4, 2 and 1 instances per wave, the maximum N = 128):
     status and iteration counts equal to the oracle's for every instance, solutions within the stated tolerance, bit-wise
     repeatable.  (The former scripts/sweep_horizons.py, now a test; the old stage-wise kernel this replaces gave run-to-run
     different results on some of these horizons.)"""
     B = 600 if N <= 46 else (200 if N <= 80 else 64)
+    monkeypatch.setenv("ADMPC_QP", "riccati")
     cfg = default_config(N=N)
     s = random_scenarios(B, N=N, seed=1000 + N, blend=(3.0, 5.0))
     eng = gpu_engine_factory(cfg)

@@ -1,0 +1,95 @@
+"""The segmented condensed kernel (admpc_seg.hip: N = 40 / 60 / 80 fp64, S cooperating waves per instance) through the C ABI against the
+CPU oracle: identical statuses and interior-point iteration counts, solutions within the long-horizon tolerance of tests/test_gpu_parity.py
+(1e-7), bit-wise repeatable, independent of the draw order, and in agreement with kernel R (ADMPC_QP=riccati) on the same inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from ad_mpc_amd.config import default_config, tight_config  # noqa: E402
+from ad_mpc_amd.scenarios import random_scenarios  # noqa: E402
+from test_gpu_parity import _assert_parity, TOL_LONG  # noqa: E402
+
+
+def _run(eng, s):
+    return eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+
+
+@pytest.mark.parametrize("N,B,blend,init", [
+    (40, 700, (100.0, 110.0), "x0"), (40, 700, (3.0, 5.0), "x0"), (40, 64, (100.0, 110.0), "zeros"), (40, 1, (3.0, 5.0), "x0"), (40, 3, (100.0, 110.0), "x0"),
+    (60, 300, (3.0, 5.0), "x0"), (60, 300, (100.0, 110.0), "zeros"), (80, 400, (100.0, 110.0), "x0"), (80, 300, (3.0, 5.0), "x0"),
+])
+def test_segmented_kernel_against_the_oracle(gpu_engine_factory, oracle_omp, N, B, blend, init):
+    cfg = default_config(N=N)
+    s = random_scenarios(B, N=N, seed=4000 + N + B, blend=blend, init=init)
+    eng = gpu_engine_factory(cfg)
+    g = _run(eng, s)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    assert (o[3] == 0).all()
+    _assert_parity(g, o, TOL_LONG)
+    g2 = _run(eng, s)                                   # bit-wise repeatable (another draw order of the persistent workgroups)
+    for a, b in zip(g, g2):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("N", [40, 80])
+def test_segmented_and_row_kernel_agree(gpu_engine_factory, oracle_omp, monkeypatch, N):
+    """Two device paths of the same Newton steps: S condensed 20-stage segments (default) and the stage-wise Riccati kernel R.  At the
+    default stop levels (the reference's) the iteration counts are identical.  At the TIGHT levels of rounds 1-2 the stopping test also
+    asks for a last input step <= 1e-6, taken at complementarity 1e-11 .. 1e-13 where the Newton direction itself is only good to ~1e-3
+    relative: instance 282 of the N = 80 batch stops with a step of 0.9992e-6 in the segmented elimination order (10 iterations; the
+    numpy statement tests/seg_spec.py gives the same) and just above 1e-6 in the Riccati order (11).  Stated, not hidden: at the tight
+    levels at most one instance per batch may differ by one iteration; the solutions agree to the tolerance either way."""
+    s = random_scenarios(512, N=N, seed=77, blend=(3.0, 5.0))
+    for cfg, strict in ((default_config(N=N), True), (tight_config(N=N), False)):
+        g_seg = _run(gpu_engine_factory(cfg), s)
+        monkeypatch.setenv("ADMPC_QP", "riccati")
+        g_ric = _run(gpu_engine_factory(cfg), s)
+        monkeypatch.delenv("ADMPC_QP")
+        o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+        _assert_parity(g_ric, o, TOL_LONG)
+        if strict:
+            _assert_parity(g_seg, o, TOL_LONG)
+            np.testing.assert_array_equal(g_seg[4], g_ric[4])
+        else:
+            np.testing.assert_array_equal(g_seg[3], o[3])
+            d = np.abs(g_seg[4] - o[4])
+            assert d.max() <= 1 and (d != 0).sum() <= 1
+            assert np.abs(g_seg[1] - o[1]).max() <= TOL_LONG and np.abs(g_seg[0] - o[0]).max() <= TOL_LONG
+        assert np.abs(g_seg[1] - g_ric[1]).max() <= TOL_LONG
+
+
+def test_segmented_kernel_start_rules(gpu_engine_factory, oracle_omp):
+    """The paths that take the cold-start residual (rolled out at the end of the condensing): trial off, warm start off, forced restart,
+    forced fallback -- N = 40 and N = 80."""
+    for N in (40, 80):
+        s = random_scenarios(256, N=N, seed=21, blend=(3.0, 5.0))
+        for name, val in (("ipm_try_unconstrained", 0.0), ("ipm_warm_thr", 0.0), ("ipm_warm_restart", 0.99), ("ipm_fallback_iter", 3.0)):
+            cfg = tight_config(N=N); setattr(cfg, name, val)
+            g = _run(gpu_engine_factory(cfg), s)
+            o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+            _assert_parity(g, o, TOL_LONG)
+
+
+def test_segmented_kernel_all_state_weights(gpu_engine_factory, oracle_omp):
+    """Weights on every state component (the QMASK = 127 instantiation) and a terminal weight of the stage's size."""
+    cfg = default_config(N=40, q=(10.0, 10.0, 100.0, 2.0, 3.0, 4.0, 5.0), terminal_scale=1e-2)
+    s = random_scenarios(300, N=40, seed=5, blend=(3.0, 5.0))
+    g = _run(gpu_engine_factory(cfg), s)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    _assert_parity(g, o, TOL_LONG)
+
+
+def test_segmented_kernel_failure_and_sqp_passes(gpu_engine_factory, oracle_omp):
+    """A non-finite instance fails alone (status 4, iterate untouched, cost +inf); several RTI passes per call skip it afterwards."""
+    cfg = default_config(N=40, sqp_iters=3)
+    s = random_scenarios(130, N=40, seed=9)
+    s["x0"][17, 3] = np.nan; s["yref"][101, 5, 0] = np.inf
+    g = _run(gpu_engine_factory(cfg), s)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=8)
+    np.testing.assert_array_equal(g[3], o[3])
+    assert g[3][17] == 4 and g[3][101] == 4 and np.isinf(g[2][17])
+    np.testing.assert_array_equal(g[0][17], s["xbar"][17]); np.testing.assert_array_equal(g[1][101], s["ubar"][101])
+    ok = o[3] == 0
+    assert ok.sum() == 128 and o[4][ok].max() < cfg.ipm_iter_max          # every other instance is a well-posed problem in all three passes
+    assert np.abs(g[1][ok] - o[1][ok]).max() <= TOL_LONG and np.abs(g[0][ok] - o[0][ok]).max() <= TOL_LONG
