@@ -1108,7 +1108,7 @@ __attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipS
 {
     const int lds = FusedLds::total * (int)sizeof(double);
     int grid = num_cu * 8; if (grid > B) grid = B;
-    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref_e, sched, cap);
+    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap);
     if (qmask == 7)
         hipLaunchKernelGGL((admpc_fused20_kernel<7>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);
     else

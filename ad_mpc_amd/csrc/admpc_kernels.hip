@@ -1345,7 +1345,8 @@ extern "C" size_t admpc_fused20_sched_ints(int cap);
 extern "C" int admpc_seg_supports(int N);
 extern "C" void admpc_seg_launch(int N, int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap);
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot);
+extern "C" size_t admpc_seg_slot_doubles(int num_cu);
 
 extern "C" {
 
@@ -1537,6 +1538,8 @@ static int ensure_fused(AdmpcSolver* s, int B)                  // fused N = 20 
 {                                                                // (segmented kernel: the work-order lists only)
     // slot buffers only where parking the linearisation beats recomputing it: with GP residuals in the model (see admpc_fused20.hip)
     if (!s->d_slot && s->cfg.n_gp > 0 && !s->use_seg) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
+    // segmented kernel: one packed Hessian per resident wave (its LDS buffer doubles as the factor's)
+    if (!s->d_slot && s->use_seg) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_seg_slot_doubles(s->num_cu) * sizeof(double)));
     if (B <= s->cap_fused) return ADMPC_OK;
     HIPCHK(hipDeviceSynchronize());
     s->cap_fused = 0;
@@ -1688,7 +1691,7 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
         // N = 40 / 60 / 80: S cooperating waves per instance, each condensing 20 stages; no workspace, no kernel boundary (admpc_seg.hip)
         int rc = ensure_fused(s, B); if (rc) return rc;
         for (int sq = 0; sq < nsqp; ++sq)
-            admpc_seg_launch(N, s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (sq == 0 && !routed) ? 1 : 0, s->d_tick, s->cap_fused);
+            admpc_seg_launch(N, s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (sq == 0 && !routed) ? 1 : 0, s->d_tick, s->cap_fused, s->d_slot);
         HIPCHK(hipGetLastError());
         return ADMPC_OK;
     }

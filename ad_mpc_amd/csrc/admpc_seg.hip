@@ -61,6 +61,8 @@ __device__ __forceinline__ void seg_dbg_copy(double* dst, const double* src, int
 //      7 wait for / run the interface recursion, 8 back substitution, 9 expand / step, 10 cut states, 11 phase A again, 12 phase E,
 //      13 (S = 2) wait for the Schur blocks + the cut's solution operators (wave 0)
 #ifdef ADMPC_PHASE_TIMERS
+__device__ unsigned long long g_seg_trace[4 * 16384];     // per instance (first 16384): start, end (s_memrealtime, 100 MHz), workgroup, interior-point start
+__device__ __forceinline__ unsigned long long seg_real() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
 __device__ unsigned long long g_seg_ticks[16];
 __device__ __forceinline__ unsigned long long seg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
 #define SEG_DECL() unsigned long long ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last = seg_now()
@@ -92,8 +94,8 @@ __device__ __forceinline__ void stage_dq_seg(double* __restrict__ dq, const doub
     for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
 }
 
-// LDS map (doubles).  Per wave: what the interior point of its segment needs -- H (packed lower rows of Huu), Hb (the constant border
-// rows: Hzu, Bbar), L (unit factor), Lb (border rows of the factor), parked per-lane constants, exchange buffers (cb, invd, sb, sb2 in
+// LDS map (doubles).  Per wave: what the interior point of its segment needs -- H (packed lower rows of Huu) / L (unit factor) in one
+// buffer, Hb (the constant border rows: Hzu, Bbar), Lb (border rows of the factor), parked per-lane constants, exchange buffers (cb, invd, sb, sb2 in
 // the relative layout dense40.h's col_head assumes), wv (border unknowns of the back substitution).  Phases A, C, E alias it as in
 // admpc_fused20.hip.  Per segment an interface block (IF_*) that the other waves read; one word block per workgroup.
 template <int S>
@@ -101,12 +103,16 @@ struct SegLds {
     static constexpr int N = 20, NTRI = 820;
     static constexpr int NB = S == 2 ? 7 : 14;                         // border rows per segment
     static constexpr int NR = 40 + NB;                                 // lanes that carry rows of the bordered matrix
-    static constexpr int oH = 0, oHb = oH + NTRI, oL = oHb + NB * 40, oLb = oL + NTRI, oPark = oLb + NB * 40, oCb = oPark + 5 * 64;
+    // H (needed from the top of an iteration to the row build of its factorisation) and L (from the factorisation to the last back
+    // substitution) are never live together: ONE buffer; H waits in the workgroup's slot of global memory (L2) and is fetched at the top
+    // of every iteration -- 6.6 KB of LDS per wave, the difference between three and four workgroups per CU at S = 2
+    static constexpr int oH = 0, oL = oH, oHb = oH + NTRI, oLb = oHb + NB * 40, oPark = oLb + NB * 40, oCb = oPark + 5 * 64;
     static constexpr int oWv = oCb + 4 * 64;
-    static constexpr int seg = oWv + 16;
     static constexpr int JTS = 24, JTK = 4 * JTS + 2;
     static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
-    static_assert(oBlA + N * NX <= seg && oGTC + N * GTS <= oDqC && oGam + (NX + 1) * 64 <= oPark, "LDS aliases");
+    static constexpr int seg_ipm = oWv + 16, seg_lin = oBlA + N * NX;      // what the interior point needs / what phase A's tables need
+    static constexpr int seg = seg_ipm > seg_lin ? seg_ipm : seg_lin;
+    static_assert(seg % 2 == 0 && oGTC + N * GTS <= oDqC && oGam + (NX + 1) * 64 <= seg && oGam + (NX + 1) * 64 <= oCb, "LDS aliases");
     // interface block of a segment (the fields of the recursion over several cuts only exist for S > 2)
     static constexpr int SCS = NB;                                     // row stride of Sc
     static constexpr int IF_SC = 0;                                    // [NB][NB] C M^-1 C' of this iteration
@@ -346,7 +352,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                                                                 const double* __restrict__ yrefeg, const double* __restrict__ pg,
                                                                 double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                                 double* __restrict__ costg, int32_t* __restrict__ statusg,
-                                                                int32_t* __restrict__ itersg, int first_pass, int* __restrict__ sched, int cap)
+                                                                int32_t* __restrict__ itersg, int first_pass, int* __restrict__ sched, int cap,
+                                                                double* __restrict__ hslot)
 {
     using LD = SegLds<S>;
     constexpr int N = 20, n = 40, NT = N * S, NB = LD::NB, NR = LD::NR;
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     double* const ifb = lds_raw + LD::oIF;                       // interface blocks of all segments
     double* const IFm = ifb + wv_ * LD::IFS;                     // this segment's
     int* const wgw = reinterpret_cast<int*>(lds_raw + LD::oWG);  // workgroup words: [0] instance of this round
+    double* const hsl = hslot + ((size_t)blockIdx.x * S + wv_) * LD::NTRI;      // this wave's H in global memory (L2), rewritten per instance
     double* const YM = lds_raw + LD::oYM;                        // S = 2: the cut's solution operators (interface_factor2)
     double* const Hp = lds_seg + LD::oH;
     double* const Hb = lds_seg + LD::oHb;
@@ -399,6 +407,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     auto factorise = [&](const double dbar_, const double sodd_, const int lz_, const bool zbar, const double h_) __attribute__((always_inline)) {
         double a[n];
         newton_row_40_b<NR>(a, row_addr(Hp, Hb, lz_), dbar_, sodd_);
+        // H's rows are in registers: its buffer becomes the factor's.  Diagonal slots of the packed factor: 0.0 (the factorisation stores the
+        // strictly-lower part only; the substitution assembly lets the source lane of a step take part with this multiplier)
+        if (lz_ < n) Lp[lz_ * (lz_ + 1) / 2 + lz_] = 0.0;
         if (zbar) {
             // row z6 (lane 46) of Qzu: + h * (sum of the barrier ratios of the stages behind the column's stage), odd columns; sb2[k] holds that sum
             const double hz = lz_ == 46 ? h_ : 0.0;
@@ -539,6 +550,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         const double* yre = last ? yrefeg + (size_t)inst * NX : yrs + N * NY;      // row 20 of the segment's references (unused unless last)
 
         SEG_STAMP(0);
+#ifdef ADMPC_PHASE_TIMERS
+        const unsigned long long tr_t0 = seg_real(); unsigned long long tr_t1 = 0;
+#endif
         double du = 0.0;
         bool failed = false;
         int it = 0;
@@ -855,7 +869,11 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 }
             }
             WSYNC();
-            if (uact) Lp[(lane * (lane + 1)) / 2 + lane] = 0.0;         // diagonal slots of the packed factor (see admpc_fused20.hip)
+            // H to the wave's slot: the factor of the trial takes its buffer.  The vector L1 does not follow the wave's own stores and may
+            // still hold lines the PREVIOUS instance of this wave read here: drop them once the stores have retired.
+            stage_in<LD::NTRI>(hsl, Hp, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // invalidate only: a release would write the L2's dirty lines back to HBM
             WSYNC();
         }
 
@@ -974,6 +992,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 }
             }
             SEG_STAMP(3);
+#ifdef ADMPC_PHASE_TIMERS
+            tr_t1 = seg_real();
+#endif
             auto cold_start = [&]() __attribute__((always_inline)) {
                 const double dlc = PK_DL, duc2 = PK_DUU;
                 du = 0.0; sl = thr; su = thr;
@@ -1010,6 +1031,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     for (int i = 0; i < 2; ++i) { const double rci = Dt[i] * Dlam[i]; musum += dact ? rci : 0.0; cmax = fmax(cmax, dact ? rci : 0.0); }
                     const double G56 = Dlam[0] * rcp_nr(Dt[0]) + Dlam[1] * rcp_nr(Dt[1]);
                     Dbar = uact ? Rj + G0 * G2 * rcp_nr(G0 + G2) + G1 * G3 * rcp_nr(G1 + G3) : 1.0;
+                    stage_in<LD::NTRI>(Hp, hsl, lane);                      // H back from the slot (the last factor is dead)
                     cb[lane] = uact ? du : 0.0;
                     const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
                     dlam_tot = rdlane(dlam_pref, 63);
@@ -1326,6 +1348,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         }
         __builtin_amdgcn_s_setprio(0);
         SEG_STAMP(12);
+#ifdef ADMPC_PHASE_TIMERS
+        if (threadIdx.x == 0 && inst < 16384) { g_seg_trace[4 * inst] = tr_t0; g_seg_trace[4 * inst + 1] = seg_real(); g_seg_trace[4 * inst + 2] = blockIdx.x; g_seg_trace[4 * inst + 3] = tr_t1; }
+#endif
     }
     SEG_FLUSH();
     // ---- every workgroup has drawn exactly one ticket beyond the batch; the last one to leave clears tickets and bins for the next launch
@@ -1349,7 +1374,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 template <int S>
 static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap)
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot)
 {
     const int lds = SegLds<S>::total * (int)sizeof(double);
     // persistent grid: as many workgroups per CU as LDS (160 KB) and wave slots (two per SIMD) allow
@@ -1363,11 +1388,11 @@ static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int
         (void)hipFuncSetAttribute((const void*)admpc_seg_kernel<S, 127>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         prepared = true;
     }
-    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref_e, sched, cap);
+    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap);
     if (qmask == 7)
-        hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap);
+        hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot);
     else
-        hipLaunchKernelGGL((admpc_seg_kernel<S, 127>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap);
+        hipLaunchKernelGGL((admpc_seg_kernel<S, 127>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot);
 }
 
 // ---- host side (called by solve_impl in admpc_kernels.hip)
@@ -1388,6 +1413,19 @@ int admpc_debug_seg_ticks(unsigned long long* out16)
 #endif
 }
 
+int admpc_debug_seg_trace(unsigned long long* out, int n_inst)
+{
+#ifdef ADMPC_PHASE_TIMERS
+    if (n_inst > 16384) n_inst = 16384;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seg_trace), (size_t)n_inst * 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return 0;
+#else
+    (void)out; (void)n_inst;
+    return 1;
+#endif
+}
+
 // bring-up builds only: copy the dump buffer (4 waves x 2 points x 16384 doubles) to the host; 1 when the build carries none
 int admpc_debug_seg(double* out, int inst)
 {
@@ -1402,6 +1440,9 @@ int admpc_debug_seg(double* out, int inst)
     return 1;
 #endif
 }
+
+// doubles of the slot buffer: one packed H per resident wave (at most 8 waves per CU)
+__attribute__((visibility("hidden"))) size_t admpc_seg_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * 820; }
 
 // horizons this unit serves (fp64): N = 20 S, S = 2, 3, 4
 __attribute__((visibility("hidden"))) int admpc_seg_supports(int N) { return N == 40 || N == 60 || N == 80; }
@@ -1418,12 +1459,12 @@ __attribute__((visibility("hidden"))) int admpc_seg_lds_bytes(int N)
 // grid: persistent workgroups of S waves; sched: admpc_fused20_sched_ints(cap) ints, zeroed at allocation (the kernel re-arms them)
 __attribute__((visibility("hidden"))) void admpc_seg_launch(int N, int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap)
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot)
 {
     switch (N / 20) {
-        case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap); break;
-        case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap); break;
-        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap); break;
+        case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+        case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
     }
 }
 

@@ -464,6 +464,7 @@ def main():
             wl = "BASELINE configs[1]: batch %d random (x0, curved ref) scenarios, N=%d, %s" % (B, N, args.dtype)
         dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
         fused = dense and os.environ.get("ADMPC_N20") != "split"
+        seg = N in (40, 60, 80) and not f32 and os.environ.get("ADMPC_QP") != "riccati"      # admpc_seg.hip: N / 20 cooperating waves per instance
         out = {
             "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
@@ -477,7 +478,8 @@ def main():
                          "frac": ach_tf / peak_tf, "traffic": (traffic or {}).get("bytes"),
                          "traffic_source": (traffic or {}).get("source"),
                          "kernel": ("one step = admpc_f20_order_kernel (work-order pre-pass, ~5 us) + admpc_fused20_kernel (dominant, > 97 %: shooting, condensing, dense interior point and expansion of an instance in one persistent wave)"
-                                    if fused else "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
+                                    if fused else "one step = admpc_f20_order_kernel (work-order pre-pass, ~5 us) + admpc_seg_kernel<%d> (dominant, > 98 %%: %d cooperating waves per instance, each shooting, condensing, factorising and expanding 20 stages; the cuts coupled through 7 x 7 blocks)" % (N // 20, N // 20)
+                                    if seg else "one step = admpc_linearize_kernel + admpc_condense_kernel<20,7> + admpc_qp_dense_kernel<20> (dominant, ~58 %) + admpc_expand_kernel<20>"
                                     if dense else "one step = admpc_linearize_kernel + admpc_rowqp_kernel (dominant, > 95 %: row-mapped Riccati interior point; batches of more than one round of waves run it twice -- trial for all, interior point on the remainder sorted by violated bounds)"),
                          "kernel_ms": kern_ms,
                          "kernel_ms_is": "HIP-event time over the K timed steps on the launch stream / K: the kernels of a step and the gaps between them (the dominant kernel's own average duration: the rocprofv3 kernel trace under profiles/)",
@@ -485,7 +487,8 @@ def main():
                              "peak_note": "157.3 TFLOP/s is the packed (v_pk_fma_f32) vector rate; kernel R issues unpacked v_fmac_f32 (DPP operands), whose rate is 78.6"} if f32 else {}),
                          "note": ("%s; roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"
                                   % ("vector FMAs, the condensed Hessian alone on v_mfma_f64_16x16x4_f64 tiles (2 %% of the arithmetic; the fp64 matrix peak equals the vector peak: profiles/r3/mfma_condense_ab.txt)"
-                                     if fused else "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt)", "fp32" if f32 else "fp64", peak_tf))},
+                                     if fused else "vector FMAs; the condensed Hessians and the Schur blocks of the cuts on v_mfma_f64_16x16x4_f64 tiles (the fp64 matrix peak equals the vector peak)"
+                                     if seg else "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt)", "fp32" if f32 else "fp64", peak_tf))},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "bytes_per_solve": algorithmic_bytes_per_solve(N, elem)},
             "host_enqueue_ms_per_step": t_enq / K * 1e3, "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
