@@ -147,6 +147,10 @@ __device__ __forceinline__ unsigned long long phase_now() {
 #define PHASE_FLUSH() do { } while (0)
 #endif
 
+// ---- The four-kernel N = 20 pipeline of rounds 1-2 (kernels C, D, E behind kernel A): superseded by the fused persistent kernel
+// (admpc_fused20.hip, whose phase bodies are these texts) and kept OUT of the product library -- `make legacy` builds
+// ../libadmpc_legacy.so with -DADMPC_LEGACY_N20 for A/B runs (ADMPC_N20=split selects the pipeline there).
+#ifdef ADMPC_LEGACY_N20
 // kernel C (N = 20 path): condensing.  One instance per wavefront, lane i <-> input i.  Writes, per instance, the packed
 // lower-triangular Hessian rows H[NTRI] and aux[128] = { g0[64] (reduced gradient at du = 0, per input), xhat6[64] (free
 // response of delta per stage) } for the interior-point kernel.  A kernel of its own so that its 40-double Hessian row and
@@ -827,6 +831,7 @@ __global__ __launch_bounds__(WAVE) void admpc_expand_kernel(const AdmpcConfig* _
         WSYNC();
     }
 }
+#endif   // ADMPC_LEGACY_N20
 
 // ---------------------------------------------------------------------------------------------
 // local reference generator: batched RefTrajectory.get_waypoints (src/ad_mpc/ref_traj.py:89-171).
@@ -1281,7 +1286,7 @@ struct AdmpcSolver {
     int use_dense;           // condensed dense-Cholesky QP kernel available for this horizon (N == 20) and not disabled
     int dense_lds_bytes;
     int n20_fused;           // N = 20 fp64 steps run the fused persistent kernel (admpc_fused20.hip); 0: the four-kernel pipeline (ADMPC_N20=split)
-    int use_seg;             // N = 40 / 60 / 80 fp64 steps run the segmented condensed kernel (admpc_seg.hip); ADMPC_QP=riccati: kernel R
+    int use_seg;             // N = 40 fp64 steps (N = 60 / 80 with ADMPC_QP=seg) run the segmented condensed kernel (admpc_seg.hip); ADMPC_QP=riccati: kernel R
     int* d_tick;             // [128 + 64 cap_fused] tickets, exit counter and work-order bins of the fused kernel (zeroed at allocation; the kernel re-arms them)
     int cap_fused;
     double* d_slot;          // per-wave slot buffers of the fused kernel (the linearisation across the interior point), allocated at its first launch
@@ -1425,9 +1430,16 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         s->use_dense = (cfg->N == 20) && !(e && strcmp(e, "riccati") == 0);
         s->dense_lds_bytes = DenseLds<20>::total * (int)sizeof(double);
         // ADMPC_N20=split keeps the four-kernel pipeline (linearise, condense, interior point, expand) for A/B runs and tests
+#ifdef ADMPC_LEGACY_N20
         const char* m = getenv("ADMPC_N20");
         s->n20_fused = !(m && strcmp(m, "split") == 0);
-        s->use_seg = admpc_seg_supports(cfg->N) && !(e && strcmp(e, "riccati") == 0);
+#else
+        s->n20_fused = 1;                        // the product library carries the fused kernel only (`make legacy` for the older pipeline)
+#endif
+        // default at N = 40 (the reference's shipped horizon: 6.1 M solves/s against kernel R's 3.4 M at B = 4096); at N = 60 / 80 the
+        // segmented kernel is correct but LDS-bound (two / one workgroup per CU) and measured level with / behind kernel R
+        // (scripts/cmp_seg_rowqp.sh): there it runs on request only, ADMPC_QP=seg
+        s->use_seg = admpc_seg_supports(cfg->N) && (cfg->N == 40 ? !(e && strcmp(e, "riccati") == 0) : (e && strcmp(e, "seg") == 0));
     }
     hipError_t e = hipMalloc((void**)&s->d_cfg, sizeof(AdmpcConfig));
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -1438,7 +1450,9 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
     for (int c = 3; c < NX; ++c) if (cfg->W[c] != 0.0 || cfg->We[c] != 0.0) s->qmask = 127;
     // opt in to > 64 KB of dynamic LDS
     admpc_rowqp_prepare();
+#ifdef ADMPC_LEGACY_N20
     (void)hipFuncSetAttribute((const void*)admpc_qp_dense_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     *out = s;
     return ADMPC_OK;
 }
@@ -1712,6 +1726,7 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
             admpc_fused20_launch(s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, s->d_tick, s->cap_fused, s->d_slot);
             continue;
         }
+#ifdef ADMPC_LEGACY_N20      // the four-kernel pipeline of rounds 1-2 (`make legacy`, ADMPC_N20=split)
         hipLaunchKernelGGL(admpc_linearize_kernel<double>, dim3(gridA), dim3(LIN_BLOCK), 0, st, s->d_cfg, B, xbar, ubar, p,
                            first ? (const int32_t*)nullptr : (const int32_t*)stat, s->d_GT, s->d_bl, s->d_sched);
         {
@@ -1735,6 +1750,9 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
             hipLaunchKernelGGL((admpc_expand_kernel<20>), dim3(gridE), dim3(WAVE), exp_lds, st, s->d_cfg, B, x0, yref, yref_e,
                                (const double*)s->d_GT, (const double*)s->d_bl, xbar, ubar, cost, stat, (const double*)s->d_aux);
         }
+#else
+        (void)gridA;
+#endif
     }
     HIPCHK(hipGetLastError());
     return ADMPC_OK;

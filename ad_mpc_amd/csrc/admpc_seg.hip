@@ -43,6 +43,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define LDG(p) (*(p))
 #define STG(p, v) (*(p) = (v))
 
+// a wave-uniform double that the compiler cannot see to be uniform (an LDS read every lane does alike): into scalar registers -- the
+// kernel lives at the 256-VGPR boundary of two waves per SIMD, and a scalar costs a vector register pair otherwise
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // Cross-WAVE exchange through LDS: inline-assembly LDS stores are invisible to the compiler's wait-count tracking, so the barrier
 // waits for everything this wave has in flight first.
 #define XSYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
@@ -166,9 +172,13 @@ __device__ __forceinline__ void ge7_solve(Col7& c) {
             const double v = fabs(rdlane(c.v[r], p));
             if (v > best) { best = v; bi = r; }
         });
+        // the row exchange as selects (a uniform condition each): written as conditional swaps hipcc turns the seven registers into a
+        // dynamically indexed array in scratch
         static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            if (bi == r) { const double t = c.v[p]; c.v[p] = c.v[r]; c.v[r] = t; }
+            const bool sw = bi == r;
+            const double vp = c.v[p], vr = c.v[r];
+            c.v[p] = sw ? vr : vp; c.v[r] = sw ? vp : vr;
         });
         const double pinv = rcp_nr(rdlane(c.v[p], p));
         static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             const double inv_nineq = 1.0 / (double)(8 * NT + 2 * (NT - 1));
             const double ubar_i = ubs[sc];
             const double dl_i = cf->lbu[ji] - ubar_i, duu_i = cf->ubu[ji] - ubar_i;
-            const double z6c = first ? 0.0 : IFm[LD::IF_ZC + 6];
+            const double z6c = first ? 0.0 : uni(IFm[LD::IF_ZC + 6]);
             double t[4], lam[4], sl = thr, su = thr;
             {
                 const double r0[4] = { thr - dl_i, thr + duu_i, thr, thr };
@@ -1058,8 +1068,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     ru = uact ? hdu + Rj * du + PK_G0 - lam[0] + lam[1] + (ji ? h * sb[ki] : 0.0)
                               : (zact ? hdu + PK_G0 + (lane == n + 6 ? dlam_tot : 0.0) : 0.0);
                     S_i = h * h * sb2[uact ? ki : 0];
-                    double rnan;
                     {
+                        double rnan;
                         const double rd0 = du + sl - PK_DL - t[0], rd1 = -du + su + PK_DUU - t[1], rd2 = sl - t[2], rd3 = su - t[3];
                         const double rsl = rho_l - lam[0] - lam[2], rsu = rho_u - lam[1] - lam[3];
                         const double Drd0 = dx6 - PK_DDL - Dt[0], Drd1 = PK_DDU - dx6 - Dt[1];
@@ -1067,7 +1077,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         ra = OpMaxNan::f(ra, fabs(rd0)); ra = OpMaxNan::f(ra, fabs(rd1));
                         const double rb = OpMaxNan::f(fabs(Drd0), fabs(Drd1));
                         rineq = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
-                        rnan = OpMaxNan::f(fabs(ru), uact ? OpMaxNan::f(fabs(rd2), fabs(rd3)) : 0.0);      // anything non-finite anywhere is a failure
+                        rnan = OpMaxNan::f(fabs(ru), uact ? OpMaxNan::f(fabs(rd2), fabs(rd3)) : 0.0);      // anything non-finite anywhere is a failure:
+                        rineq = OpMaxNan::f(rineq, rnan * 0.0);                                             // 0 if finite, NaN otherwise -- rides in the same reduction
                     }
                     // start value of the tracked stationarity residual (only at a start point: rstat < 0)
                     double rs0 = 0.0;
@@ -1086,22 +1097,22 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     const double cmx_w = wave_reduce<OpMax>(cmax);
                     const double rin_w = wave_reduce<OpMaxNan>(rineq);
                     const double stp_w = wave_reduce<OpMax>(stp_local);
-                    const double rs0_w = wave_reduce<OpMaxNan>(rs0);
-                    const double nan_w = wave_reduce<OpMaxNan>(rnan);
+                    double rs0_w = 0.0;
+                    if (rstat < 0.0) rs0_w = wave_reduce<OpMaxNan>(rs0);
                     if (lane == 0) {
-                        RED(wv_, 0, 0) = mus_w; RED(wv_, 0, 1) = cmx_w; RED(wv_, 0, 2) = rin_w; RED(wv_, 0, 3) = stp_w; RED(wv_, 0, 4) = rs0_w; RED(wv_, 0, 5) = nan_w;
+                        RED(wv_, 0, 0) = mus_w; RED(wv_, 0, 1) = cmx_w; RED(wv_, 0, 2) = rin_w; RED(wv_, 0, 3) = stp_w; RED(wv_, 0, 4) = rs0_w;
                     }
                     XSYNC();
-                    double msum = 0.0, cmx = 0.0, rin = 0.0, stp = -INFINITY, rs0a = 0.0, rna = 0.0;
+                    double msum = 0.0, cmx = 0.0, rin = 0.0, stp = -INFINITY, rs0a = 0.0;
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         msum += RED(s, 0, 0); cmx = fmax(cmx, RED(s, 0, 1)); rin = OpMaxNan::f(rin, RED(s, 0, 2));
-                        stp = fmax(stp, RED(s, 0, 3)); rs0a = OpMaxNan::f(rs0a, RED(s, 0, 4)); rna = OpMaxNan::f(rna, RED(s, 0, 5));
+                        stp = fmax(stp, RED(s, 0, 3)); rs0a = OpMaxNan::f(rs0a, RED(s, 0, 4));
                     }
-                    mu = msum * inv_nineq; step = stp;
-                    if (rstat < 0.0) rstat = rs0a;
+                    mu = uni(msum * inv_nineq); step = uni(stp); cmx = uni(cmx); rin = uni(rin);
+                    if (rstat < 0.0) rstat = uni(rs0a);
                     const double rmax = OpMaxNan::f(rin, rstat);
-                    if (!(mu == mu) || !(rmax == rmax) || !(rna == rna)) { failed = true; break; }
+                    if (!(mu == mu) || !(rmax == rmax)) { failed = true; break; }
                     if (cmx <= tol_comp && step <= tol_step &&
                         (rmax <= tol_res || (it > 0 && rmax > 0.1 * rmax_prev && rmax <= ADMPC_IPM_FLOOR_CAP * tol_res))) break;      // admpc.h: stopping test
                     rmax_prev = rmax;
@@ -1154,7 +1165,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     ddu = uact ? x : 0.0;
                     cb[lane] = ddu;
                     WSYNC();
-                    const double dz6 = first ? 0.0 : IFm[LD::IF_DZ + 6];
+                    const double dz6 = first ? 0.0 : uni(IFm[LD::IF_DZ + 6]);
                     const double du1_stage = lane < N ? cb[2 * lane + 1] : 0.0;
                     const double pre = wave_scan_incl<OpSum>(du1_stage);
                     const double ddx6 = dz6 + h * (pre - du1_stage);
@@ -1183,6 +1194,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     double rra = 0.0, sdda = 0.0;
 #pragma unroll
                     for (int s = 0; s < S; ++s) { rra = fmax(rra, RED(s, 2 + ps, 0)); sdda += RED(s, 2 + ps, 1); }
+                    rra = uni(rra); sdda = uni(sdda);
                     const double amax = rra > 1.0 ? rcp_nr(rra) : 1.0;
                     if (ps == 0) {
                         // complementarity after the affine step: sum (t + a dt)(lam + a dlam) = (1 - a) sum t lam + a^2 sum dt dlam (the
@@ -1463,8 +1475,12 @@ __attribute__((visibility("hidden"))) void admpc_seg_launch(int N, int num_cu, h
 {
     switch (N / 20) {
         case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+#ifndef SEG_DEV_ONLY_S2      // development builds: one instantiation compiles in a third of the time
         case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
         default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+#else
+        default: break;
+#endif
     }
 }
 

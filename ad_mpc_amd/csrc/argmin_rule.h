@@ -10,7 +10,7 @@
 #include <stdint.h>
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ADMPC_HD __host__ __device__ __forceinline__
 #else
 #define ADMPC_HD static inline

@@ -218,16 +218,35 @@ def dry_collective(args, world, rank, launched):
             best = adist.global_argmin_records(adist.pack_pair(v, i), adist.pairs_min_host) if launched else adist.pack_pair(v, i)
     if launched: dist.barrier()
     elapsed = time.perf_counter() - t0
+    # the collective-free segment of the real run (per-rank rate by the rank's own clock, gathered): here the local arg-min loop stands in
+    tl = time.perf_counter()
+    for _ in range(max(K, 1)):
+        adist.local_argmin_torch(cost, index_offset=lo)
+    rl = torch.tensor([B * max(K, 1) / max(time.perf_counter() - tl, 1e-9)], dtype=torch.float64)
+    rates = [float(rl.item())]
     if launched:
         tt = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+        allr = [torch.empty_like(rl) for _ in range(world)]; dist.all_gather(allr, rl); rates = [float(t.item()) for t in allr]
     if rank == 0:
+        traffic = measured_traffic(args.horizon, B, args.dtype, "")
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cfg = default_config(N=args.horizon, Ts=0.05)
+                cpu = cpu_baseline(cfg, random_scenarios(64, N=args.horizon, Ts=0.05, seed=1234), target_seconds=0.5)
+            except Exception as e:
+                cpu = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         allc = torch.remainder((torch.arange(world * B, dtype=torch.float64) + 1.0) * 0.6180339887498949, 1.0) + 1.0
         bc, bidx = adist.unpack_pair(best)
         print(json.dumps({"metric": "MPC solves/sec (N=%d, nx=7, nu=2, fp64)" % args.horizon, "value": None, "unit": "solves/s", "dry": True,
                           "n_gpus": world, "ranks_seen": int(ones.item()), "steps": K, "warmup": Wm, "ms_per_step": elapsed / max(K, 1) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": "DRY RUN of the N > 1 plumbing on CPU ranks (gloo): no solve", "batch_per_gpu": B,
-                                     "collective": "gloo all-gather arg-min (16 B/rank), reducer admpc_argmin_pairs_host"},
+                                     "collective": "gloo all-gather arg-min (16 B/rank), reducer admpc_argmin_pairs_host",
+                                     "one_gpu_solves_per_s_at_this_batch": rates[0]},
+                          "per_rank_solves_per_s_no_collective": {"min": min(rates), "max": max(rates), "rank0": rates[0], "batch_per_gpu": B, "dry": True},
+                          "roofline": {"traffic": (traffic or {}).get("bytes"), "traffic_source": (traffic or {}).get("source")},
+                          "cpu_baseline": cpu,
                           "argmin": {"cost": bc, "index": bidx},
                           "argmin_single_process": {"cost": float(allc.min()), "index": int(torch.argmin(allc))}}), flush=True)
     if launched:
@@ -360,6 +379,20 @@ def main():
             ev = torch.cuda.Event(); ev.record(red); reduced[q] = ev
         return best
 
+    # ---- launched runs: the same K steps WITHOUT any collective first (no arg-min, no side stream), every rank by its own clock: the
+    # denominator of a scaling efficiency that is measured in the same run, on the same per-GPU batch (the default batches of `--gpus 1`
+    # and `--gpus N` differ: 4096 / 8192 per GPU, and the per-GPU rate depends on the batch -- VERDICT round 3, weak 6)
+    local_rate = None
+    if launched:
+        for i in range(Wm):
+            eng.solve(x0, yref, yref_e, p, xb[i].clone(), ub[i].clone(), cost, status, iters)
+        xs = [xinit.clone() for _ in range(K)]; us = [uinit.clone() for _ in range(K)]
+        torch.cuda.synchronize(); tl = time.perf_counter()
+        for i in range(K):
+            eng.solve(x0, yref, yref_e, p, xs[i], us[i], cost, status, iters)
+        torch.cuda.synchronize()
+        local_rate = B * K / (time.perf_counter() - tl)
+        del xs, us
     ranks_seen = 1
     if launched:                                  # what the collective itself counts: every rank adds one
         ones = torch.ones(1, dtype=torch.int64, device=eng.device)
@@ -391,6 +424,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    rates = None
+    if launched:
+        rl = torch.tensor([local_rate], dtype=torch.float64, device=eng.device)
+        allr = [torch.empty_like(rl) for _ in range(world)]
+        dist.all_gather(allr, rl)
+        rates = [float(t.item()) for t in allr]
     kern_ms = float(ev_begin.elapsed_time(ev_end)) / K      # the step's kernels and the gaps between them, by the device's clock
     it_host = iters.cpu().numpy(); st_host = status.cpu().numpy()
     two = None
@@ -464,7 +503,7 @@ def main():
             wl = "BASELINE configs[1]: batch %d random (x0, curved ref) scenarios, N=%d, %s" % (B, N, args.dtype)
         dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
         fused = dense and os.environ.get("ADMPC_N20") != "split"
-        seg = N in (40, 60, 80) and not f32 and os.environ.get("ADMPC_QP") != "riccati"      # admpc_seg.hip: N / 20 cooperating waves per instance
+        seg = not f32 and ((N == 40 and os.environ.get("ADMPC_QP") != "riccati") or (N in (60, 80) and os.environ.get("ADMPC_QP") == "seg"))      # admpc_seg.hip: N / 20 cooperating waves per instance
         out = {
             "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
@@ -494,6 +533,11 @@ def main():
             "host_enqueue_ms_per_step": t_enq / K * 1e3, "mean_ipm_iters": mean_iters, "max_ipm_iters": int(it_host.max()), "status_nonzero": int((st_host != 0).sum()),
             "unconstrained_trial": {"enabled": bool(trial), "fraction_solved_without_interior_point": float((it_host == 0).mean())},
         }
+        if rates is not None:
+            out["per_rank_solves_per_s_no_collective"] = {"min": min(rates), "max": max(rates), "rank0": rates[0], "batch_per_gpu": B,
+                "note": "the same K steps on every rank before the timed region, no arg-min, no barrier inside, each rank by its own clock: "
+                        "N x min is what the job would do if the collective and the closing barrier were free"}
+            out["config"]["one_gpu_solves_per_s_at_this_batch"] = rates[0]
         if two is not None:
             out["two_in_flight"] = two
         if tight is not None:
@@ -501,7 +545,7 @@ def main():
         if best is not None:
             bc, bidx = adist.unpack_pair(best)
             out["argmin"] = {"cost": bc, "index": bidx}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, scen)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line

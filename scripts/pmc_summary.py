@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("f20_order", "fused20", "linearize", "condense", "qp_dense", "expand", "rowqp_sort", "rowqp", "argmin", "epilogue", "waypoints", "shoot"):
+    for key in ("f20_order", "fused20", "seg_kernel", "linearize", "condense", "qp_dense", "expand", "rowqp_sort", "rowqp", "argmin", "epilogue", "waypoints", "shoot"):
         if key in name:
             return key
     return None
@@ -41,11 +41,11 @@ def main(dirs):
         out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v)} for c, v in sorted(counters.items())}
     # HBM traffic of one step = sum over the step's kernels, per launch: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
     # counts 32-byte requests as 16 for wide coalesced reads and is doubled (MI355X_MICROARCH.md, HBM section)
-    step = [k for k in ("f20_order", "fused20", "linearize", "condense", "qp_dense", "expand", "rowqp") if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
+    step = [k for k in ("f20_order", "fused20", "seg_kernel", "linearize", "condense", "qp_dense", "expand", "rowqp") if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
     if step:
         # launches per step, relative to the kernel that runs exactly once per step: the fused N = 20 kernel, else the linearisation kernel
         # (a split batch launches the row kernel twice + its sort kernel, whose traffic -- two passes over B keys -- is not counted)
-        once = "fused20" if "fused20" in step else ("linearize" if "linearize" in step else None)
+        once = "fused20" if "fused20" in step else ("seg_kernel" if "seg_kernel" in step else ("linearize" if "linearize" in step else None))
         per = {k: (out[k]["FETCH_SIZE"]["launches"] / out[once]["FETCH_SIZE"]["launches"] if once else 1.0) for k in step}
         fetch = sum(out[k]["FETCH_SIZE"]["mean_per_launch"] * per[k] for k in step) * 1024.0 * 2.0
         write = sum(out[k]["WRITE_SIZE"]["mean_per_launch"] * per[k] for k in step) * 1024.0

@@ -122,6 +122,15 @@ def test_bench_starts_its_own_ranks_and_never_reports_fewer():
     js = json.loads(lines[0])
     assert js["n_gpus"] == 2 and js["ranks_seen"] == 2 and js["dry"] is True and js["value"] is None and js["steps"] == 3
     assert js["argmin"] == js["argmin_single_process"] and js["argmin"]["index"] == 10945 >= 8192
+    # the inputs of a scaling curve: every N > 1 line carries a per-rank rate measured WITHOUT the collective in the
+    # same run at the same per-GPU batch (min / max over ranks, rank 0's as the one-GPU value at this batch), the committed PMC traffic of
+    # the 8192-instance shard (no live passes in a multi-rank run), and the CPU baseline of rank 0
+    pr = js["per_rank_solves_per_s_no_collective"]
+    assert pr["batch_per_gpu"] == 8192 and 0 < pr["min"] <= pr["rank0"] <= pr["max"] or pr["min"] <= pr["max"]
+    assert js["config"]["one_gpu_solves_per_s_at_this_batch"] == pr["rank0"] and js["config"]["batch_per_gpu"] == 8192
+    assert "traffic" in js["roofline"] and "traffic_source" in js["roofline"]
+    cb = js["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     # a world size that contradicts --gpus is refused by every rank
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), bench, "--gpus", "4", "--dry-collective", "gloo"],

@@ -529,6 +529,30 @@ def test_gp_residual_config3_full_size(gpu_engine_factory, oracle_omp):
         _assert_parity(g, o)
 
 
+def test_gp_residual_at_the_shipped_horizon(gpu_engine_factory, oracle_omp):
+    """N = 40 (the reference's shipped horizon) WITH the GP residual: the one family whose states sit above the 1e-7 of the other
+    long-horizon tests, with its own stated tolerance: inputs <= 1e-7, states <= 1e-5, identical statuses and
+    iteration counts.  The GP-augmented linearised dynamics has an unstable lateral mode: the expansion x_{k+1} = A_k dx_k + B_k du_k + b_k
+    amplifies the rounding-level disagreement of the inputs (1e-10 .. 1e-11) by ~1e5 over 40 stages; the worst entry is always v_y at the
+    last stage (profiles/r3/gp_n40_state_amplification.txt: 2.4e-6 over five seeds).  A condition number of the expansion, in the
+    reference's own formulation as much as here -- stated, not hidden.  Both device paths: the segmented kernel (default) and kernel R."""
+    cfg = default_config(N=40); set_gp(cfg, grid_gp())
+    s = random_scenarios(4096, N=40, seed=100)
+    o = oracle_omp.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"], nthreads=16)
+    assert (o[3] == 0).all()
+    for qp in (None, "riccati"):
+        if qp: os.environ["ADMPC_QP"] = qp
+        try:
+            g = gpu_engine_factory(cfg).solve_numpy(s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        finally:
+            os.environ.pop("ADMPC_QP", None)
+        np.testing.assert_array_equal(g[3], o[3]); np.testing.assert_array_equal(g[4], o[4])
+        du = np.abs(g[1] - o[1]).max(); dx = np.abs(g[0] - o[0]).max()
+        assert du <= 1e-7 and dx <= 1e-5, (qp, du, dx)
+        worst = np.unravel_index(np.argmax(np.abs(g[0] - o[0])), g[0].shape)
+        assert dx <= 1e-7 or worst[1] >= 30, worst             # what exceeds the plain tolerance sits at the end of the horizon
+
+
 def _multi_feature_gps(seed=8):
     """Three regressors with 3, 2 and 1 features (states and inputs mixed, one length scale per feature)."""
     rng = np.random.default_rng(seed)

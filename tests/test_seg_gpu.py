@@ -19,7 +19,8 @@ def _run(eng, s):
     (40, 700, (100.0, 110.0), "x0"), (40, 700, (3.0, 5.0), "x0"), (40, 64, (100.0, 110.0), "zeros"), (40, 1, (3.0, 5.0), "x0"), (40, 3, (100.0, 110.0), "x0"),
     (60, 300, (3.0, 5.0), "x0"), (60, 300, (100.0, 110.0), "zeros"), (80, 400, (100.0, 110.0), "x0"), (80, 300, (3.0, 5.0), "x0"),
 ])
-def test_segmented_kernel_against_the_oracle(gpu_engine_factory, oracle_omp, N, B, blend, init):
+def test_segmented_kernel_against_the_oracle(gpu_engine_factory, oracle_omp, monkeypatch, N, B, blend, init):
+    monkeypatch.setenv("ADMPC_QP", "seg")               # the default at N = 40; on request at N = 60 / 80 (kernel R is the default there)
     cfg = default_config(N=N)
     s = random_scenarios(B, N=N, seed=4000 + N + B, blend=blend, init=init)
     eng = gpu_engine_factory(cfg)
@@ -42,6 +43,7 @@ def test_segmented_and_row_kernel_agree(gpu_engine_factory, oracle_omp, monkeypa
     levels at most one instance per batch may differ by one iteration; the solutions agree to the tolerance either way."""
     s = random_scenarios(512, N=N, seed=77, blend=(3.0, 5.0))
     for cfg, strict in ((default_config(N=N), True), (tight_config(N=N), False)):
+        monkeypatch.setenv("ADMPC_QP", "seg")
         g_seg = _run(gpu_engine_factory(cfg), s)
         monkeypatch.setenv("ADMPC_QP", "riccati")
         g_ric = _run(gpu_engine_factory(cfg), s)
@@ -59,9 +61,10 @@ def test_segmented_and_row_kernel_agree(gpu_engine_factory, oracle_omp, monkeypa
         assert np.abs(g_seg[1] - g_ric[1]).max() <= TOL_LONG
 
 
-def test_segmented_kernel_start_rules(gpu_engine_factory, oracle_omp):
+def test_segmented_kernel_start_rules(gpu_engine_factory, oracle_omp, monkeypatch):
     """The paths that take the cold-start residual (rolled out at the end of the condensing): trial off, warm start off, forced restart,
     forced fallback -- N = 40 and N = 80."""
+    monkeypatch.setenv("ADMPC_QP", "seg")
     for N in (40, 80):
         s = random_scenarios(256, N=N, seed=21, blend=(3.0, 5.0))
         for name, val in (("ipm_try_unconstrained", 0.0), ("ipm_warm_thr", 0.0), ("ipm_warm_restart", 0.99), ("ipm_fallback_iter", 3.0)):
@@ -93,3 +96,21 @@ def test_segmented_kernel_failure_and_sqp_passes(gpu_engine_factory, oracle_omp)
     ok = o[3] == 0
     assert ok.sum() == 128 and o[4][ok].max() < cfg.ipm_iter_max          # every other instance is a well-posed problem in all three passes
     assert np.abs(g[1][ok] - o[1][ok]).max() <= TOL_LONG and np.abs(g[0][ok] - o[0][ok]).max() <= TOL_LONG
+
+
+def test_default_kernel_by_horizon(gpu_engine_factory, monkeypatch):
+    """N = 40 runs the segmented kernel by default (its work-order pre-pass shows in the launch: the iterations of a solve are the same
+    either way, the bits are not); N = 80 runs kernel R by default -- the segmented kernel there is bit-different and on request."""
+    for N, seg_default in ((40, True), (80, False)):
+        s = random_scenarios(64, N=N, seed=3, blend=(3.0, 5.0))
+        cfg = default_config(N=N)
+        monkeypatch.delenv("ADMPC_QP", raising=False)
+        g_def = _run(gpu_engine_factory(cfg), s)
+        monkeypatch.setenv("ADMPC_QP", "seg")
+        g_seg = _run(gpu_engine_factory(cfg), s)
+        monkeypatch.setenv("ADMPC_QP", "riccati")
+        g_ric = _run(gpu_engine_factory(cfg), s)
+        monkeypatch.delenv("ADMPC_QP")
+        same = g_seg if seg_default else g_ric
+        np.testing.assert_array_equal(g_def[1], same[1]); np.testing.assert_array_equal(g_def[0], same[0])
+        assert np.abs(g_seg[1] - g_ric[1]).max() <= TOL_LONG and (g_seg[1] != g_ric[1]).any()
