@@ -141,6 +141,7 @@ struct FusedLds {
 #endif
 #include "work_order.h"
 
+static_assert(WAVE == 64, "one wavefront per workgroup: WSYNC is a wave-level fence in this build");
 template <int QMASK>
 __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfig* __restrict__ cfg, int B,
                                                                 const double* __restrict__ x0g, const double* __restrict__ yrefg,
@@ -364,7 +365,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 // packed stage record: stored columns c = 0..6 <-> (A[:,2..6], B[:,0..1]), rows 0..5 of each
                 const int c0 = g == 0 ? 0 : (g == 1 ? 3 : 5);
                 const int nc = g == 0 ? 3 : 2;
-                WSYNC();                                   // every lane has read its tables: GT does not alias them, but keep the phases apart
+                WSYNC();                                   // REQUIRED: GT overlays the Jacobian tables (FusedLds: oGTC = oJT = 0) -- every lane has read its
+                                                           // tables before the first store.  With ADMPC_WSYNC_FENCE_ONLY this is a wave-level fence: the
+                                                           // kernel must stay ONE wave per workgroup (launch bounds below)
                 double* Gk = GT + k * GTS;
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
@@ -1108,6 +1111,9 @@ __attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipS
 {
     const int lds = FusedLds::total * (int)sizeof(double);
     int grid = num_cu * 8; if (grid > B) grid = B;
+    // every launch pair is self-contained: ticket counter, exit counter and bin counts start from zero on the caller's stream (the last
+    // workgroup to leave re-arms them as well; a launch that failed half-way, or a handle misused from two streams, cannot poison the next)
+    (void)hipMemsetAsync(sched, 0, F20_HDR * sizeof(int), st);
     hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap);
     if (qmask == 7)
         hipLaunchKernelGGL((admpc_fused20_kernel<7>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);

@@ -874,12 +874,80 @@ __global__ void admpc_quad_route_invalid_kernel(int B, const int32_t* __restrict
 
 }  // namespace
 
+// ---- solver_type "SQP" (create_ros_gp_mpc.py:63-68, quad_3d_optimizer.py:203): cfg.sqp_iters QPs per call with acados' stopping test in front of
+// every QP but the first.  The test (one thread per instance: the mode serves point references, a handful of instances) follows
+// oracle/quad_oracle.c:quad_nlp_residuals -- the multipliers of the last QP by the adjoint recursion of its stationarity (full condensing returns
+// none for the dynamics), on the linearisation (Ap, Bp) that QP was built on; the residuals on the linearisation (phi, An, Bn) of the iterate.
+//   act [B]: 0 = still iterating, 1 = finished (fst [B] holds its final status)
+__global__ void admpc_quad_sqp_test_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                           const double* __restrict__ yrefeg, const double* __restrict__ xbarg, const double* __restrict__ ubarg,
+                                           const double* __restrict__ Apg, const double* __restrict__ Bpg, const double* __restrict__ phig,
+                                           const double* __restrict__ Ang, const double* __restrict__ Bng, int32_t* __restrict__ act, int32_t* __restrict__ fst)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || act[b] != 0) return;
+    const int N = c->N;
+    const double Ts = c->Ts, tol = c->sqp_tol;
+    const double* xb = xbarg + (size_t)b * (N + 1) * QX; const double* ub = ubarg + (size_t)b * N * QU;
+    const double* yr = yrefg + (size_t)b * N * QY; const double* ye = yrefeg + (size_t)b * QX;
+    double rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
+    auto upn = [](double& acc, double v) { const double a = fabs(v); if (a > acc || !(a == a)) acc = a; };
+    for (int i = 0; i < QX; ++i) upn(re, xb[i] - x0g[(size_t)b * QX + i]);
+    double pk[QX];
+    for (int i = 0; i < QX; ++i) pk[i] = c->We[i] * (xb[N * QX + i] - ye[i]);      // pi_{N-1}; the terminal stationarity row is zero by this definition
+    for (int k = N - 1; k >= 0; --k) {
+        const double* Ap = Apg + ((size_t)b * N + k) * QX * QX; const double* An = Ang + ((size_t)b * N + k) * QX * QX;
+        const double* Bp = Bpg + ((size_t)b * N + k) * QX * QU; const double* Bn = Bng + ((size_t)b * N + k) * QX * QU;
+        const double* ph = phig + ((size_t)b * N + k) * QX;
+        for (int i = 0; i < QX; ++i) upn(re, ph[i] - xb[(k + 1) * QX + i]);
+        for (int m = 0; m < QU; ++m) {
+            const double u = ub[k * QU + m];
+            const double gr = Ts * c->W[QX + m] * (u - yr[k * QY + QX + m]);
+            double mk = gr, a = gr;
+            for (int i = 0; i < QX; ++i) { mk += Bp[i * QU + m] * pk[i]; a += Bn[i * QU + m] * pk[i]; }
+            upn(rs, a - mk);
+            const double vl = c->lbu[m] - u, vu = u - c->ubu[m];
+            upn(ri, vl > 0.0 ? vl : 0.0); upn(ri, vu > 0.0 ? vu : 0.0);
+            const double ml = mk > 0.0 ? mk : 0.0, mu_ = mk < 0.0 ? -mk : 0.0;
+            upn(rc, ml * (u - c->lbu[m])); upn(rc, mu_ * (c->ubu[m] - u));
+        }
+        if (k >= 1) {
+            double pn[QX];
+            for (int j = 0; j < QX; ++j) {
+                const double gr = Ts * c->W[j] * (xb[k * QX + j] - yr[k * QY + j]);
+                double pm = gr, a = gr;
+                for (int i = 0; i < QX; ++i) { pm += Ap[i * QX + j] * pk[i]; a += An[i * QX + j] * pk[i]; }
+                upn(rs, a - pm);
+                pn[j] = pm;
+            }
+            for (int j = 0; j < QX; ++j) pk[j] = pn[j];
+        }
+    }
+    if (rs <= tol && re <= tol && ri <= tol && rc <= tol) { act[b] = 1; fst[b] = 0; }
+}
+// behind a QP of an SQP solve: an instance whose QP failed is finished with that status
+__global__ void admpc_quad_sqp_merge_kernel(int B, const int32_t* __restrict__ status, int32_t* __restrict__ act, int32_t* __restrict__ fst)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && act[b] == 0 && status[b] != 0) { act[b] = 1; fst[b] = status[b]; }
+}
+// final statuses: finished instances carry theirs; an instance still iterating at the limit is ACADOS_MAXITER (2) when a tolerance was asked for
+__global__ void admpc_quad_sqp_final_kernel(int B, int tol_on, const int32_t* __restrict__ act, const int32_t* __restrict__ fst, int32_t* __restrict__ status)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) status[b] = act[b] ? fst[b] : (tol_on ? 2 : status[b]);
+}
+
 struct AdmpcQuadSolver {
     AdmpcQuadConfig cfg;
     AdmpcQuadConfig* d_cfg;
     int* d_ticket;           // work counter of the solve kernel
     int device, num_cu, lds_bytes;
     int generic;             // ADMPC_QUAD_GENERIC=1: the LDS-resident Cholesky path also at N nu = 40 (A/B tests)
+    // SQP mode (cfg.sqp_iters > 1), allocated at its first solve: two linearisations (the last QP's and the iterate's), activity flags
+    int cap_sqp;
+    double *d_A[2], *d_B[2], *d_phi;
+    int32_t *d_act, *d_fst, *d_st;
 };
 
 namespace {
@@ -908,6 +976,7 @@ void admpc_quad_default_config(AdmpcQuadConfig* c)
     const double xf[4] = { h, -h, -h, h }, yf[4] = { -h, -h, h, h }, zt[4] = { -0.013, 0.013, -0.013, 0.013 };
     for (int i = 0; i < 4; ++i) { c->x_f[i] = xf[i]; c->y_f[i] = yf[i]; c->z_l_tau[i] = zt[i]; }
     c->ipm_mu0 = 1.0; c->ipm_thr0 = 0.1; c->ipm_tol_comp = 1e-8; c->ipm_tol_res = 1e-8;      // HPIPM mode BALANCE, the reference's setting
+    c->sqp_iters = 1; c->sqp_tol = 0.0;                                                       // SQP_RTI, the shipped solver_type
 }
 
 int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** out)
@@ -920,6 +989,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
         if (!(cfg->lbu[m] < cfg->ubu[m])) return admpc_set_error(ADMPC_EINVAL, "quad: lbu < ubu required");
     }
     if (cfg->ipm_iter_max < 1 || !(cfg->ipm_mu0 > 0) || !(cfg->ipm_thr0 > 0)) return admpc_set_error(ADMPC_EINVAL, "quad: bad interior-point parameters");
+    if (cfg->sqp_iters < 0 || cfg->sqp_iters > 10000 || !(cfg->sqp_tol >= 0)) return admpc_set_error(ADMPC_EINVAL, "quad: sqp_iters must be in [0, 10000], sqp_tol >= 0");
     if (cfg->n_gp < 0 || cfg->n_gp > ADMPC_QUAD_GP_MAX) return admpc_set_error(ADMPC_EINVAL, "quad: n_gp out of range");
     for (int g = 0; g < cfg->n_gp; ++g) {
         const AdmpcGp& gp = cfg->gp[g];
@@ -936,6 +1006,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     AdmpcQuadSolver* s = new (std::nothrow) AdmpcQuadSolver();
     if (!s) return admpc_set_error(ADMPC_ENOMEM, "out of host memory");
     s->cfg = *cfg; s->device = device; s->d_cfg = nullptr; s->d_ticket = nullptr;
+    s->cap_sqp = 0; s->d_A[0] = s->d_A[1] = s->d_B[0] = s->d_B[1] = s->d_phi = nullptr; s->d_act = s->d_fst = s->d_st = nullptr;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return admpc_set_error(ADMPC_EHIP, "hipGetDeviceProperties failed"); }
     s->num_cu = prop.multiProcessorCount;
@@ -961,6 +1032,11 @@ void admpc_quad_destroy(AdmpcQuadSolver* s)
     QGuard guard(s->device);
     if (s->d_cfg) (void)hipFree(s->d_cfg);
     if (s->d_ticket) (void)hipFree(s->d_ticket);
+    for (int i = 0; i < 2; ++i) { if (s->d_A[i]) (void)hipFree(s->d_A[i]); if (s->d_B[i]) (void)hipFree(s->d_B[i]); }
+    if (s->d_phi) (void)hipFree(s->d_phi);
+    if (s->d_act) (void)hipFree(s->d_act);
+    if (s->d_fst) (void)hipFree(s->d_fst);
+    if (s->d_st) (void)hipFree(s->d_st);
     delete s;
 }
 
@@ -990,7 +1066,44 @@ int admpc_quad_solve_batch_ex(AdmpcQuadSolver* s, int B, const double* x0, const
     if (!x0 || !yref || !yref_e || !xbar || !ubar) return admpc_set_error(ADMPC_EINVAL, "null array argument");
     QGuard guard(s->device);
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");
-    return quad_solve(s, B, x0, yref, yref_e, gp_state, xbar, ubar, cost, status, iters, nullptr, 0, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int nsqp = s->cfg.sqp_iters > 1 ? s->cfg.sqp_iters : 1;
+    if (nsqp == 1) return quad_solve(s, B, x0, yref, yref_e, gp_state, xbar, ubar, cost, status, iters, nullptr, 0, st);
+    // ---- solver_type "SQP": nsqp QPs, acados' stopping test in front of every one but the first when a tolerance is set
+    const int N = s->cfg.N;
+    const bool tol_on = s->cfg.sqp_tol > 0.0;
+    if (B > s->cap_sqp) {
+        if (hipDeviceSynchronize() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipDeviceSynchronize failed");
+        for (int i = 0; i < 2; ++i) { if (s->d_A[i]) (void)hipFree(s->d_A[i]); if (s->d_B[i]) (void)hipFree(s->d_B[i]); s->d_A[i] = s->d_B[i] = nullptr; }
+        if (s->d_phi) (void)hipFree(s->d_phi); if (s->d_act) (void)hipFree(s->d_act); if (s->d_fst) (void)hipFree(s->d_fst); if (s->d_st) (void)hipFree(s->d_st);
+        s->d_phi = nullptr; s->d_act = s->d_fst = s->d_st = nullptr; s->cap_sqp = 0;
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipMalloc((void**)&s->d_A[i], (size_t)B * N * QX * QX * sizeof(double)) == hipSuccess && hipMalloc((void**)&s->d_B[i], (size_t)B * N * QX * QU * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s->d_phi, (size_t)B * N * QX * sizeof(double)) == hipSuccess && hipMalloc((void**)&s->d_act, (size_t)B * sizeof(int32_t)) == hipSuccess
+                && hipMalloc((void**)&s->d_fst, (size_t)B * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&s->d_st, (size_t)B * sizeof(int32_t)) == hipSuccess;
+        if (!ok) return admpc_set_error(ADMPC_EHIP, "quad SQP workspace allocation failed");
+        s->cap_sqp = B;
+    }
+    int32_t* stat = status ? status : s->d_st;
+    if (hipMemsetAsync(s->d_act, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess || hipMemsetAsync(stat, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess)
+        return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
+    const double* gps = gp_state ? gp_state : x0;                    // the first node's GP state as the solve kernel takes it
+    int gridS = s->num_cu * 2; if (gridS > B) gridS = B;
+    const int tb = 64, tg = (B + tb - 1) / tb;
+    for (int sq = 0; sq < nsqp; ++sq) {
+        const int cur = sq & 1, prev = cur ^ 1;
+        hipLaunchKernelGGL(admpc_quad_shoot_kernel, dim3(gridS), dim3(64), s->lds_bytes, st, s->d_cfg, B, (const double*)xbar, (const double*)ubar, gps, s->d_phi, s->d_A[cur], s->d_B[cur]);
+        if (tol_on && sq > 0)
+            hipLaunchKernelGGL(admpc_quad_sqp_test_kernel, dim3(tg), dim3(tb), 0, st, s->d_cfg, B, x0, yref, yref_e, (const double*)xbar, (const double*)ubar,
+                               (const double*)s->d_A[prev], (const double*)s->d_B[prev], (const double*)s->d_phi, (const double*)s->d_A[cur], (const double*)s->d_B[cur], s->d_act, s->d_fst);
+        int rc = quad_solve(s, B, x0, yref, yref_e, gp_state, xbar, ubar, cost, stat, iters, s->d_act, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(admpc_quad_sqp_merge_kernel, dim3(tg), dim3(tb), 0, st, B, (const int32_t*)stat, s->d_act, s->d_fst);
+    }
+    hipLaunchKernelGGL(admpc_quad_sqp_final_kernel, dim3(tg), dim3(tb), 0, st, B, tol_on ? 1 : 0, (const int32_t*)s->d_act, (const int32_t*)s->d_fst, stat);
+    if (hipGetLastError() != hipSuccess) return admpc_set_error(ADMPC_EHIP, "quad SQP kernel launch failed");
+    return ADMPC_OK;
 }
 
 int admpc_quad_solve_batch(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e,
@@ -1025,6 +1138,7 @@ int admpc_quad_solve_batch_routed(AdmpcQuadSolver* const* solvers, int K, int B,
     for (int c = 0; c < K; ++c) {
         if (!solvers[c]) return admpc_set_error(ADMPC_EINVAL, "null solver");
         if (solvers[c]->device != solvers[0]->device || solvers[c]->cfg.N != solvers[0]->cfg.N) return admpc_set_error(ADMPC_EINVAL, "the cluster solvers must share device and horizon");
+        if (solvers[c]->cfg.sqp_iters > 1) return admpc_set_error(ADMPC_EINVAL, "quad: solver_type SQP (sqp_iters > 1) is not implemented for routed (clustered GP) solves");
     }
     QGuard guard(solvers[0]->device);
     if (!guard.good) return admpc_set_error(ADMPC_EHIP, "hipSetDevice failed");

@@ -1400,6 +1400,9 @@ static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int
         (void)hipFuncSetAttribute((const void*)admpc_seg_kernel<S, 127>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         prepared = true;
     }
+    // every launch pair is self-contained: ticket counter, exit counter and bin counts start from zero on the caller's stream (the last
+    // workgroup to leave re-arms them as well; a launch that failed half-way, or a handle misused from two streams, cannot poison the next)
+    (void)hipMemsetAsync(sched, 0, F20_HDR * sizeof(int), st);
     hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap);
     if (qmask == 7)
         hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot);

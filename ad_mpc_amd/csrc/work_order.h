@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig*
     __syncthreads();
     if (threadIdx.x < F20_NB) base[threadIdx.x] = cnt[threadIdx.x] > 0 ? atomicAdd(sched + F20_BINS0 + threadIdx.x, cnt[threadIdx.x]) : 0;
     __syncthreads();
-    if (q >= 0) sched[F20_HDR + (size_t)q * cap + base[q] + rank] = b;
+    // never past the bin's list: the counts start from zero in every launch (the launch functions clear the header on the caller's stream),
+    // and a handle admits one solve at a time (admpc.h) -- should a caller break that rule, work is dropped from the ORDER, not memory overrun
+    if (q >= 0 && base[q] + rank < cap) sched[F20_HDR + (size_t)q * cap + base[q] + rank] = b;
 }
 
 // next instance for a persistent wave (wave-uniform), -1 when the batch is drained: tickets walk the bins from the most expensive

@@ -66,6 +66,19 @@ class Quad3DOptimizer:
             q_mask = np.asarray(q_mask, dtype=np.float64)
             q_diagonal = q_diagonal * np.concatenate((q_mask[:3], np.zeros(1), q_mask[3:]))
         terminal_cost = 0 if solver_options is None or not solver_options["terminal_cost"] else 1
+        # :203  nlp_solver_type = 'SQP_RTI' if solver_options is None else solver_options["solver_type"]; create_ros_gp_mpc.py:63-68 asks for
+        # "SQP" with point references.  "SQP": acados' loop -- at most nlp_solver_max_iter = 100 QPs, stopping on the four KKT residual norms
+        # <= 1e-6 (my_quad_acados_ocp.json:2075-2080), status 2 at the limit.  Anything else is refused, never ignored.
+        solver_type = "SQP_RTI" if solver_options is None else solver_options.get("solver_type", "SQP_RTI")
+        if solver_type == "SQP_RTI":
+            cfg.sqp_iters, cfg.sqp_tol = 1, 0.0
+        elif solver_type == "SQP":
+            cfg.sqp_iters, cfg.sqp_tol = 100, 1e-6
+            if gp_regressors is not None and isinstance(gp_regressors, QuadGPEnsemble) and len(gp_regressors.clusters) > 1:
+                raise NotImplementedError('solver_type "SQP" with a clustered GP ensemble (routed solves) is not implemented')
+        else:
+            raise ValueError('solver_options["solver_type"] must be "SQP_RTI" or "SQP" (quad_3d_optimizer.py:203), got %r' % (solver_type,))
+        self.solver_type = solver_type
         for i in range(QNX):
             cfg.W[i] = float(q_diagonal[i]); cfg.We[i] = float(q_diagonal[i]) * terminal_cost
         for m in range(QNU):
@@ -154,7 +167,7 @@ class Quad3DOptimizer:
         x, u, cost, st, it = self.solvers[m].solve_numpy(x_init, self.yref[m][None], self.yref_e[m][None], self.x_iter[m][None], self.u_iter[m][None],
                                                          gp_state=gp_state)
         self.status = int(st[0])
-        if self.status == 0:
+        if self.status in (0, 2):                 # 2: solver_type "SQP" at its iteration limit -- acados keeps (and so returns) the last iterate
             self.x_iter[m], self.u_iter[m] = x[0], u[0]
         w_opt = np.reshape(self.u_iter[m].copy(), (-1))
         return w_opt if not return_x else (w_opt, self.x_iter[m].copy())

@@ -18,7 +18,8 @@ class AdmpcQuadConfig(C.Structure):
         ("mass", C.c_double), ("J", C.c_double * 3), ("max_thrust", C.c_double),
         ("x_f", C.c_double * 4), ("y_f", C.c_double * 4), ("z_l_tau", C.c_double * 4), ("g", C.c_double), ("rdrv", C.c_double * 3),
         ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double), ("ipm_tol_comp", C.c_double), ("ipm_tol_res", C.c_double),
-        ("n_gp", C.c_int32), ("_pad", C.c_int32), ("gp", AdmpcGp * QUAD_GP_MAX),
+        ("sqp_tol", C.c_double),
+        ("n_gp", C.c_int32), ("sqp_iters", C.c_int32), ("gp", AdmpcGp * QUAD_GP_MAX),
     ]
 
     def copy(self):
@@ -46,6 +47,7 @@ def default_quad_config(N=10, t_horizon=1.0):
     for i, (xf, yf, zt) in enumerate(zip((h, -h, -h, h), (-h, -h, h, h), (-0.013, 0.013, -0.013, 0.013))):
         c.x_f[i], c.y_f[i], c.z_l_tau[i] = xf, yf, zt
     c.ipm_mu0, c.ipm_thr0 = 1.0, 0.1
+    c.sqp_iters, c.sqp_tol = 1, 0.0                 # SQP_RTI (the shipped solver_type); "SQP": sqp_iters 100, sqp_tol 1e-6 (my_quad_acados_ocp.json:2075-2080)
     c.ipm_tol_comp, c.ipm_tol_res = 1e-8, 1e-8      # the reference's levels: HPIPM mode BALANCE (acados_models/my_quad_acados_ocp.json leaves qp_solver_tol_* unset); tight_quad_ipm: 1e-10 / 1e-9
     return c
 

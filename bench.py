@@ -54,10 +54,19 @@ def algorithmic_bytes_per_solve(N, elem=8):
     return elem * (n_in + n_out) + 4
 
 
-def algorithmic_flops_per_solve(N, mean_ipm_iters, trial):
+def gp_flops_per_model_eval(cfg):
+    """Residual GPs inside the model (configs[2]): per training point of a regressor with d features 3 d (scaled squared distance) + 1 (exp,
+    counted as one operation like the sin / cos of SURVEY 8d's model count) + 2 (mean) + 3 d (gradient): 3 + 6 d; one-feature regressors with
+    20 points each (grid_gp): 3 x 20 x 9 = 540 per evaluation of the model, i.e. N x 4 x 540 per solve on top of the shooting's N x 4360."""
+    return float(sum(cfg.gp[g].n_points * (3 + 6 * cfg.gp[g].n_feat) for g in range(cfg.n_gp)))
+
+
+def algorithmic_flops_per_solve(N, mean_ipm_iters, trial, gp_eval_flops=0.0):
     """shooting N*4360 + N*1900 per interior-point iteration (measured mean iterations).  With the unconstrained
-    trial (cfg.ipm_try_unconstrained) every instance also pays one factorisation + one solve = 0.7 of an iteration's count."""
-    return N * 4360.0 + N * 1900.0 * (mean_ipm_iters + (0.7 if trial else 0.0))
+    trial (cfg.ipm_try_unconstrained) every instance also pays one factorisation + one solve = 0.7 of an iteration's count.
+    gp_eval_flops: the residual GPs' kernel sums per model evaluation (4 RK stages per shooting stage), so that configs[2]'s fraction
+    counts the same arithmetic as configs[1]'s."""
+    return N * (4360.0 + 4.0 * gp_eval_flops) + N * 1900.0 * (mean_ipm_iters + (0.7 if trial else 0.0))
 
 
 def measured_traffic(N, B, dtype, variant=""):
@@ -96,7 +105,7 @@ def traffic_child_args(argv, steps, warm):
     return out + ["--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-two-in-flight", "--no-tight-stop", "--no-live-traffic"]
 
 
-def live_traffic(argv, timeout_s=150):
+def live_traffic(argv, timeout_s=45):
     """HBM bytes of one step measured NOW, for this run's own workload: two child runs of this script under `rocprofv3 --pmc`
     (FETCH_SIZE and WRITE_SIZE in passes of their own: the TCC counters share slots -- MI355X_MICROARCH.md, HBM section; FETCH_SIZE is
     in KiB and doubled on gfx950, WRITE_SIZE in KiB), 3 steps each, no side measurements, summed over the kernels of a step and
@@ -122,6 +131,7 @@ def live_traffic(argv, timeout_s=150):
             r = subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
+                print("bench.py: live traffic: the %s pass exited with %d; reporting the committed summary of this workload instead" % (ctr, r.returncode), file=sys.stderr)
                 return None
             per_kernel = {}                                # kernel -> dispatch -> value (a counter row per XCD / SE instance is summed)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -138,7 +148,8 @@ def live_traffic(argv, timeout_s=150):
             total[ctr] = sum(sum(v.values()) for v in per_kernel.values()) / float(steps + warm)
         return {"bytes": total["FETCH_SIZE"] * 1024.0 * 2.0 + total["WRITE_SIZE"] * 1024.0,
                 "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (%d steps each)" % (steps + warm)}
-    except Exception:
+    except Exception as e:                 # a timeout (two passes, at most 45 s each) or an unreadable counter file
+        print("bench.py: live traffic: %r; reporting the committed summary of this workload instead" % (e,), file=sys.stderr)
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -281,9 +292,11 @@ def main():
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # torch.distributed.run: one rank per GPU, also for N = 1
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr); sys.exit(2)
-    # ---- N ranks or nothing.  No GPU call has happened yet (torch.cuda.device_count() does not initialise the device).
-    if not args.dry_collective and torch.cuda.device_count() < args.gpus:
-        print("bench.py: --gpus %d but only %d GPU(s) visible: refusing to report a smaller job" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+    # ---- N ranks or nothing.  The un-launched parent must see N GPUs; a launched rank only its own (a launcher may give every rank one
+    # visible device).  What matters for the ranks this file starts itself is that they are a child PROCESS, never an exec of this one.
+    ndev = torch.cuda.device_count()
+    if not args.dry_collective and ((not launched and ndev < args.gpus) or (launched and ndev <= (local_rank if ndev > 1 else 0))):
+        print("bench.py: --gpus %d but only %d GPU(s) visible%s: refusing to report a smaller job" % (args.gpus, ndev, " to rank %d" % rank if launched else ""), file=sys.stderr)
         sys.exit(3)
     if not launched and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
@@ -300,12 +313,13 @@ def main():
     os.dup2(2, 1)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dv = local_rank if torch.cuda.device_count() > 1 else 0
+        torch.cuda.set_device(dv)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dv))
         if dist.get_world_size() != args.gpus:
             print("bench.py: the process group has %d ranks, --gpus asks for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
             sys.exit(3)
-    dev_index = local_rank if launched else 0
+    dev_index = (local_rank if torch.cuda.device_count() > 1 else 0) if launched else 0      # one visible device per rank: index 0
     torch.cuda.set_device(dev_index)
 
     if args.batch_per_gpu is None:
@@ -482,7 +496,7 @@ def main():
         total = world * B * K
         value = total / elapsed
         trial = cfg.ipm_try_unconstrained != 0.0
-        flops = algorithmic_flops_per_solve(N, mean_iters, trial) * B
+        flops = algorithmic_flops_per_solve(N, mean_iters, trial, gp_flops_per_model_eval(cfg)) * B
         byts = algorithmic_bytes_per_solve(N, elem) * B
         traffic = None
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)      # already under a profiler (scripts/profile*.sh): no nested passes
@@ -503,7 +517,7 @@ def main():
             wl = "BASELINE configs[1]: batch %d random (x0, curved ref) scenarios, N=%d, %s" % (B, N, args.dtype)
         dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
         fused = dense and os.environ.get("ADMPC_N20") != "split"
-        seg = not f32 and ((N == 40 and os.environ.get("ADMPC_QP") != "riccati") or (N in (60, 80) and os.environ.get("ADMPC_QP") == "seg"))      # admpc_seg.hip: N / 20 cooperating waves per instance
+        seg = not f32 and ((N == 40 and not args.gp and os.environ.get("ADMPC_QP") != "riccati") or (N in (40, 60, 80) and os.environ.get("ADMPC_QP") == "seg"))      # admpc_seg.hip: N / 20 cooperating waves per instance
         out = {
             "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
@@ -524,7 +538,7 @@ def main():
                          "kernel_ms_is": "HIP-event time over the K timed steps on the launch stream / K: the kernels of a step and the gaps between them (the dominant kernel's own average duration: the rocprofv3 kernel trace under profiles/)",
                          **({"peak_unpacked": FP64_PEAK_TFLOPS, "frac_unpacked": ach_tf / FP64_PEAK_TFLOPS,
                              "peak_note": "157.3 TFLOP/s is the packed (v_pk_fma_f32) vector rate; kernel R issues unpacked v_fmac_f32 (DPP operands), whose rate is 78.6"} if f32 else {}),
-                         "note": ("%s; roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"
+                         "note": ("%s; roof = %s vector peak %.1f TFLOP/s; algorithmic FLOPs = N*4360 (+ N*4*540 for the GP kernel sums with --gp) + N*1900*(mean_ipm_iters + 0.7 for the unconstrained trial) per solve (SURVEY 8d)"
                                   % ("vector FMAs, the condensed Hessian alone on v_mfma_f64_16x16x4_f64 tiles (2 %% of the arithmetic; the fp64 matrix peak equals the vector peak: profiles/r3/mfma_condense_ab.txt)"
                                      if fused else "vector FMAs; the condensed Hessians and the Schur blocks of the cuts on v_mfma_f64_16x16x4_f64 tiles (the fp64 matrix peak equals the vector peak)"
                                      if seg else "the kernels issue vector FMAs only (no MFMA executes: profiles/r2/mfma_vs_valu_f64.txt)", "fp32" if f32 else "fp64", peak_tf))},

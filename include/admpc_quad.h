@@ -15,7 +15,8 @@
  * State  x = [p(3), q_wxyz(4), v(3), w(3)],  input u = activations of the four rotors in [0, 1].
  * Conventions as in admpc.h: device pointers owned by the caller, instance-major and dense, fp64; `stream` is a hipStream_t passed
  * as void*; 0 or a negative ADMPC_E* code is returned (admpc_last_error() of admpc.h gives the message); one solve in flight per
- * handle.  Per-instance status: 0 success (also at ipm_iter_max, acados RTI semantics), 4 non-finite step (iterate untouched).
+ * handle.  Per-instance status: 0 success (also at ipm_iter_max, acados RTI semantics), 2 SQP mode not converged within sqp_iters
+ * steps (iterate valid), 4 non-finite step (iterate untouched).
  */
 #ifndef ADMPC_QUAD_H
 #define ADMPC_QUAD_H
@@ -59,10 +60,16 @@ typedef struct AdmpcQuadConfig {
                                    * class): v' += R(q) D R(q)' v.  Zeros (the shipped generated code, default): no drag term.     */
     double  ipm_mu0, ipm_thr0, ipm_tol_comp, ipm_tol_res; /* interior point: start and stop levels (defaults 1e-8 / 1e-8: HPIPM
                                                            * mode BALANCE, what the reference runs; 1e-10 / 1e-9 for the exact minimiser) */
+    double  sqp_tol;              /* solver_type "SQP" (create_ros_gp_mpc.py:63-68 for point references, quad_3d_optimizer.py:203): with
+                                   * sqp_iters > 1, acados' stopping test in front of every QP but the first -- the inf-norms of the NLP's KKT
+                                   * residuals (stationarity, shooting defects, input-box violation, complementarity) all <= sqp_tol
+                                   * (my_quad_acados_ocp.json:2077-2080: 1e-6): status 0; not met after sqp_iters QPs: status 2
+                                   * (ACADOS_MAXITER; the iterate is valid).  0: sqp_iters plain RTI steps.                       */
     /* GP residual of the acceleration (quad_3d_optimizer.py:289-327): the features are taken from z = [x with the velocity in the
      * BODY frame; u] (feat[] indexes these 17 entries; 7..16 are offered: body-frame velocity, body rates, inputs), gp[g].out in {7, 8, 9} names the body-frame acceleration component the mean
      * is added to; the sum is rotated back to the world frame:  v' += R(q) mu(z).  n_gp = 0: nominal model (the shipped code). */
-    int32_t n_gp, _pad;
+    int32_t n_gp;
+    int32_t sqp_iters;            /* <= 1: SQP_RTI, one step per call (the shipped setting); > 1: that many SQP steps (nlp_solver_max_iter 100) */
     AdmpcGp gp[ADMPC_QUAD_GP_MAX];
 } AdmpcQuadConfig;
 

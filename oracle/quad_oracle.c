@@ -308,8 +308,13 @@ static int box_qp(const Cfg* c, int n, real H[NMAX][NMAX], const real* g, const 
 }
 
 /* gp_state: the GP state of the first node (run_optimization's gp_regression_state, :546-552; NULL: the initial state x0, its default) */
+/* pi_out [N][13], m_out [N][4] (may be NULL): the multipliers of the QP just solved, as acados holds them for the next stopping test.
+ * With full condensing the QP solver returns none for the dynamics: they follow from the adjoint recursion of the QP's stationarity in the
+ * states, and the net multiplier of an input's box pair (lower minus upper) from its stationarity in the inputs:
+ *   pi_{N-1} = We (x+_N - xref_N),   pi_{k-1} = Ts Q (x+_k - xref_k) + A_k' pi_k,   m_k = Ts R (u+_k - uref_k) + B_k' pi_k
+ * (A_k, B_k of the linearisation the QP was built on; x+, u+ the iterate after the full step). */
 static int rti_step(const Cfg* c, const real* x0, const real* yref, const real* yref_e, const real* gp_state, real* xbar, real* ubar, real* cost, int* iters,
-                    real* H_out, real* g_out)
+                    real* H_out, real* g_out, real* pi_out, real* m_out)
 {
     Work w;
     const int N = c->N, n = N * NU;
@@ -347,6 +352,71 @@ static int rti_step(const Cfg* c, const real* x0, const real* yref, const real* 
     for (int cc = 0; cc < NX; ++cc) { const real e = xn[N * NX + cc] - yref_e[cc]; J += 0.5 * c->We[cc] * e * e; }
     memcpy(xbar, xn, sizeof(real) * (N + 1) * NX); memcpy(ubar, un, sizeof(real) * n);
     *cost = J;
+    if (pi_out) {
+        real pk[NX];
+        for (int i = 0; i < NX; ++i) pk[i] = c->We[i] * (xn[N * NX + i] - yref_e[i]);
+        for (int k = N - 1; k >= 0; --k) {
+            for (int i = 0; i < NX; ++i) pi_out[k * NX + i] = pk[i];
+            for (int m = 0; m < NU; ++m) {
+                real a = c->Ts * c->W[NX + m] * (un[k * NU + m] - yref[k * ADMPC_QUAD_NY + NX + m]);
+                for (int i = 0; i < NX; ++i) a += w.B[k][i][m] * pk[i];
+                m_out[k * NU + m] = a;
+            }
+            if (k >= 1) {
+                real pn[NX];
+                for (int j = 0; j < NX; ++j) {
+                    real a = c->Ts * c->W[j] * (xn[k * NX + j] - yref[k * ADMPC_QUAD_NY + j]);
+                    for (int i = 0; i < NX; ++i) a += w.A[k][i][j] * pk[i];
+                    pn[j] = a;
+                }
+                memcpy(pk, pn, sizeof pk);
+            }
+        }
+    }
+    return 0;
+}
+
+/* acados' SQP stopping test (ocp_nlp_sqp.c / ocp_nlp_res_compute at the pinned commit 91a01d4c, requirements.txt:1; restated from the
+ * published algorithm): inf-norms of the NLP's KKT residuals at the iterate (xbar, ubar) with the multipliers (pi, m) of the last QP --
+ * res[0] stationarity, res[1] shooting defects (and x_0 - x0), res[2] violation of the input box, res[3] complementarity. */
+static void quad_nlp_residuals(const Cfg* c, const real* x0, const real* yref, const real* yref_e, const real* gp_state,
+                               const real* xbar, const real* ubar, const real* pi, const real* mm, real res[4])
+{
+    const int N = c->N;
+    real rs = 0, re = 0, ri = 0, rc = 0;
+#define UPN(acc, v) do { real a_ = fabs(v); if (a_ > acc || !(a_ == a_)) acc = a_; } while (0)
+    for (int i = 0; i < NX; ++i) UPN(re, xbar[i] - x0[i]);
+    for (int k = 0; k < N; ++k) {
+        real phi[NX], A[NX][NX], Bm[NX][NU];
+        quad_oracle_rk4_sens(c, xbar + k * NX, ubar + k * NU, (k == 0 && c->n_gp > 0) ? (gp_state ? gp_state : x0) : 0, c->Ts, phi, &A[0][0], &Bm[0][0]);
+        for (int i = 0; i < NX; ++i) UPN(re, phi[i] - xbar[(k + 1) * NX + i]);
+        for (int m = 0; m < NU; ++m) {
+            const real u = ubar[k * NU + m];
+            real a = c->Ts * c->W[NX + m] * (u - yref[k * ADMPC_QUAD_NY + NX + m]) - mm[k * NU + m];
+            for (int i = 0; i < NX; ++i) a += Bm[i][m] * pi[k * NX + i];
+            UPN(rs, a);
+            const real vl = c->lbu[m] - u, vu = u - c->ubu[m];
+            UPN(ri, vl > 0 ? vl : 0); UPN(ri, vu > 0 ? vu : 0);
+            const real ml = mm[k * NU + m] > 0 ? mm[k * NU + m] : 0, mu_ = mm[k * NU + m] < 0 ? -mm[k * NU + m] : 0;
+            UPN(rc, ml * (u - c->lbu[m])); UPN(rc, mu_ * (c->ubu[m] - u));
+        }
+        if (k >= 1)
+            for (int j = 0; j < NX; ++j) {
+                real a = c->Ts * c->W[j] * (xbar[k * NX + j] - yref[k * ADMPC_QUAD_NY + j]) - pi[(k - 1) * NX + j];
+                for (int i = 0; i < NX; ++i) a += A[i][j] * pi[k * NX + i];
+                UPN(rs, a);
+            }
+    }
+    for (int j = 0; j < NX; ++j) UPN(rs, c->We[j] * (xbar[N * NX + j] - yref_e[j]) - pi[(N - 1) * NX + j]);
+#undef UPN
+    res[0] = rs; res[1] = re; res[2] = ri; res[3] = rc;
+}
+
+/* tests: the four residuals of an iterate with given multipliers */
+int quad_oracle_nlp_residuals(const Cfg* c, const double* x0, const double* yref, const double* yref_e, const double* gp_state,
+                              const double* xbar, const double* ubar, const double* pi, const double* mm, double* res)
+{
+    quad_nlp_residuals(c, x0, yref, yref_e, gp_state, xbar, ubar, pi, mm, res);
     return 0;
 }
 
@@ -361,9 +431,27 @@ int quad_oracle_solve_batch(const Cfg* c, int B, const double* x0, const double*
 #pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : nbad) schedule(dynamic, 8)
 #endif
     for (int b = 0; b < B; ++b) {
-        int it = 0; real J;
-        const int st = rti_step(c, x0 + (size_t)b * NX, yref + (size_t)b * N * ADMPC_QUAD_NY, yref_e + (size_t)b * NX,
-                                gp_state ? gp_state + (size_t)b * NX : 0, xbar + (size_t)b * (N + 1) * NX, ubar + (size_t)b * N * NU, &J, &it, 0, 0);
+        int it = 0; real J = 0;
+        /* cfg.sqp_iters > 1: that many SQP steps (solver_type "SQP", create_ros_gp_mpc.py:63-68); with cfg.sqp_tol > 0 acados' stopping test
+         * in front of every QP but the first (a cold solver holds no multipliers: the first QP is always solved): converged -> status 0,
+         * the limit reached -> status 2 (ACADOS_MAXITER, iterate valid), a non-finite QP -> status 4 at once */
+        const int nsqp = c->sqp_iters > 1 ? c->sqp_iters : 1;
+        const int tol_on = nsqp > 1 && c->sqp_tol > 0;
+        real pi[ADMPC_QUAD_MAX_N * NX], mm[NMAX];
+        const real* gs = gp_state ? gp_state + (size_t)b * NX : 0;
+        int st = 0;
+        for (int sq = 0; sq < nsqp; ++sq) {
+            if (tol_on && sq > 0) {
+                real r[4];
+                quad_nlp_residuals(c, x0 + (size_t)b * NX, yref + (size_t)b * N * ADMPC_QUAD_NY, yref_e + (size_t)b * NX, gs,
+                                   xbar + (size_t)b * (N + 1) * NX, ubar + (size_t)b * N * NU, pi, mm, r);
+                if (r[0] <= c->sqp_tol && r[1] <= c->sqp_tol && r[2] <= c->sqp_tol && r[3] <= c->sqp_tol) { st = -1; break; }
+            }
+            st = rti_step(c, x0 + (size_t)b * NX, yref + (size_t)b * N * ADMPC_QUAD_NY, yref_e + (size_t)b * NX,
+                          gs, xbar + (size_t)b * (N + 1) * NX, ubar + (size_t)b * N * NU, &J, &it, 0, 0, pi, mm);
+            if (st != 0) break;
+        }
+        if (tol_on) st = st == -1 ? 0 : (st == 0 ? 2 : st);
         if (cost) cost[b] = J;
         if (status) status[b] = st;
         if (iters) iters[b] = it;
@@ -377,7 +465,7 @@ int quad_oracle_qp_debug(const Cfg* c, const double* x0, const double* yref, con
                          double* H, double* g, int32_t* iters)
 {
     int it = 0; real J;
-    const int st = rti_step(c, x0, yref, yref_e, 0, xbar, ubar, &J, &it, H, g);
+    const int st = rti_step(c, x0, yref, yref_e, 0, xbar, ubar, &J, &it, H, g, 0, 0);
     *iters = it;
     return st;
 }

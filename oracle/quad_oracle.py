@@ -26,6 +26,7 @@ class QuadOracle:
         L.quad_oracle_rk4_sens.argtypes = [cp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp]
         L.quad_oracle_solve_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
         L.quad_oracle_qp_debug.argtypes = [cp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]
+        L.quad_oracle_nlp_residuals.argtypes = [cp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
 
     def f(self, cfg, x, u, gpx=None):
         """gpx: the GP-state parameter of a first node (features and rotation of the GP residual come from it), or None."""
@@ -52,6 +53,14 @@ class QuadOracle:
         gs = None if gp_state is None else np.ascontiguousarray(gp_state, dtype=np.float64).reshape(B, QNX)
         self.lib.quad_oracle_solve_batch(C.byref(cfg), B, _ptr(x0), _ptr(yref), _ptr(yref_e), _ptr(gs) if gs is not None else None, _ptr(x), _ptr(u), _ptr(cost), _ptr(st, _ip), _ptr(it, _ip), int(nthreads))
         return x, u, cost, st, it
+
+    def nlp_residuals(self, cfg, x0, yref, yref_e, xbar, ubar, pi, m):
+        """(res_stat, res_eq, res_ineq, res_comp) of one instance's iterate with the multipliers pi [N,13], m [N,4] (lower minus upper)."""
+        a = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+        x0, yref, yref_e, xbar, ubar, pi, m = map(a, (x0, yref, yref_e, xbar, ubar, pi, m))
+        res = np.empty(4)
+        self.lib.quad_oracle_nlp_residuals(C.byref(cfg), _ptr(x0), _ptr(yref), _ptr(yref_e), None, _ptr(xbar), _ptr(ubar), _ptr(pi), _ptr(m), _ptr(res))
+        return res
 
     def qp_debug(self, cfg, x0, yref, yref_e, xbar, ubar):
         N = cfg.N; n = N * QNU

@@ -236,3 +236,64 @@ def test_first_node_gp_state_parameter(qoracle):
     n0 = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
     n1 = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], gp_state=other)
     assert np.array_equal(n0[1], n1[1])
+
+
+def test_sqp_mode_and_its_stopping_test(qoracle):
+    """solver_type "SQP" (create_ros_gp_mpc.py:63-68, quad_3d_optimizer.py:203) in the oracle: cfg.sqp_iters QPs with acados' stopping test.
+    (a) the C restatement of the four residuals against an independent numpy statement (multipliers by the adjoint recursion, residuals on
+    a fresh linearisation); (b) the loop: statuses 0 / 2, a converged instance has residuals <= tol and stays where it is when solved
+    again; the limit gives status 2 with a valid iterate; more QPs never hurt."""
+    cfg = default_quad_config(); N = cfg.N
+    s = random_quad_scenarios(12, cfg, seed=7, aggressive=0.3)
+    # ---- (a): one RTI step, then the residuals at the new iterate with the multipliers of that QP
+    for i in range(4):
+        A = np.empty((N, QNX, QNX)); Bm = np.empty((N, QNX, QNU))
+        for k in range(N):
+            _, A[k], Bm[k] = qoracle.rk4_sens(cfg, s["xbar"][i, k], s["ubar"][i, k], cfg.Ts)
+        x, u, *_ = qoracle.solve_batch(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], s["xbar"][i], s["ubar"][i])
+        x, u = x[0], u[0]
+        Q = cfg.Ts * np.array(cfg.W[:QNX]); R = cfg.Ts * np.array(cfg.W[QNX:]); We = np.array(cfg.We[:])
+        pi = np.empty((N, QNX)); m = np.empty((N, QNU))
+        pk = We * (x[N] - s["yref_e"][i])
+        for k in range(N - 1, -1, -1):
+            pi[k] = pk
+            m[k] = R * (u[k] - s["yref"][i, k, QNX:]) + Bm[k].T @ pk
+            if k >= 1:
+                pk = Q * (x[k] - s["yref"][i, k, :QNX]) + A[k].T @ pk
+        rs = re = ri = rc = 0.0
+        re = np.abs(x[0] - s["x0"][i]).max()
+        for k in range(N):
+            phi, An, Bn = qoracle.rk4_sens(cfg, x[k], u[k], cfg.Ts)
+            re = max(re, np.abs(phi - x[k + 1]).max())
+            rs = max(rs, np.abs(R * (u[k] - s["yref"][i, k, QNX:]) + Bn.T @ pi[k] - m[k]).max())
+            if k >= 1:
+                rs = max(rs, np.abs(Q * (x[k] - s["yref"][i, k, :QNX]) + An.T @ pi[k] - pi[k - 1]).max())
+            lb = np.array(cfg.lbu[:]); ub = np.array(cfg.ubu[:])
+            ri = max(ri, np.maximum(lb - u[k], 0).max(), np.maximum(u[k] - ub, 0).max())
+            rc = max(rc, (np.maximum(m[k], 0) * (u[k] - lb)).max(), (np.maximum(-m[k], 0) * (ub - u[k])).max())
+        rs = max(rs, np.abs(We * (x[N] - s["yref_e"][i]) - pi[N - 1]).max())
+        got = qoracle.nlp_residuals(cfg, s["x0"][i], s["yref"][i], s["yref_e"][i], x, u, pi, m)
+        np.testing.assert_allclose(got, [rs, re, ri, rc], rtol=1e-9, atol=1e-13)
+        assert got[1] > 1e-6                         # one RTI step from a cold iterate leaves shooting defects: not converged
+    # ---- (b): the loop
+    # (full-step Gauss-Newton SQP, acados' FIXED_STEP globalisation: no line search.  On this problem it converges linearly where it
+    # converges and settles into a small two-cycle of the inputs elsewhere -- about half of the mild scenarios within 100 QPs; what the loop
+    # must get right is the bookkeeping: 0 exactly for the instances that pass the test, 2 with a valid iterate for the others)
+    s = random_quad_scenarios(24, cfg, seed=7, pos_err=0.8, tilt=0.2, aggressive=0.0)
+    c100 = cfg.copy(); c100.sqp_iters, c100.sqp_tol = 100, 1e-6
+    x, u, cost, st, it = qoracle.solve_batch(c100, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    assert set(st.tolist()) <= {0, 2} and (st == 0).sum() >= 8 and np.isfinite(x).all()
+    x2, u2, _, st2, _ = qoracle.solve_batch(c100, s["x0"], s["yref"], s["yref_e"], x, u)
+    ok = st == 0
+    # a converged iterate: one more QP is solved (a cold solver has no multipliers for the first test), then the test passes; the QP barely moves it
+    assert (st2[ok] == 0).all() and np.abs(x2[ok] - x[ok]).max() < 1e-5 and np.abs(u2[ok] - u[ok]).max() < 1e-5
+    c3 = cfg.copy(); c3.sqp_iters, c3.sqp_tol = 3, 1e-6
+    x3, u3, _, st3, _ = qoracle.solve_batch(c3, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    assert (st3 == 2).sum() >= 12 and np.isfinite(x3).all()
+    crti = cfg.copy(); crti.sqp_iters, crti.sqp_tol = 3, 0.0       # three plain RTI steps: the same iterates as three calls
+    xa, ua = s["xbar"], s["ubar"]
+    for _ in range(3):
+        xa, ua, *_ = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], xa, ua)
+    xb, ub, _, stb, _ = qoracle.solve_batch(crti, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    assert (stb == 0).all() and np.abs(xa - xb).max() == 0.0 and np.abs(ua - ub).max() == 0.0
+    np.testing.assert_array_equal(x3, xb)            # ... and the first three QPs of the SQP loop are exactly those
