@@ -574,6 +574,393 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
 }
 
 
+// =====================================================================================================================================
+// N = 20 -- the default horizon of the reference class (quad_3d_optimizer.py:28) -- as TWO cooperating waves per instance (round 4): each
+// wave shoots, condenses (40 inputs), factorises and expands 10 stages with the machinery of the one-wave kernel above; the two segments
+// are coupled through the 13 states at the cut, z = dx_10:  z = Bbar U_0 + c  with multiplier nu.  The bordered factorisation (the 13 rows
+// of Bbar ride along in wave 0's lanes 40..52, the 13 rows of Hzu in wave 1's), the Schur blocks on v_mfma_f64_16x16x4_f64 and the four
+// solution operators of the cut are seg_cut.h -- the scheme of the car's segmented kernel (admpc_seg.hip; DESIGN.md section 4, kernel S) with
+// D = 13.  Same Newton steps as the oracle's dense 80-input box QP (oracle/quad_oracle.c: box_qp) in another elimination order.
+// =====================================================================================================================================
+#include "seg_cut.h"
+#define QSYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#define QWAVE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+struct QSegLds {      // doubles; per wave: the one-wave kernel's map for 10 stages (gam rows of 64 lanes: the z lanes publish too) + the border rows
+    static constexpr int Ns = 10, n = 40, NB = 14, NR = 54, D = 13, GS = 16;
+    static constexpr int oA = 0, oB = oA + Ns * QX * QX, ob = oB + Ns * QX * QU, oH = ob + Ns * QX, oHb = oH + 820, oL = oHb + NB * n, oLb = oL + 820,
+                         oGam = oLb + NB * n, oVec = oGam + QX * 64, oXnew = oVec + 64, oXbs = oXnew + 144, oYrs = oXbs + 144, oXhs = oYrs + 184,
+                         oWts = oXhs + 16, oWv = oWts + 28, seg = oWv + 16;
+    // interface block of a segment
+    static constexpr int IF_SC = 0, IF_HZZ = IF_SC + NB * NB, IF_C = IF_HZZ + D * GS, IF_ZB = IF_C + 16, IF_Z = IF_ZB + 16, IF_DZ = IF_Z + 16,
+                         IF_GZ = IF_DZ + 16, IF_RED = IF_GZ + 16, IF_BU = IF_RED + 32, IFS = IF_BU + 16;
+    static constexpr int oIF = 2 * seg, oYM = oIF + 2 * IFS, oPI = oYM + 4 * D * GS, oWG = oPI + D * GS, total = oWG + 8;
+};
+
+__global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
+                                                             const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
+                                                             double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
+                                                             int* __restrict__ ticket, const double* __restrict__ gpsg, const int32_t* __restrict__ routeg, int which)
+{
+    using LD = QSegLds;
+    constexpr int Ns = LD::Ns, n = LD::n, NR = LD::NR, D = LD::D, GS = LD::GS, NT = 2 * Ns;
+    extern __shared__ double lds_raw[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool first = wv == 0, last = wv == 1;
+    const int k0 = wv * Ns;
+    double* const P = lds_raw + wv * LD::seg;
+    double* const A_ = P + LD::oA; double* const B_ = P + LD::oB; double* const b_ = P + LD::ob;
+    double* const Hp = P + LD::oH; double* const Hb = P + LD::oHb; double* const Lp = P + LD::oL; double* const Lb = P + LD::oLb;
+    double* const gam = P + LD::oGam; double* const vec = P + LD::oVec; double* const xnew = P + LD::oXnew; double* const xbs = P + LD::oXbs;
+    double* const yrs = P + LD::oYrs; double* const xhs = P + LD::oXhs; double* const wts = P + LD::oWts; double* const wvec = P + LD::oWv;
+    double* const ifb = lds_raw + LD::oIF;
+    double* const IFm = ifb + wv * LD::IFS;
+    double* const YM = lds_raw + LD::oYM; double* const PI = lds_raw + LD::oPI;
+    int* const wgw = reinterpret_cast<int*>(lds_raw + LD::oWG);
+    const Dense40bLds W{Hp, Hb, Lp, Lb, gam, gam + 64};             // exchange buffers / pivots in gam (free after the condensing)
+#define QRED(s_, ph_, i_) ifb[(s_) * LD::IFS + LD::IF_RED + (ph_) * 8 + (i_)]
+    const bool act = lane < n;
+    const bool zl = !first && lane >= n && lane < n + D;             // z rows (wave 1); wave 0's lanes 40..52 carry the rows of Bbar
+    const int li = act ? lane : 0, ji = li / QU, mi = li - ji * QU;
+    const int zi = zl ? lane - n : 0;
+    const double Ts = c->Ts;
+    if (lane < QX) { wts[lane] = Ts * c->W[lane]; wts[QX + lane] = c->We[lane]; }
+    const double Rw = Ts * c->W[QX + mi], lbm = c->lbu[mi], ubm = c->ubu[mi];
+    const double thr0 = c->ipm_thr0, mu0 = c->ipm_mu0, tolc = c->ipm_tol_comp, tolr = c->ipm_tol_res;
+    const int itmax = c->ipm_iter_max;
+    const double inv2n = 1.0 / (2.0 * (double)(NT * QU));
+    typedef double d4q __attribute__((ext_vector_type(4)));
+
+    int inst = blockIdx.x;
+    for (;;) {
+        // ---- the workgroup's next instance (wave 0 draws, both waves take it)
+        if (wv == 0 && lane == 0) wgw[0] = inst;
+        QSYNC();
+        inst = __builtin_amdgcn_readfirstlane(wgw[0]);
+        if (inst >= B) break;
+        auto next_inst = [&](int cur) -> int {                       // evaluated by both waves alike only for the static stride; the counter is wave 0's
+            if (!ticket) return cur + (int)gridDim.x;
+            int tk = 0;
+            if (wv == 0) { if (lane == 0) tk = atomicAdd(ticket, 1); tk = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tk); }
+            return tk;
+        };
+        if (routeg && routeg[inst] != which) { inst = next_inst(inst); QSYNC(); continue; }
+        double* xb = xbarg + (size_t)inst * (NT + 1) * QX;
+        double* ub = ubarg + (size_t)inst * NT * QU;
+        const double* yr = yrefg + (size_t)inst * NT * QY;
+        const double* ye = yrefeg + (size_t)inst * QX;
+        const double* x0 = x0g + (size_t)inst * QX;
+        const double* gq = gpsg ? gpsg + (size_t)inst * QX : x0;
+        double* xbg = xb + (size_t)k0 * QX;                           // the segment's rows
+        double* ubg = ub + (size_t)k0 * QU;
+        const double* yrg = yr + (size_t)k0 * QY;
+        for (int i = lane; i < (Ns + 1) * QX; i += 64) xbs[i] = xbg[i];
+        for (int i = lane; i < Ns * QY + QX; i += 64) yrs[i] = i < Ns * QY ? yrg[i] : (last ? ye[i - Ns * QY] : yrg[i]);      // row 10: terminal reference (last) / the next stage's states
+        // ---- 1. shooting of the segment's 10 stages: 17 tasks (state + one sensitivity column) per stage
+        for (int t = lane; t < Ns * (QX + QU); t += 64) {
+            const int k = t / (QX + QU), col = t - k * (QX + QU);
+            double x[QX], u[QU], phi[QX], sc[QX];
+#pragma unroll
+            for (int i = 0; i < QX; ++i) x[i] = xbg[k * QX + i];
+#pragma unroll
+            for (int m = 0; m < QU; ++m) u[m] = ubg[k * QU + m];
+            rk4_col(c, x, u, k + k0 == 0, gq, c->Ts, col, phi, sc);
+#pragma unroll
+            for (int i = 0; i < QX; ++i) {
+                if (col < QX) A_[(k * QX + i) * QX + col] = sc[i]; else B_[(k * QX + i) * QU + (col - QX)] = sc[i];
+                if (col == 0) b_[k * QX + i] = phi[i] - xbg[(k + 1) * QX + i];
+            }
+        }
+        QWAVE();
+        // ---- 2. condensing: lane i < 40 carries column i of Gamma_k = d x_k / d U_s, lanes 40..52 of wave 1 the columns of Phi_k = d x_k / d z
+        double hrow[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) hrow[j] = 0.0;
+        double g[QX];
+#pragma unroll
+        for (int i = 0; i < QX; ++i) g[i] = (zl && zi == i) ? 1.0 : 0.0;
+        if (lane < QX) xhs[lane] = first ? x0[lane] - xb[lane] : 0.0;
+        const double ubar_i = ubg[li];
+        double grad = act ? Rw * (ubar_i - yrg[ji * QY + QX + mi]) : 0.0;
+        d4q hzz = {0.0, 0.0, 0.0, 0.0};                              // Hzz = sum Phi' Q Phi on one MFMA tile (wave 1)
+        const int r16 = lane & 15, kq = lane >> 4;
+        QWAVE();
+        if (!first) {
+            // the segment's first stage is the cut itself: Phi = I, Gamma = 0, free response 0 -- its tracking cost belongs to this segment
+            if (zl) grad += wts[zi] * (xbs[zi] - yrs[zi]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const int i = kq + 4 * v; if (i == r16 && i < QX) hzz[v] = wts[i]; }
+        }
+        for (int k = 0; k < Ns; ++k) {
+            double gn[QX];
+            const int rr = lane < QX ? lane : 0;
+            double xn = b_[k * QX + rr];
+#pragma unroll
+            for (int cc = 0; cc < QX; ++cc) xn += A_[(k * QX + rr) * QX + cc] * xhs[cc];
+            double Ar[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int e = lane + 64 * m; Ar[m] = A_[k * QX * QX + (e < QX * QX ? e : QX * QX - 1)]; }
+#pragma unroll
+            for (int r = 0; r < QX; ++r) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < QX; ++cc) sacc += bcast(Ar[(r * QX + cc) / 64], (r * QX + cc) % 64) * g[cc];
+                gn[r] = zl ? sacc : (act ? (ji == k ? B_[(k * QX + r) * QU + mi] : (ji < k ? sacc : 0.0)) : 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < QX; ++r) { g[r] = gn[r]; gam[r * 64 + lane] = gn[r]; }
+            if (lane < QX) xhs[lane] = xn;
+            QWAVE();
+            const bool cost_k = k + 1 < Ns || last;                  // stage k0 + 10 is the next segment's; the horizon's last stage carries the terminal weights
+            if (cost_k) {
+                const double* ref = yrs + (k + 1) * QY;
+                const int lim = (k + 1) * QU;
+                const int wo = (k + 1 < Ns) ? 0 : QX;
+                double wg[QX];
+#pragma unroll
+                for (int cc = 0; cc < QX; ++cc) {
+                    const double wq = wts[wo + cc];
+                    wg[cc] = g[cc] * wq;
+                    if (wq != 0.0) grad += wg[cc] * (xbs[(k + 1) * QX + cc] + xhs[cc] - ref[cc]);
+                }
+                double Rb[QX][3];
+#pragma unroll
+                for (int cc = 0; cc < QX; ++cc)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) Rb[cc][m] = gam[cc * 64 + 16 * m + (lane & 15)];
+                static_for<0, 10>([&](auto qq) __attribute__((always_inline)) {
+                    constexpr int i2 = 4 * decltype(qq)::value;
+                    if (i2 < lim) {
+                        static_for<0, QX>([&](auto ccc) __attribute__((always_inline)) {
+                            constexpr int cc = decltype(ccc)::value;
+                            fmac_rowbc4_ld<i2 % 16>(hrow[i2], hrow[i2 + 1], hrow[i2 + 2], hrow[i2 + 3], Rb[cc][i2 / 16], wg[cc]);
+                        });
+                    }
+                });
+                if (!first) {
+                    // Hzz += Phi' W Phi: four K-steps of a 16 x 16 x 4 tile (13 components, the rest weightless); operand (i = lane & 15, k = lane >> 4)
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int comp = 4 * t4 + kq;
+                        const int cc = comp < QX ? comp : 0;
+                        const double ph = gam[cc * 64 + n + (r16 < D ? r16 : 0)];
+                        const double wq = comp < QX ? wts[wo + cc] : 0.0;
+                        hzz = __builtin_amdgcn_mfma_f64_16x16x4f64(ph * wq, ph, hzz, 0, 0, 0);
+                    }
+                }
+            }
+            QWAVE();
+        }
+        // ---- the packed rows: inputs -> H (+ R on the diagonal), z lanes -> Hzu (border rows 0..12), Hzz; wave 0: Bbar = Gamma at the cut, c
+        store_row_40(hrow, lds_byte_addr(Hp + (act ? tri(li, 0) : 0)));
+        if (zl) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) Hb[zi * n + j] = hrow[j];
+        }
+        if (!first) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const int i = kq + 4 * v; if (i < D && r16 < D) IFm[LD::IF_HZZ + i * GS + r16] = hzz[v]; }
+        }
+        if (first && act) {
+#pragma unroll
+            for (int r = 0; r < QX; ++r) Hb[r * n + lane] = g[r];
+        }
+        if (act) Hb[13 * n + lane] = 0.0;                             // the fourteenth border row of the 54-row blocks: unused
+        if (first && lane < QX) IFm[LD::IF_C + lane] = xhs[lane];
+        QWAVE();
+        if (act) { Hp[tri(li, li)] += Rw; Lp[tri(li, li)] = 0.0; }
+        const double gz0 = zl ? grad : 0.0;                           // d f_1 / d z at (z = 0, U = 0)
+        QSYNC();
+        if (!first && lane < D) { IFm[LD::IF_Z + lane] = ifb[LD::IF_C + lane]; }      // cold start: z = c_0 (U_0 = 0)
+        QWAVE();
+        // ---- 3. box QP, the two segments coupled through the cut
+        const double lo = lbm - ubar_i, hi = ubm - ubar_i;
+        double du = 0.0;
+        double tl = act ? fmax(du - lo, thr0) : 1.0, tu = act ? fmax(hi - du, thr0) : 1.0;
+        double ll = act ? mu0 / tl : 0.0, lu = act ? mu0 / tu : 0.0;
+        double alpha_prev = 1.0;
+        int it = 0, st = 0;
+        bool cons = false;
+        for (;; ++it) {
+            int lz = lane;
+            asm volatile("" : "+v"(lz));
+            // local gradients: inputs  grad + H du (+ Hzu' z) - ll + lu ;  z rows (wave 1)  gz0 + Hzu du + Hzz z
+            double hdu = dense40b_symv<NR>(W, lane, act ? du : 0.0, lz);
+            if (!first) {
+                const double* base = act ? Hb + lane : IFm + LD::IF_HZZ + zi * GS;
+                const int stride = act ? n : 1;
+                double a = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < D; ++cc) a = fma(base[cc * stride], IFm[LD::IF_Z + cc], a);
+                hdu += a;
+            }
+            const double rs_loc = act ? grad + hdu - ll + lu : 0.0;
+            const double gzc = zl ? gz0 + hdu : 0.0;
+            if (zl) IFm[LD::IF_GZ + zi] = gzc;
+            QSYNC();
+            // the full condensed stationarity residual (the oracle's rs): wave 0's inputs also see the second segment through the cut
+            double rs_full = rs_loc;
+            if (first && act) {
+                double a = 0.0;
+#pragma unroll
+                for (int r = 0; r < D; ++r) a = fma(Hb[r * n + lane], ifb[LD::IFS + LD::IF_GZ + r], a);
+                rs_full += a;
+            }
+            const double rl = du - lo - tl, ru = hi - du - tu;
+            {
+                const double mus = wave_sum(act ? tl * ll + tu * lu : 0.0);
+                const double cmx = wave_max(act ? fmax(tl * ll, tu * lu) : 0.0);
+                const double rmx = wave_max(act ? fmax(fabs(rs_full), fmax(fabs(rl), fabs(ru))) : 0.0);
+                if (lane == 0) { QRED(wv, 0, 0) = mus; QRED(wv, 0, 1) = cmx; QRED(wv, 0, 2) = rmx; }
+            }
+            QSYNC();
+            const double mu = (QRED(0, 0, 0) + QRED(1, 0, 0)) * inv2n;
+            const double cmax = fmax(QRED(0, 0, 1), QRED(1, 0, 1));
+            const double rmax = OpMaxNan::f(QRED(0, 0, 2), QRED(1, 0, 2));
+            if (!(mu == mu) || !(rmax == rmax)) { st = 4; break; }
+            if ((cmax <= tolc && rmax <= tolr) || it >= itmax + (cons ? ADMPC_QUAD_IPM_FALLBACK_ITER : 0)) break;
+            if (!cons && it >= ADMPC_QUAD_IPM_FALLBACK_ITER) {
+                cons = true;
+                du = 0.0;
+                tl = act ? fmax(du - lo, thr0) : 1.0; tu = act ? fmax(hi - du, thr0) : 1.0;
+                ll = act ? mu0 / tl : 0.0; lu = act ? mu0 / tu : 0.0;
+                alpha_prev = 1.0;
+                if (!first && lane < D) IFm[LD::IF_Z + lane] = ifb[LD::IF_C + lane];
+                QSYNC();
+                --it;
+                continue;
+            }
+            const double Dl = act ? ll / tl : 0.0, Du = act ? lu / tu : 0.0;
+            dense40b_factorise<NR>(W, act ? Dl + Du : 1.0, lz);
+            dense40b_schur<LD::NB>(W, IFm + LD::IF_SC, LD::NB, lane);
+            QSYNC();
+            if (wv == 0) cut_operators2<D, GS>(ifb + LD::IF_SC, LD::NB, ifb + LD::IFS + LD::IF_HZZ, GS, 0.0, -1, ifb + LD::IFS + LD::IF_SC, LD::NB, PI, YM, lz);
+            // one coupled solve: right-hand side y on the inputs, the reduced stationarity of z on wave 1's z rows
+            auto solve = [&](const double yu, const double yz) -> double {
+                double y = act ? yu : (zl ? yz : 0.0);
+                const unsigned pub = lds_byte_addr(W.cb + (lz & 15));
+                fwd_subst_40_b<NR>(y, dense40b_row_addr<NR>(Lp, Lb, lz), pub);
+                if (lz >= n && lz < n + 16) IFm[LD::IF_ZB + lz - n] = y;
+                QSYNC();
+                const double a = cut_apply2<D, GS>(YM, first, ifb + LD::IF_ZB, ifb + LD::IFS + LD::IF_ZB, lz);
+                if (lz < 16) wvec[lz] = lz < D ? (first ? -a : a) : 0.0;
+                if (!first && lz < D) IFm[LD::IF_DZ + lz] = a;
+                QWAVE();
+                double x = y * W.invd[act ? lz : 0];
+#pragma unroll
+                for (int bq = 0; bq < D; ++bq) x = fma(-Lb[bq * n + (act ? lz : 0)], wvec[bq], x);
+                bwd_subst_40(x, lds_byte_addr(Lp + (act ? lz : 0)), pub);
+                return act ? x : 0.0;
+            };
+            const double da = solve(-rs_loc + (-ll - Dl * rl) - (-lu - Du * ru), -gzc);
+            double dtl = da + rl, dtu = -da + ru;
+            double dll = -ll - Dl * dtl, dlu = -lu - Du * dtu;
+            auto ratio_local = [&]() -> double {
+                double a = 1.0;
+                if (act) {
+                    if (dtl < 0) a = fmin(a, -tl / dtl);
+                    if (dtu < 0) a = fmin(a, -tu / dtu);
+                    if (dll < 0) a = fmin(a, -ll / dll);
+                    if (dlu < 0) a = fmin(a, -lu / dlu);
+                }
+                return wave_min(a);
+            };
+            {
+                const double am = ratio_local();
+                const double sd = wave_sum(act ? dtl * dll + dtu * dlu : 0.0);
+                if (lane == 0) { QRED(wv, 1, 0) = am; QRED(wv, 1, 1) = sd; }
+            }
+            QSYNC();
+            double amax = fmin(QRED(0, 1, 0), QRED(1, 1, 0));
+            // sum (t + a dt)(l + a dl) = (1 - a) sum t l + a^2 sum dt dl  (the predictor's right-hand side is t l: t dl + l dt = -t l exactly)
+            const double muaff = ((1.0 - amax) * mu / inv2n + amax * amax * (QRED(0, 1, 1) + QRED(1, 1, 1))) * inv2n;
+            double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+            if (alpha_prev < ADMPC_QUAD_IPM_BLOCKED_STEP) sigma = 1.0;
+            const double smu = sigma * mu;
+            const double cl = act ? (smu - (cons ? 0.0 : dtl * dll)) / tl : 0.0, cu = act ? (smu - (cons ? 0.0 : dtu * dlu)) / tu : 0.0;
+            const double d = solve(-rs_loc + (cl - ll - Dl * rl) - (cu - lu - Du * ru), -gzc);
+            dtl = d + rl; dtu = -d + ru;
+            dll = cl - ll - Dl * dtl; dlu = cu - lu - Du * dtu;
+            {
+                const double am = ratio_local();
+                if (lane == 0) QRED(wv, 2, 0) = am;
+            }
+            QSYNC();
+            amax = fmin(QRED(0, 2, 0), QRED(1, 2, 0));
+            double tau = 1.0 - muaff; tau = fmax(tau, 0.995); tau = fmin(tau, 0.999999);
+            const double alpha = fmin(tau * amax, 1.0);
+            if (act) {
+                du += alpha * d;
+                tl = fmax(tl + alpha * dtl, 1e-40); tu = fmax(tu + alpha * dtu, 1e-40);
+                ll = fmax(ll + alpha * dll, 1e-40); lu = fmax(lu + alpha * dlu, 1e-40);
+            }
+            if (!first && lane < D) IFm[LD::IF_Z + lane] += alpha * IFm[LD::IF_DZ + lane];
+            alpha_prev = alpha;
+            QWAVE();
+        }
+        // ---- 4. expansion from the cut state of the returned inputs, full step, cost
+        if (first) {
+            const double duv = act ? du : 0.0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                const double v = wave_sum(Hb[r * n + li] * duv);
+                if (lane == 0) IFm[LD::IF_BU + r] = v + IFm[LD::IF_C + r];
+            }
+        }
+        QSYNC();
+        vec[lane] = act ? du : 0.0;
+        bool bad = st != 0;
+        const double un = ubar_i + du;
+        if (act && !(fabs(un) <= 1e300)) bad = true;
+        double dx = lane < QX ? (first ? x0[lane] - xb[lane] : ifb[LD::IF_BU + lane]) : 0.0;
+        if (lane < QX) xnew[lane] = xbs[lane] + dx;
+        double J = 0.0;
+        if (act) { const double e = un - yrg[ji * QY + QX + mi]; J += 0.5 * Rw * e * e; }
+        QWAVE();
+        for (int k = 0; k < Ns; ++k) {
+            if (lane < QX) gam[lane] = dx;
+            QWAVE();
+            double dn = 0.0;
+            if (lane < QX) {
+                dn = b_[k * QX + lane];
+                for (int cc = 0; cc < QX; ++cc) dn += A_[(k * QX + lane) * QX + cc] * gam[cc];
+                for (int m = 0; m < QU; ++m) dn += B_[(k * QX + lane) * QU + m] * vec[k * QU + m];
+                const double xv = xbs[(k + 1) * QX + lane] + dn;
+                xnew[(k + 1) * QX + lane] = xv;
+                if (!(fabs(xv) <= 1e300)) bad = true;
+            }
+            QWAVE();
+            dx = dn;
+        }
+        // tracking cost of the segment's stages: k0 .. k0 + 9 with the stage weights; the last segment adds the terminal stage
+        for (int i = lane; i < (Ns + 1) * QX; i += 64) {
+            const int k = i / QX, cc = i - k * QX;
+            if (k < Ns || last) {
+                const double e = xnew[i] - yrs[k * QY + cc];
+                J += 0.5 * (k < Ns ? Ts * c->W[cc] : c->We[cc]) * e * e;
+            }
+        }
+        const bool anyb = __any(bad) != 0;
+        J = wave_sum(J);
+        if (lane == 0) { QRED(wv, 3, 0) = J; QRED(wv, 3, 1) = anyb ? 1.0 : 0.0; }
+        QSYNC();                                                       // every wave has read what it needs of xbar (the row at the cut is shared)
+        const bool badall = QRED(0, 3, 1) != 0.0 || QRED(1, 3, 1) != 0.0;
+        if (!badall) {
+            for (int i = lane + (first ? 0 : QX); i < (Ns + 1) * QX; i += 64) xbg[i] = xnew[i];      // rows k0 + 1 .. k0 + 10 (wave 0: row 0 as well)
+            if (act) ubg[li] = un;
+        }
+        if (wv == 0 && lane == 0) {
+            if (costg) costg[inst] = badall ? INFINITY : QRED(0, 3, 0) + QRED(1, 3, 0);
+            if (statusg) statusg[inst] = badall ? 4 : 0;
+            if (itersg) itersg[inst] = it;
+        }
+        inst = next_inst(inst);
+        QSYNC();
+    }
+#undef QRED
+}
+
 // ---- horizons beyond 16 (N nu up to 96 inputs; the reference class defaults to n_nodes = 20, quad_3d_optimizer.py:29): the same
 // algorithm with one THREAD per input in a workgroup of two wavefronts.  What the one-wave kernel exchanges inside the wave (v_readlane
 // broadcasts, DPP reductions) goes through LDS and workgroup barriers here -- about a thousand barriers per interior-point iteration:
@@ -944,6 +1331,7 @@ struct AdmpcQuadSolver {
     int* d_ticket;           // work counter of the solve kernel
     int device, num_cu, lds_bytes;
     int generic;             // ADMPC_QUAD_GENERIC=1: the LDS-resident Cholesky path also at N nu = 40 (A/B tests)
+    int wide20;              // ADMPC_QUAD_WIDE=1: N = 20 on the two-wave dense kernel of round 3 instead of the segmented kernel (A/B tests)
     // SQP mode (cfg.sqp_iters > 1), allocated at its first solve: two linearisations (the last QP's and the iterate's), activity flags
     int cap_sqp;
     double *d_A[2], *d_B[2], *d_phi;
@@ -1012,6 +1400,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     s->num_cu = prop.multiProcessorCount;
     s->lds_bytes = (quad_lds_doubles(cfg->N) + (cfg->N * QU > 64 ? cfg->N * QU + 4 : 0)) * (int)sizeof(double);      // wide path: + pivots, broadcast and reduction slots
     { const char* e = getenv("ADMPC_QUAD_GENERIC"); s->generic = e && e[0] == '1'; }
+    { const char* e = getenv("ADMPC_QUAD_WIDE"); s->wide20 = e && e[0] == '1'; }
     if (hipMalloc((void**)&s->d_cfg, sizeof(AdmpcQuadConfig)) != hipSuccess || hipMalloc((void**)&s->d_ticket, sizeof(int)) != hipSuccess ||
         hipMemcpy(s->d_cfg, cfg, sizeof(AdmpcQuadConfig), hipMemcpyHostToDevice) != hipSuccess) {
         if (s->d_cfg) (void)hipFree(s->d_cfg);
@@ -1022,6 +1411,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     (void)hipFuncSetAttribute((const void*)admpc_quad_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_shoot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)admpc_quad_solve_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)admpc_quad_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = s;
     return ADMPC_OK;
 }
@@ -1043,11 +1433,15 @@ void admpc_quad_destroy(AdmpcQuadSolver* s)
 static int quad_solve(AdmpcQuadSolver* s, int B, const double* x0, const double* yref, const double* yref_e, const double* gp_state,
                       double* xbar, double* ubar, double* cost, int32_t* status, int32_t* iters, const int32_t* route, int which, hipStream_t st)
 {
-    int per_cu = (160 * 1024) / s->lds_bytes; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    const bool seg20 = s->cfg.N == 20 && !s->wide20;      // the class default horizon: two cooperating waves per instance, 10 condensed stages each
+    const int ldsb = seg20 ? QSegLds::total * (int)sizeof(double) : s->lds_bytes;
+    int per_cu = (160 * 1024) / ldsb; if (per_cu > (seg20 ? 4 : 8)) per_cu = seg20 ? 4 : 8; if (per_cu < 1) per_cu = 1;
     int grid = s->num_cu * per_cu; if (grid > B) grid = B;
     int* ticket = B > 8 * grid ? s->d_ticket : nullptr;
     if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), st) != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
-    if (s->cfg.N * QU > 64)          // horizons beyond 16: one thread per input, two waves per instance
+    if (seg20)
+        hipLaunchKernelGGL(admpc_quad_seg_kernel, dim3(grid), dim3(128), ldsb, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
+    else if (s->cfg.N * QU > 64)          // horizons beyond 16: one thread per input, two waves per instance
         hipLaunchKernelGGL(admpc_quad_solve_wide_kernel, dim3(grid), dim3(QW_NT), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
     else if (s->cfg.N * QU == 40 && !s->generic)
         hipLaunchKernelGGL(admpc_quad_solve_kernel<true>, dim3(grid), dim3(64), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);

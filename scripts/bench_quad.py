@@ -8,7 +8,8 @@ from ad_mpc_amd.quad_config import default_quad_config
 from ad_mpc_amd.quad_scenarios import random_quad_scenarios
 from ad_mpc_amd.engine import QuadBatchSolver
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = default_quad_config(); s = random_quad_scenarios(B, cfg, seed=1)
+NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 10                 # horizon: 10 (the shipped code), 20 (the class default)
+cfg = default_quad_config(N=NQ, t_horizon=0.1 * NQ); s = random_quad_scenarios(B, cfg, seed=1)
 if os.environ.get("QUAD_ITMAX"): cfg.ipm_iter_max = int(os.environ["QUAD_ITMAX"])      # 0: shooting + condensing + expansion only (cost split)
 eng = QuadBatchSolver(cfg); d = lambda a: torch.as_tensor(a, device="cuda")
 x0, yr, ye, xb0, ub0 = d(s["x0"]), d(s["yref"]), d(s["yref_e"]), d(s["xbar"]), d(s["ubar"])
