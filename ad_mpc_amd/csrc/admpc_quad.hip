@@ -586,21 +586,28 @@ __global__ __launch_bounds__(64) void admpc_quad_solve_kernel(const Cfg* __restr
 #define QSYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #define QWAVE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-struct QSegLds {      // doubles; per wave: the one-wave kernel's map for 10 stages (gam rows of 64 lanes: the z lanes publish too) + the border rows
+struct QSegLds {      // doubles; per wave.  The linearisation (A, B, b of 10 stages: 18.7 KB) does NOT live here: it waits in the wave's slot of global
+    // memory (L2) and passes through a two-stage buffer in the loops that walk the stages (condensing, expansion) -- with it resident the
+    // kernel fitted one workgroup per CU, without it two.  gam (the Gamma / Phi components of the current stage, rows of 64 lanes: the z lanes
+    // publish too) overlays the factor, which only the interior point writes.
     static constexpr int Ns = 10, n = 40, NB = 14, NR = 54, D = 13, GS = 16;
-    static constexpr int oA = 0, oB = oA + Ns * QX * QX, ob = oB + Ns * QX * QU, oH = ob + Ns * QX, oHb = oH + 820, oL = oHb + NB * n, oLb = oL + 820,
-                         oGam = oLb + NB * n, oVec = oGam + QX * 64, oXnew = oVec + 64, oXbs = oXnew + 144, oYrs = oXbs + 144, oXhs = oYrs + 184,
+    static constexpr int STG = 236;                                    // one stage of the linearisation: A [169], B [52], b [13] (+ 2)
+    static constexpr int SLOT = Ns * 234;                              // doubles per wave in the slot buffer: A [10][169] | B [10][52] | b [10][13]
+    static constexpr int oStg = 0, oH = oStg + 2 * STG, oHb = oH + 820, oL = oHb + NB * n, oLb = oL + 820, oGam = oL,
+                         oEx = oLb + NB * n, oVec = oEx + 192, oXnew = oVec + 64, oXbs = oXnew + 144, oYrs = oXbs + 144, oXhs = oYrs + 184,
                          oWts = oXhs + 16, oWv = oWts + 28, seg = oWv + 16;
+    static_assert(QX * 64 <= 820 + NB * n, "gam overlays L and Lb");
     // interface block of a segment
     static constexpr int IF_SC = 0, IF_HZZ = IF_SC + NB * NB, IF_C = IF_HZZ + D * GS, IF_ZB = IF_C + 16, IF_Z = IF_ZB + 16, IF_DZ = IF_Z + 16,
                          IF_GZ = IF_DZ + 16, IF_RED = IF_GZ + 16, IF_BU = IF_RED + 32, IFS = IF_BU + 16;
     static constexpr int oIF = 2 * seg, oYM = oIF + 2 * IFS, oPI = oYM + 4 * D * GS, oWG = oPI + D * GS, total = oWG + 8;
 };
 
-__global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void admpc_quad_seg_kernel(const Cfg* __restrict__ c, int B, const double* __restrict__ x0g, const double* __restrict__ yrefg,
                                                              const double* __restrict__ yrefeg, double* __restrict__ xbarg, double* __restrict__ ubarg,
                                                              double* __restrict__ costg, int32_t* __restrict__ statusg, int32_t* __restrict__ itersg,
-                                                             int* __restrict__ ticket, const double* __restrict__ gpsg, const int32_t* __restrict__ routeg, int which)
+                                                             int* __restrict__ ticket, const double* __restrict__ gpsg, const int32_t* __restrict__ routeg, int which,
+                                                             double* __restrict__ slotg)
 {
     using LD = QSegLds;
     constexpr int Ns = LD::Ns, n = LD::n, NR = LD::NR, D = LD::D, GS = LD::GS, NT = 2 * Ns;
@@ -610,7 +617,9 @@ __global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restri
     const bool first = wv == 0, last = wv == 1;
     const int k0 = wv * Ns;
     double* const P = lds_raw + wv * LD::seg;
-    double* const A_ = P + LD::oA; double* const B_ = P + LD::oB; double* const b_ = P + LD::ob;
+    double* const stg = P + LD::oStg;                                // [2][236] the stage buffer: A_k, B_k, b_k of the stage a loop works on / the next
+    double* const slot = slotg + ((size_t)blockIdx.x * 2 + wv) * LD::SLOT;      // this wave's linearisation in global memory (L2), rewritten per instance
+    double* const slA = slot; double* const slB = slot + Ns * QX * QX; double* const slb = slB + Ns * QX * QU;
     double* const Hp = P + LD::oH; double* const Hb = P + LD::oHb; double* const Lp = P + LD::oL; double* const Lb = P + LD::oLb;
     double* const gam = P + LD::oGam; double* const vec = P + LD::oVec; double* const xnew = P + LD::oXnew; double* const xbs = P + LD::oXbs;
     double* const yrs = P + LD::oYrs; double* const xhs = P + LD::oXhs; double* const wts = P + LD::oWts; double* const wvec = P + LD::oWv;
@@ -618,7 +627,8 @@ __global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restri
     double* const IFm = ifb + wv * LD::IFS;
     double* const YM = lds_raw + LD::oYM; double* const PI = lds_raw + LD::oPI;
     int* const wgw = reinterpret_cast<int*>(lds_raw + LD::oWG);
-    const Dense40bLds W{Hp, Hb, Lp, Lb, gam, gam + 64};             // exchange buffers / pivots in gam (free after the condensing)
+    double* const ex = P + LD::oEx;                                  // [192] exchange buffers / pivots of the factorisation (cb, invd, second buffer)
+    const Dense40bLds W{Hp, Hb, Lp, Lb, ex, ex + 64};
 #define QRED(s_, ph_, i_) ifb[(s_) * LD::IFS + LD::IF_RED + (ph_) * 8 + (i_)]
     const bool act = lane < n;
     const bool zl = !first && lane >= n && lane < n + D;             // z rows (wave 1); wave 0's lanes 40..52 carry the rows of Bbar
@@ -631,6 +641,19 @@ __global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restri
     const int itmax = c->ipm_iter_max;
     const double inv2n = 1.0 / (2.0 * (double)(NT * QU));
     typedef double d4q __attribute__((ext_vector_type(4)));
+    // stage k of the linearisation from the slot: 234 doubles, four loads per lane, issued a stage ahead of their use
+    auto stage_fetch = [&](const int k, double (&t)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int e = lane + 64 * q; e = e < 234 ? e : 233;
+            const double* src = e < 169 ? slA + k * 169 + e : (e < 221 ? slB + k * 52 + (e - 169) : slb + k * 13 + (e - 221));
+            t[q] = *src;
+        }
+    };
+    auto stage_commit = [&](double* dst, const double (&t)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = lane + 64 * q; if (e < 234) dst[e] = t[q]; }
+    };
 
     int inst = blockIdx.x;
     for (;;) {
@@ -668,9 +691,18 @@ __global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restri
             rk4_col(c, x, u, k + k0 == 0, gq, c->Ts, col, phi, sc);
 #pragma unroll
             for (int i = 0; i < QX; ++i) {
-                if (col < QX) A_[(k * QX + i) * QX + col] = sc[i]; else B_[(k * QX + i) * QU + (col - QX)] = sc[i];
-                if (col == 0) b_[k * QX + i] = phi[i] - xbg[(k + 1) * QX + i];
+                if (col < QX) slA[(k * QX + i) * QX + col] = sc[i]; else slB[(k * QX + i) * QU + (col - QX)] = sc[i];
+                if (col == 0) slb[k * QX + i] = phi[i] - xbg[(k + 1) * QX + i];
             }
+        }
+        // the slot is read back below: the stores have to be out, and the vector L1 may still hold the lines the PREVIOUS instance of this wave
+        // read here (it does not follow the wave's own stores): drop them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        {
+            double t0_[4];
+            stage_fetch(0, t0_);
+            stage_commit(stg, t0_);
         }
         QWAVE();
         // ---- 2. condensing: lane i < 40 carries column i of Gamma_k = d x_k / d U_s, lanes 40..52 of wave 1 the columns of Phi_k = d x_k / d z
@@ -694,23 +726,27 @@ __global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restri
         }
         for (int k = 0; k < Ns; ++k) {
             double gn[QX];
+            const double* Ak = stg + (k & 1) * LD::STG; const double* Bk = Ak + 169; const double* bk = Ak + 221;
+            double tnext[4];
+            if (k + 1 < Ns) stage_fetch(k + 1, tnext);                 // lands under this stage's arithmetic
             const int rr = lane < QX ? lane : 0;
-            double xn = b_[k * QX + rr];
+            double xn = bk[rr];
 #pragma unroll
-            for (int cc = 0; cc < QX; ++cc) xn += A_[(k * QX + rr) * QX + cc] * xhs[cc];
+            for (int cc = 0; cc < QX; ++cc) xn += Ak[rr * QX + cc] * xhs[cc];
             double Ar[3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) { const int e = lane + 64 * m; Ar[m] = A_[k * QX * QX + (e < QX * QX ? e : QX * QX - 1)]; }
+            for (int m = 0; m < 3; ++m) { const int e = lane + 64 * m; Ar[m] = Ak[e < QX * QX ? e : QX * QX - 1]; }
 #pragma unroll
             for (int r = 0; r < QX; ++r) {
                 double sacc = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < QX; ++cc) sacc += bcast(Ar[(r * QX + cc) / 64], (r * QX + cc) % 64) * g[cc];
-                gn[r] = zl ? sacc : (act ? (ji == k ? B_[(k * QX + r) * QU + mi] : (ji < k ? sacc : 0.0)) : 0.0);
+                gn[r] = zl ? sacc : (act ? (ji == k ? Bk[r * QU + mi] : (ji < k ? sacc : 0.0)) : 0.0);
             }
 #pragma unroll
             for (int r = 0; r < QX; ++r) { g[r] = gn[r]; gam[r * 64 + lane] = gn[r]; }
             if (lane < QX) xhs[lane] = xn;
+            if (k + 1 < Ns) stage_commit(stg + ((k + 1) & 1) * LD::STG, tnext);
             QWAVE();
             const bool cost_k = k + 1 < Ns || last;                  // stage k0 + 10 is the next segment's; the horizon's last stage carries the terminal weights
             if (cost_k) {
@@ -917,19 +953,28 @@ __global__ __launch_bounds__(128) void admpc_quad_seg_kernel(const Cfg* __restri
         if (lane < QX) xnew[lane] = xbs[lane] + dx;
         double J = 0.0;
         if (act) { const double e = un - yrg[ji * QY + QX + mi]; J += 0.5 * Rw * e * e; }
+        {
+            double t0_[4];
+            stage_fetch(0, t0_);
+            stage_commit(stg, t0_);
+        }
         QWAVE();
         for (int k = 0; k < Ns; ++k) {
-            if (lane < QX) gam[lane] = dx;
+            const double* Ak = stg + (k & 1) * LD::STG; const double* Bk = Ak + 169; const double* bk = Ak + 221;
+            double tnext[4];
+            if (k + 1 < Ns) stage_fetch(k + 1, tnext);
+            if (lane < QX) ex[lane] = dx;
             QWAVE();
             double dn = 0.0;
             if (lane < QX) {
-                dn = b_[k * QX + lane];
-                for (int cc = 0; cc < QX; ++cc) dn += A_[(k * QX + lane) * QX + cc] * gam[cc];
-                for (int m = 0; m < QU; ++m) dn += B_[(k * QX + lane) * QU + m] * vec[k * QU + m];
+                dn = bk[lane];
+                for (int cc = 0; cc < QX; ++cc) dn += Ak[lane * QX + cc] * ex[cc];
+                for (int m = 0; m < QU; ++m) dn += Bk[lane * QU + m] * vec[k * QU + m];
                 const double xv = xbs[(k + 1) * QX + lane] + dn;
                 xnew[(k + 1) * QX + lane] = xv;
                 if (!(fabs(xv) <= 1e300)) bad = true;
             }
+            if (k + 1 < Ns) stage_commit(stg + ((k + 1) & 1) * LD::STG, tnext);
             QWAVE();
             dx = dn;
         }
@@ -1331,6 +1376,7 @@ struct AdmpcQuadSolver {
     int* d_ticket;           // work counter of the solve kernel
     int device, num_cu, lds_bytes;
     int generic;             // ADMPC_QUAD_GENERIC=1: the LDS-resident Cholesky path also at N nu = 40 (A/B tests)
+    double* d_slot;          // segmented N = 20 kernel: the linearisation of every resident wave (QSegLds::SLOT doubles each), allocated at its first launch
     int wide20;              // ADMPC_QUAD_WIDE=1: N = 20 on the two-wave dense kernel of round 3 instead of the segmented kernel (A/B tests)
     // SQP mode (cfg.sqp_iters > 1), allocated at its first solve: two linearisations (the last QP's and the iterate's), activity flags
     int cap_sqp;
@@ -1394,6 +1440,7 @@ int admpc_quad_create(const AdmpcQuadConfig* cfg, int device, AdmpcQuadSolver** 
     AdmpcQuadSolver* s = new (std::nothrow) AdmpcQuadSolver();
     if (!s) return admpc_set_error(ADMPC_ENOMEM, "out of host memory");
     s->cfg = *cfg; s->device = device; s->d_cfg = nullptr; s->d_ticket = nullptr;
+    s->d_slot = nullptr;
     s->cap_sqp = 0; s->d_A[0] = s->d_A[1] = s->d_B[0] = s->d_B[1] = s->d_phi = nullptr; s->d_act = s->d_fst = s->d_st = nullptr;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return admpc_set_error(ADMPC_EHIP, "hipGetDeviceProperties failed"); }
@@ -1422,6 +1469,7 @@ void admpc_quad_destroy(AdmpcQuadSolver* s)
     QGuard guard(s->device);
     if (s->d_cfg) (void)hipFree(s->d_cfg);
     if (s->d_ticket) (void)hipFree(s->d_ticket);
+    if (s->d_slot) (void)hipFree(s->d_slot);
     for (int i = 0; i < 2; ++i) { if (s->d_A[i]) (void)hipFree(s->d_A[i]); if (s->d_B[i]) (void)hipFree(s->d_B[i]); }
     if (s->d_phi) (void)hipFree(s->d_phi);
     if (s->d_act) (void)hipFree(s->d_act);
@@ -1439,8 +1487,11 @@ static int quad_solve(AdmpcQuadSolver* s, int B, const double* x0, const double*
     int grid = s->num_cu * per_cu; if (grid > B) grid = B;
     int* ticket = B > 8 * grid ? s->d_ticket : nullptr;
     if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), st) != hipSuccess) return admpc_set_error(ADMPC_EHIP, "hipMemsetAsync failed");
-    if (seg20)
-        hipLaunchKernelGGL(admpc_quad_seg_kernel, dim3(grid), dim3(128), ldsb, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
+    if (seg20) {
+        if (!s->d_slot && hipMalloc((void**)&s->d_slot, (size_t)s->num_cu * 4 * 2 * QSegLds::SLOT * sizeof(double)) != hipSuccess)
+            return admpc_set_error(ADMPC_EHIP, "quad: slot buffer allocation failed");
+        hipLaunchKernelGGL(admpc_quad_seg_kernel, dim3(grid), dim3(128), ldsb, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which, s->d_slot);
+    }
     else if (s->cfg.N * QU > 64)          // horizons beyond 16: one thread per input, two waves per instance
         hipLaunchKernelGGL(admpc_quad_solve_wide_kernel, dim3(grid), dim3(QW_NT), s->lds_bytes, st, s->d_cfg, B, x0, yref, yref_e, xbar, ubar, cost, status, iters, ticket, gp_state, route, which);
     else if (s->cfg.N * QU == 40 && !s->generic)
