@@ -1554,7 +1554,10 @@ static int ensure_dense(AdmpcSolver* s, int B)                  // four-kernel N
 static int ensure_fused(AdmpcSolver* s, int B)                  // fused N = 20 step: one slot buffer per resident wave, the work-order lists
 {                                                                // (segmented kernel: the work-order lists only)
     // slot buffers only where parking the linearisation beats recomputing it: with GP residuals in the model (see admpc_fused20.hip)
-    if (!s->d_slot && s->cfg.n_gp > 0 && !s->use_seg) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
+    // (ADMPC_F20_PARK=1 / 0 forces / forbids the slot buffers whatever the model: A/B runs)
+    const char* pk = getenv("ADMPC_F20_PARK");
+    const bool park = pk ? pk[0] == '1' : s->cfg.n_gp > 0;
+    if (!s->d_slot && park && !s->use_seg) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_fused20_slot_doubles(s->num_cu) * sizeof(double)));
     // segmented kernel: one packed Hessian per resident wave (its LDS buffer doubles as the factor's)
     if (!s->d_slot && s->use_seg) HIPCHK(hipMalloc((void**)&s->d_slot, admpc_seg_slot_doubles(s->num_cu) * sizeof(double)));
     if (B <= s->cap_fused) return ADMPC_OK;

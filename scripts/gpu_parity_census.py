@@ -54,7 +54,7 @@ from ad_mpc_amd.quad_config import default_quad_config
 from ad_mpc_amd.quad_scenarios import random_quad_scenarios
 from ad_mpc_amd.engine import QuadBatchSolver
 qo = QuadOracle()
-for N, B in ((10, 4096), (5, 1024), (16, 1024), (20, 256)):
+for N, B in ((10, 4096), (5, 1024), (16, 1024), (20, 2048), (24, 128)):      # N = 20: the segmented two-wave kernel (round 4); 24: the dense two-wave kernel
     qc = default_quad_config(); qc.N = N
     qe = QuadBatchSolver(qc)
     n = 0; bad = 0; itoff = 0; du = 0.0; dx = 0.0; mx = 0

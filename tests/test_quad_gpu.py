@@ -349,3 +349,34 @@ def test_quad_sqp_mode_on_the_device(qoracle):
     assert rti.cfg.sqp_iters == 1
     with pytest.raises(ValueError):
         Quad3DOptimizer(solver_options={"solver_type": "DDP", "terminal_cost": False})
+
+
+def test_quad_segmented_kernel_at_the_class_default_horizon(qoracle, monkeypatch):
+    """N = 20 (quad_3d_optimizer.py:28) runs on admpc_quad_seg_kernel: two cooperating waves per instance.  Beyond the parity cases above: a batch
+    large enough for the work counter (B > 8 x the grid), a non-finite instance (status 4, iterate untouched, its neighbours unaffected), bit-wise
+    repeatability, a routed mask, and agreement with the dense two-wave kernel of round 3 (ADMPC_QUAD_WIDE=1) on the same inputs."""
+    from ad_mpc_amd.engine import QuadBatchSolver
+    cfg = default_quad_config(N=20, t_horizon=2.0)
+    B = 5000
+    s = random_quad_scenarios(B, cfg, seed=77)
+    s["x0"][123, 8] = np.nan
+    eng = QuadBatchSolver(cfg, device=0)
+    g = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    o = qoracle.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"], nthreads=16)
+    np.testing.assert_array_equal(g[3], o[3]); assert g[3][123] == 4 and (np.delete(g[3], 123) == 0).all() and np.isinf(g[2][123])
+    np.testing.assert_array_equal(g[0][123], s["xbar"][123]); np.testing.assert_array_equal(g[1][123], s["ubar"][123])
+    ok = o[3] == 0
+    np.testing.assert_array_equal(g[4][ok], o[4][ok])
+    assert np.abs(g[1][ok] - o[1][ok]).max() <= 1e-8 and np.abs(g[0][ok] - o[0][ok]).max() <= 1e-8
+    np.testing.assert_allclose(g[2][ok], o[2][ok], rtol=1e-9)
+    g2 = eng.solve_numpy(s["x0"], s["yref"], s["yref_e"], s["xbar"], s["ubar"])
+    for a, b in zip(g, g2):
+        np.testing.assert_array_equal(a, b)
+    eng.close()
+    monkeypatch.setenv("ADMPC_QUAD_WIDE", "1")
+    sub = {k: v[:96] for k, v in s.items()}
+    ew = QuadBatchSolver(cfg, device=0)
+    gw = ew.solve_numpy(sub["x0"], sub["yref"], sub["yref_e"], sub["xbar"], sub["ubar"])
+    ew.close()
+    np.testing.assert_array_equal(gw[4], g[4][:96])
+    assert np.abs(gw[1] - g[1][:96]).max() <= 1e-8 and (gw[1] != g[1][:96]).any()          # another kernel, another elimination order: close, not bit-equal
