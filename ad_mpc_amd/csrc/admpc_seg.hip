@@ -39,6 +39,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #include "dense40.h"
 #include "cond_common.h"
 #include "work_order.h"
+#include "seg_cut.h"          // bordered factorisation, Schur blocks, the operators of a single cut: shared with the quadrotor's segmented kernel
 
 #define LDG(p) (*(p))
 #define STG(p, v) (*(p) = (v))
@@ -143,60 +144,11 @@ struct SegLds {
     static constexpr int total = oYM + (S == 2 ? 4 * 56 : 0);
 };
 
-// ---- 7 x 7 blocks of the interface recursion (wave 0).  Matrices live in LDS, row-major with stride 8; "lane = column": lane c holds
-// column c of a matrix (or a right-hand side) in seven registers.
-struct Col7 { double v[7]; };
-
-// out = A * col (A[r][k] at A + r * sa + k * ka: uniform LDS reads)
-__device__ __forceinline__ Col7 mat_col(const double* A, const int sa, const int ka, const Col7& x) {
-    Col7 o;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) a = fma(A[r * sa + k * ka], x.v[k], a);
-        o.v[r] = a;
-    }
-    return o;
-}
-
-// Gaussian elimination with partial pivoting: lanes 0..6 hold the columns of a 7 x 7 matrix, any other lane a right-hand side; on return
-// every right-hand-side lane holds its solution.  Row operations are lane-parallel; pivots and multipliers are wave-uniform (v_readlane).
-__device__ __forceinline__ void ge7_solve(Col7& c) {
-    static_for<0, 7>([&](auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        double best = fabs(rdlane(c.v[p], p));
-        int bi = p;
-        static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
-            constexpr int r = decltype(rc)::value;
-            const double v = fabs(rdlane(c.v[r], p));
-            if (v > best) { best = v; bi = r; }
-        });
-        // the row exchange as selects (a uniform condition each): written as conditional swaps hipcc turns the seven registers into a
-        // dynamically indexed array in scratch
-        static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
-            constexpr int r = decltype(rc)::value;
-            const bool sw = bi == r;
-            const double vp = c.v[p], vr = c.v[r];
-            c.v[p] = sw ? vr : vp; c.v[r] = sw ? vp : vr;
-        });
-        const double pinv = rcp_nr(rdlane(c.v[p], p));
-        static_for<p + 1, 7>([&](auto rc) __attribute__((always_inline)) {
-            constexpr int r = decltype(rc)::value;
-            const double m = rdlane(c.v[r], p) * pinv;
-            c.v[r] = fma(-m, c.v[p], c.v[r]);
-        });
-    });
-    static_for<0, 7>([&](auto qc) __attribute__((always_inline)) {
-        constexpr int r = 6 - decltype(qc)::value;
-        double a = c.v[r];
-        static_for<r + 1, 7>([&](auto cc) __attribute__((always_inline)) {
-            constexpr int k = decltype(cc)::value;
-            a = fma(-rdlane(c.v[r], k), c.v[k], a);
-        });
-        c.v[r] = a * rcp_nr(rdlane(c.v[r], r));
-    });
-}
+// ---- 7 x 7 blocks of the interface recursion (wave 0): seg_cut.h's column type, product and elimination with D = 7.  Matrices live in LDS,
+// row-major; "lane = column": lane c holds column c of a matrix (or a right-hand side) in seven registers.
+typedef ColD<7> Col7;
+__device__ __forceinline__ Col7 mat_col(const double* A, const int sa, const int /*ka = 1*/, const Col7& x) { return cut_mat_col<7>(A, sa, x); }
+__device__ __forceinline__ void ge7_solve(Col7& c) { cut_ge_solve<7>(c); }
 
 // The coupling of the S segments (wave 0, between two workgroup barriers).  Per segment s, from its interface block:
 //   Pzz_s = Hzz_s + e6 e6' sum(G56) - Sc_zz,  Pzb_s = Sc_zb,  Pbb_s = Sc_bb,  Ahat_s = Abar_s - Pzb_s',
@@ -313,47 +265,12 @@ __device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const 
     }
 }
 
-// Two segments, one cut: the coupling has a closed form in four 7 x 7 operators that depend on the factorisation only, so they are built
-// ONCE per interior-point iteration (wave 0, while wave 1 already runs its forward substitution) and each right-hand side costs a wave
-// fourteen multiply-adds per lane.  With  Pi = Hzz_1 + e6 e6' sum(G56) - (Qzu M^-1 Quz)_1,  Pbb = (Bbar M^-1 Bbar')_0,
-// Lambda = I + Pbb Pi,  dhat = -zb_0,  eta = zb_1:
-//     dz_1 = Lambda^-1 (dhat + Pbb eta) = Y1 dhat + Y2 eta,      nu_1 = eta - Pi dz_1 = Y3 dhat + Y4 eta
-//     Y1 = Lambda^-1,  Y2 = Lambda^-1 Pbb,  Y3 = -Pi Y1,  Y4 = I - Pi Y2
-// Lanes 0..6 hold the columns of Lambda, lanes 8..14 those of Pbb, lanes 16..22 those of I: one elimination (partial pivoting).
+// Two segments, one cut: the coupling has a closed form in four 7 x 7 operators that depend on the factorisation only (seg_cut.h:
+// cut_operators2 / cut_apply2), built ONCE per interior-point iteration by wave 0 while wave 1 already runs its forward substitution.
 __device__ __forceinline__ void interface_factor2(double* __restrict__ ifb, double* __restrict__ YM, const int lane) {
     using LD = SegLds<2>;
-    double* F0 = ifb;
     double* F1 = ifb + LD::IFS;
-    const int cl = lane & 7;
-    const int c7 = cl < 7 ? cl : 0;
-    const int grp = lane >> 3;                                     // 0: Lambda, 1: Pbb, 2: I
-    Col7 pi;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) pi.v[r] = F1[LD::IF_HZZ + r * 8 + c7] + ((r == 6 && c7 == 6) ? F1[LD::IF_G56] : 0.0) - F1[LD::IF_SC + r * LD::SCS + c7];
-    if (lane < 7) {
-#pragma unroll
-        for (int r = 0; r < 7; ++r) F1[LD::IF_PI + r * 8 + lane] = pi.v[r];
-    }
-    Col7 T = mat_col(F0 + LD::IF_SC, LD::SCS, 1, pi);                    // Pbb Pi[:, c]
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        const double pb = F0[LD::IF_SC + r * LD::SCS + c7];
-        const double id = r == c7 ? 1.0 : 0.0;
-        T.v[r] = grp == 0 ? T.v[r] + id : (grp == 1 ? pb : id);
-    }
-    ge7_solve(T);                                                  // lanes 8..14: columns of Y2, lanes 16..22: columns of Y1
-    WSYNC();                                                       // Pi is in LDS
-    Col7 P = mat_col(F1 + LD::IF_PI, 8, 1, T);                      // Pi X
-    const bool isx = (grp == 1 || grp == 2) && cl < 7;
-    if (isx) {
-        double* Ya = YM + (grp == 2 ? 0 : 56);                      // Y1 / Y2
-        double* Yb = YM + (grp == 2 ? 2 * 56 : 3 * 56);             // Y3 / Y4
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            Ya[r * 8 + cl] = T.v[r];
-            Yb[r * 8 + cl] = grp == 2 ? -P.v[r] : (r == cl ? 1.0 : 0.0) - P.v[r];
-        }
-    }
+    cut_operators2<7, 8>(ifb + LD::IF_SC, LD::SCS, F1 + LD::IF_HZZ, 8, F1[LD::IF_G56], 6, F1 + LD::IF_SC, LD::SCS, F1 + LD::IF_PI, YM, lane);
 }
 
 template <int S, int QMASK>
@@ -414,84 +331,24 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 
     // Factorisation of the bordered Newton matrix: M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) = L D L' with the
     // border rows (lanes 40 .. NR-1: Hb, plus the delta-box barrier on the z6 row when zbar) riding along -> Lb = C L^-T D^-1.
+    const Dense40bLds W{Hp, Hb, Lp, Lb, cb, invd};
     auto factorise = [&](const double dbar_, const double sodd_, const int lz_, const bool zbar, const double h_) __attribute__((always_inline)) {
-        double a[n];
-        newton_row_40_b<NR>(a, row_addr(Hp, Hb, lz_), dbar_, sodd_);
-        // H's rows are in registers: its buffer becomes the factor's.  Diagonal slots of the packed factor: 0.0 (the factorisation stores the
-        // strictly-lower part only; the substitution assembly lets the source lane of a step take part with this multiplier)
-        if (lz_ < n) Lp[lz_ * (lz_ + 1) / 2 + lz_] = 0.0;
-        if (zbar) {
-            // row z6 (lane 46) of Qzu: + h * (sum of the barrier ratios of the stages behind the column's stage), odd columns; sb2[k] holds that sum
-            const double hz = lz_ == 46 ? h_ : 0.0;
-            static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
-                constexpr int k = decltype(kc)::value;
-                a[2 * k + 1] = fma(hz, sb2[k], a[2 * k + 1]);
-            });
-        }
-        const unsigned lrow = row_addr(Lp, Lb, lz_);
-        const unsigned pub_wr = lds_byte_addr(cb + lz_), pub_rd = lds_byte_addr(cb + (lz_ & 15));
-        auto chain = [&](auto jc, double& nln) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            const double dj = rdlane(a[j], j);
-            const double dinv = rcp_nr(dj);
-            const double lu = a[j] * dinv;
-            invd[j] = dinv;
-            asm volatile("s_bfm_b64 exec, %2, %3\n\tds_write_b64 %0, %1 offset:%4\n\ts_mov_b64 exec, -1"
-                         : : "v"(lrow), "v"(lu), "n"(NR - 1 - j), "n"(j + 1), "n"(8 * j) : "memory");
-            nln = -lu;
-        };
-        double Rb[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, nlb[2] = {0.0, 0.0};
-        cb[lz_] = a[0];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) Rb[0][m] = cb[16 * m + (lz_ & 15)];
-        chain(std::integral_constant<int, 0>{}, nlb[0]);
-        static_for<0, n - 1>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            // NR = 47: every row beyond the columns sits in the third 16-lane row -- the schedule of the 40-row factorisation (columns
-            // j >= 31 come from the lanes' own registers); NR = 54: rows in the fourth 16-lane row need every column through LDS
-            constexpr bool wide = NR > 48;
-            constexpr bool own = !wide && (j + 1) / 16 == 2;
-            constexpr bool pub = wide ? (j + 2 < n) : (j + 2 < n && (j + 2) / 16 < 2);
-            constexpr int mlo = (j + 2) / 16 < 2 ? (j + 2) / 16 : 2;
-            double (&R)[3] = Rb[j & 1];
-            double (&Rn)[3] = Rb[(j + 1) & 1];
-            double& nl = nlb[j & 1];
-            double& nln = nlb[(j + 1) & 1];
-            col_head<j + 1, mlo, pub, own>(a[j + 1], R, nl, Rn, pub_wr, pub_rd);
-            if constexpr (!pub) Rn[2] = a[j + 1];
-            chain(std::integral_constant<int, j + 1>{}, nln);
-            constexpr int j4 = ((j + 2 + 3) / 4) * 4 < n ? ((j + 2 + 3) / 4) * 4 : n;
-            static_for<j + 2, j4>([&](auto c) __attribute__((always_inline)) {
-                constexpr int jj = decltype(c)::value;
-                if constexpr (own) fmac_rowbc<jj % 16>(a[jj], R[jj / 16], nl);
-                else fmac_rowbc_ld<jj % 16>(a[jj], R[jj / 16], nl);
-            });
-            static_for<j4 / 4, n / 4>([&](auto c) __attribute__((always_inline)) {
-                constexpr int jj = 4 * decltype(c)::value;
-                if constexpr (own) fmac_rowbc4<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
-                else fmac_rowbc4_ld<jj % 16>(a[jj], a[jj + 1], a[jj + 2], a[jj + 3], R[jj / 16], nl);
-            });
+        dense40b_factorise<NR>(W, dbar_, lz_, sodd_, [&](double (&a)[n]) __attribute__((always_inline)) {
+            // H's rows are in registers: its buffer becomes the factor's.  Diagonal slots of the packed factor: 0.0 (the factorisation stores the
+            // strictly-lower part only; the substitution assembly lets the source lane of a step take part with this multiplier)
+            if (lz_ < n) Lp[lz_ * (lz_ + 1) / 2 + lz_] = 0.0;
+            if (zbar) {
+                // row z6 (lane 46) of Qzu: + h * (sum of the barrier ratios of the stages behind the column's stage), odd columns; sb2[k] holds that sum
+                const double hz = lz_ == 46 ? h_ : 0.0;
+                static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    a[2 * k + 1] = fma(hz, sb2[k], a[2 * k + 1]);
+                });
+            }
         });
-        WSYNC();
     };
-    // Schur blocks of the border: Sc = Lb D Lb' (NB x NB) in ten v_mfma_f64_16x16x4_f64: A[i][k] = Lb[i][c] d_c, B[k][j] = Lb[j][c], c = 4 t + k
-    auto schur = [&](const int lane) __attribute__((always_inline)) {
-        const int r16 = lane & 15, kq = lane >> 4;
-        const int rb = r16 < NB ? r16 : 0;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            const int c = 4 * t + kq;
-            const double lb = Lb[rb * n + c];
-            const double dc = rcp_nr(invd[c]);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb * dc, lb, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int i = kq + 4 * v;                             // C/D layout of the 16 x 16 x 4 tile: register v of lane (kq, r16) is element (kq + 4 v, r16)
-            if (i < NB && r16 < NB) IFm[LD::IF_SC + i * LD::SCS + r16] = acc[v];
-        }
-    };
+    // Schur blocks of the border: Sc = Lb D Lb' (NB x NB) in ten v_mfma_f64_16x16x4_f64 (seg_cut.h)
+    auto schur = [&](const int lane) __attribute__((always_inline)) { dense40b_schur<NB>(W, IFm + LD::IF_SC, LD::SCS, lane); };
     // The coupled Newton solve for one right-hand side: y on the input lanes, the reduced stationarity of z_s on the z lanes (0 on
     // the Bbar lanes).  Returns the step of this lane's input; dz_s / nu_{s+1} are in the interface blocks afterwards.
     auto coupled_solve = [&](double y, const int lz_) __attribute__((always_inline)) -> double {
@@ -504,12 +361,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         if constexpr (S == 2) {
             // one cut: both waves apply the operators of interface_factor2 to (dhat, eta) themselves -- wave 0 needs nu_1 (its border rows
             // are Bbar: unknown -nu_1), wave 1 needs dz_1 (its border rows are the z rows)
-            const int r7 = lz_ < 7 ? lz_ : 0;
-            const double* Ya = YM + (first ? 2 * 56 : 0) + r7 * 8;
-            const double* Yb = Ya + 56;
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) a = fma(Yb[k], ifb[LD::IFS + LD::IF_ZB + k], fma(-Ya[k], ifb[LD::IF_ZB + k], a));
+            const double a = cut_apply2<7, 8>(YM, first, ifb + LD::IF_ZB, ifb + LD::IFS + LD::IF_ZB, lz_);
             if (lz_ < 7) { wvec[lz_] = first ? -a : a; if (!first) IFm[LD::IF_DZ + lz_] = a; }
             SEG_STAMP(7);
         } else {

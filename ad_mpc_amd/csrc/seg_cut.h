@@ -1,5 +1,5 @@
-// seg_cut.h -- the coupling of TWO condensed segments through the D states at their cut (D = 7: the car, admpc_seg.hip carries its own copy of
-// this text with D fixed; D = 13: the quadrotor, admpc_quad.hip), and the bordered 40 x 40 factorisation both build on (dense40.h).
+// seg_cut.h -- the coupling of TWO condensed segments through the D states at their cut (D = 7: the car, admpc_seg.hip; D = 13: the quadrotor,
+// admpc_quad.hip), and the bordered 40 x 40 factorisation both build on (dense40.h): ONE text for both vehicle models.
 // Mathematics and notation: DESIGN.md section 4, kernel S; tests/seg_spec.py.  Include inside the translation unit's anonymous namespace after
 // dense40.h.
 //
@@ -113,7 +113,7 @@ __device__ __forceinline__ double cut_apply2(const double* Y, const bool first, 
     return a;
 }
 
-// ---- the bordered 40 x 40 factorisation as a function (the car's segmented kernel carries the same text as a lambda over its own LDS names):
+// ---- the bordered 40 x 40 factorisation:
 // M = H + diag(dbar) = L D L' with row i in the registers of lane i and the NR - 40 border rows (full rows of Hb, lanes 40 .. NR-1) riding
 // along: Lb = C L^-T D^-1.  LDS: Hp / Lp packed lower rows [820] (the diagonal slots of Lp hold 0.0), Hb / Lb [NR - 40][40], cb: exchange
 // buffers in the layout col_head assumes (cb [64], invd [64] = 1 / D_jj, second buffer at cb + 128).
@@ -122,12 +122,16 @@ template <int NR>
 __device__ __forceinline__ unsigned dense40b_row_addr(double* tri_, double* brd, const int lz_) {
     return lds_byte_addr(lz_ < 40 ? tri_ + lz_ * (lz_ + 1) / 2 : (lz_ < NR ? brd + (lz_ - 40) * 40 : tri_));
 }
-template <int NR>
-__device__ __forceinline__ void dense40b_factorise(const Dense40bLds& W, const double dbar_, const int lz_)
+struct Dense40bNoFix { __device__ __forceinline__ void operator()(double (&)[40]) const {} };
+// fix(a): hook behind the row build (the rows are in registers, H's buffer is free): the car's kernel zeroes the factor's diagonal slots there
+// (H and L share one buffer) and adds the steering-box barrier to the z6 border row; s_odd: added to the odd columns of this lane's row
+template <int NR, class Fix = Dense40bNoFix>
+__device__ __forceinline__ void dense40b_factorise(const Dense40bLds& W, const double dbar_, const int lz_, const double sodd_ = 0.0, const Fix& fix = Fix())
 {
     constexpr int n = 40;
     double a[n];
-    newton_row_40_b<NR>(a, dense40b_row_addr<NR>(W.Hp, W.Hb, lz_), dbar_, 0.0);
+    newton_row_40_b<NR>(a, dense40b_row_addr<NR>(W.Hp, W.Hb, lz_), dbar_, sodd_);
+    fix(a);
     const unsigned lrow = dense40b_row_addr<NR>(W.Lp, W.Lb, lz_);
     const unsigned pub_wr = lds_byte_addr(W.cb + lz_), pub_rd = lds_byte_addr(W.cb + (lz_ & 15));
     double* const invd = W.invd;
