@@ -135,10 +135,10 @@ struct SegLds {
     static constexpr int IF_PI = IF_BU + 8;                            // [7][8]   Pi_s (backward recursion over the cuts)
     static constexpr int IF_G56 = IF_PI + 56;                          // [2]      sum of the delta-box barrier ratios of the segment
     static constexpr int IF_ABAR = IF_G56 + 2;                         // [7][8]   Abar_s = Phi at the segment's end            (S > 2)
-    static constexpr int IF_ETA = IF_ABAR + (S > 2 ? 56 : 0);          // [8]                                                    (S > 2)
-    static constexpr int IF_X = IF_ETA + (S > 2 ? 8 : 0);              // [7][8]   Lambda_s^-1 Ahat_s                           (S > 2)
-    static constexpr int IF_XR = IF_X + (S > 2 ? 56 : 0);              // [8]      Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1})       (S > 2)
-    static constexpr int IFS = IF_XR + (S > 2 ? 8 : 0);
+    static constexpr int IF_X = IF_ABAR + (S > 2 ? 56 : 0);            // [7][8]   X_s = Lambda_s^-1 Ahat_s                     (S > 2)
+    static constexpr int IF_AH = IF_X + (S > 2 ? 56 : 0);              // [7][8]   Ahat_s = Abar_s - Pzb_s'                     (S > 2)
+    static constexpr int IF_WI = IF_AH + (S > 2 ? 56 : 0);             // [7][8]   Wi_s = Lambda_s^-1                           (S > 2)
+    static constexpr int IFS = IF_WI + (S > 2 ? 56 : 0);
     static constexpr int oIF = S * seg, oWG = oIF + S * IFS;
     static constexpr int oYM = oWG + 8;                                // [4][7][8] solution operators of the single cut (S = 2)
     static constexpr int total = oYM + (S == 2 ? 4 * 56 : 0);
@@ -150,119 +150,107 @@ typedef ColD<7> Col7;
 __device__ __forceinline__ Col7 mat_col(const double* A, const int sa, const int /*ka = 1*/, const Col7& x) { return cut_mat_col<7>(A, sa, x); }
 __device__ __forceinline__ void ge7_solve(Col7& c) { cut_ge_solve<7>(c); }
 
-// The coupling of the S segments (wave 0, between two workgroup barriers).  Per segment s, from its interface block:
+// The coupling of the S segments through their S - 1 cuts.  Per segment s, from its interface block:
 //   Pzz_s = Hzz_s + e6 e6' sum(G56) - Sc_zz,  Pzb_s = Sc_zb,  Pbb_s = Sc_bb,  Ahat_s = Abar_s - Pzb_s',
 //   yhat_s = zb[z rows] (reduced stationarity of z_s),  dhat_s = -zb[Bbar rows]
 // Backward over the cuts:  nu_s = eta_s - Pi_s dz_s  with  Pi_{S-1} = Pzz, eta_{S-1} = yhat;  Lambda_s = I + Pbb_s Pi_{s+1},
 //   Pi_s = Pzz_s + Ahat_s' Pi_{s+1} Lambda_s^-1 Ahat_s,   eta_s = yhat_s + Ahat_s' (eta_{s+1} - Pi_{s+1} Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1}))
 // Forward:  dz_{s+1} = Lambda_s^-1 (Ahat_s dz_s + dhat_s + Pbb_s eta_{s+1}),  nu_{s+1} = eta_{s+1} - Pi_{s+1} dz_{s+1}.
-// (tests/seg_spec.py: newton()).  Matrices and vectors are recomputed in both solves of an iteration: the blocks are tiny.
+// (tests/seg_spec.py: newton()).  What depends on the factorisation only -- Pi_s, Ahat_s, X_s = Lambda_s^-1 Ahat_s, Wi_s = Lambda_s^-1 -- is built ONCE
+// per interior-point iteration by wave 0 (interface_factor, while the other waves run their forward substitutions); every right-hand side then
+// needs matrix-vector products only, which every wave runs for itself in registers (interface_apply: no barrier, the same bits in every wave).
 template <int S>
-__device__ __forceinline__ void interface_solve(double* __restrict__ ifb, const int lane) {
+__device__ __forceinline__ void interface_factor(double* __restrict__ ifb, const int lane) {
     using LD = SegLds<S>;
     const int l49 = lane < 49 ? lane : 48;
-    const int er = div7(l49), ec = l49 - 7 * er;                    // element (er, ec) for the element-wise steps
-    const int c7 = lane < 7 ? lane : 0;
-    // ---- the last segment: Pi = Pzz, eta = yhat
-    {
+    const int er = div7(l49), ec = l49 - 7 * er;                    // element (er, ec) for the element-wise step
+    const int grp = lane >> 3, cl = lane & 7, c7 = cl < 7 ? cl : 0;  // groups of eight lanes: 0 = columns of Lambda, 1 = of Ahat, 2 = of I
+    const bool keep = cl < 7;
+    {                                                               // the last segment: Pi = Pzz
         double* F = ifb + (S - 1) * LD::IFS;
         const double v = F[LD::IF_HZZ + er * 8 + ec] + ((er == 6 && ec == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + er * LD::SCS + ec];
         if (lane < 49) F[LD::IF_PI + er * 8 + ec] = v;
-        if (lane < 7) F[LD::IF_ETA + lane] = F[LD::IF_ZB + lane];
     }
     WSYNC();
-    // ---- middle segments, backward
 #pragma unroll 1
-    for (int s = S - 2; s >= 1; --s) {
+    for (int s = S - 2; s >= 0; --s) {
         double* F = ifb + s * LD::IFS;
         const double* Fn = ifb + (s + 1) * LD::IFS;
-        const double* Pbb = F + LD::IF_SC + 7 * LD::SCS + 7;            // [r * 14 + c]
-        // lanes 0..6: columns of Pi_{s+1}; lane 7: eta_{s+1}; lanes 8..14: columns of Ahat_s (right-hand sides as they are)
+        const bool mid = s > 0;                                    // segment 0 has no z rows: its border rows 0..6 are Bbar, and nothing in front of it
+        const double* Pbb = F + LD::IF_SC + (mid ? 7 * LD::SCS + 7 : 0);
         Col7 col;
-        const int ac = (lane >= 8 && lane < 15) ? lane - 8 : 0;
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const double pv = Fn[LD::IF_PI + r * 8 + c7], ev = Fn[LD::IF_ETA + r];
-            col.v[r] = lane < 7 ? pv : ev;
-        }
+        for (int r = 0; r < 7; ++r) col.v[r] = Fn[LD::IF_PI + r * 8 + c7];
         Col7 T = mat_col(Pbb, LD::SCS, 1, col);
+        Col7 ah;
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
-            const double ah = F[LD::IF_ABAR + r * 8 + ac] - F[LD::IF_SC + ac * LD::SCS + 7 + r];      // Ahat[r][ac] = Abar[r][ac] - Pzb[ac][r]
-            const double dh = -F[LD::IF_ZB + 7 + r];
-            T.v[r] = lane < 7 ? T.v[r] + (r == lane ? 1.0 : 0.0) : (lane == 7 ? T.v[r] + dh : ah);
+            ah.v[r] = mid ? F[LD::IF_ABAR + r * 8 + c7] - F[LD::IF_SC + c7 * LD::SCS + 7 + r] : 0.0;      // Ahat[r][c] = Abar[r][c] - Pzb[c][r]
+            const double id = r == c7 ? 1.0 : 0.0;
+            T.v[r] = grp == 0 ? T.v[r] + id : (grp == 1 ? ah.v[r] : id);
         }
-        ge7_solve(T);                                              // lane 7: xr; lanes 8..14: columns of X = Lambda^-1 Ahat
-        if (lane == 7) {
+        ge7_solve(T);                                              // group 1: columns of X = Lambda^-1 Ahat, group 2: of Wi = Lambda^-1
+        if (grp == 2 && keep) {
 #pragma unroll
-            for (int r = 0; r < 7; ++r) F[LD::IF_XR + r] = T.v[r];
+            for (int r = 0; r < 7; ++r) F[LD::IF_WI + r * 8 + cl] = T.v[r];
         }
-        if (lane >= 8 && lane < 15) {
+        if (!mid) break;
+        if (grp == 1 && keep) {
 #pragma unroll
-            for (int r = 0; r < 7; ++r) F[LD::IF_X + r * 8 + ac] = T.v[r];
+            for (int r = 0; r < 7; ++r) { F[LD::IF_X + r * 8 + cl] = T.v[r]; F[LD::IF_AH + r * 8 + cl] = ah.v[r]; }
         }
-        // Y = Pi_{s+1} v  (lane 7: eta_{s+1} - Pi_{s+1} xr), Z = Ahat' Y
-        Col7 Y = mat_col(Fn + LD::IF_PI, 8, 1, T);
+        WSYNC();                                                   // Ahat is read back transposed below
+        Col7 Y = mat_col(Fn + LD::IF_PI, 8, 1, T);                 // group 1: Pi_{s+1} X
+        if (grp == 1 && keep) {
 #pragma unroll
-        for (int r = 0; r < 7; ++r) Y.v[r] = lane == 7 ? Fn[LD::IF_ETA + r] - Y.v[r] : Y.v[r];
-        Col7 Z;
+            for (int r = 0; r < 7; ++r) {
+                double a = F[LD::IF_HZZ + r * 8 + cl] + ((r == 6 && cl == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + r * LD::SCS + cl];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k], Y.v[k], a);      // Ahat[k][r]
-            Z.v[r] = a;
-        }
-        WSYNC();
-        if (lane == 7) {
-#pragma unroll
-            for (int r = 0; r < 7; ++r) F[LD::IF_ETA + r] = F[LD::IF_ZB + r] + Z.v[r];
-        }
-        if (lane >= 8 && lane < 15) {
-#pragma unroll
-            for (int r = 0; r < 7; ++r)
-                F[LD::IF_PI + r * 8 + ac] = F[LD::IF_HZZ + r * 8 + ac] + ((r == 6 && ac == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + r * LD::SCS + ac] + Z.v[r];
+                for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_AH + k * 8 + r], Y.v[k], a);
+                F[LD::IF_PI + r * 8 + cl] = a;
+            }
         }
         WSYNC();
     }
-    // ---- segment 0 (its border rows 0..6 are Bbar_0): dz_1 = Lambda_0^-1 (dhat_0 + Pbb_0 eta_1)
+}
+
+// One right-hand side through the cuts (every wave for itself; lane r < 7 holds component r of every vector, products through v_readlane):
+// returns dz_w (0 for the first segment) and nu_{w+1} (0 for the last) of the wave's segment w.
+template <int S>
+__device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, const int w, const int lane, double& dz_own, double& nu_next) {
+    using LD = SegLds<S>;
+    const int r = lane < 7 ? lane : 0;
+    auto mv = [&](const double* M, const int sr, const int sc, const double x) __attribute__((always_inline)) -> double {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a = fma(M[r * sr + k * sc], rdlane(x, k), a);
+        return a;
+    };
+    double eta[S], xr[S], dz[S], nu[S];
+    eta[S - 1] = ifb[(S - 1) * LD::IFS + LD::IF_ZB + r];
+    static_for<1, S - 1>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int s = S - 1 - decltype(ic)::value;              // S-2 .. 1
+        const double* F = ifb + s * LD::IFS;
+        const double* Fn = ifb + (s + 1) * LD::IFS;
+        const double v = mv(F + LD::IF_SC + 7 * LD::SCS + 7, LD::SCS, 1, eta[s + 1]) - F[LD::IF_ZB + 7 + r];
+        xr[s] = mv(F + LD::IF_WI, 8, 1, v);
+        const double wv = eta[s + 1] - mv(Fn + LD::IF_PI, 8, 1, xr[s]);
+        eta[s] = F[LD::IF_ZB + r] + mv(F + LD::IF_AH, 1, 8, wv);
+    });
     {
-        double* F = ifb;
-        double* Fn = ifb + LD::IFS;
-        Col7 col;
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const double pv = Fn[LD::IF_PI + r * 8 + c7], ev = Fn[LD::IF_ETA + r];
-            col.v[r] = lane < 7 ? pv : ev;
-        }
-        Col7 T = mat_col(F + LD::IF_SC, LD::SCS, 1, col);
-#pragma unroll
-        for (int r = 0; r < 7; ++r) T.v[r] = lane < 7 ? T.v[r] + (r == lane ? 1.0 : 0.0) : T.v[r] - F[LD::IF_ZB + r];
-        ge7_solve(T);
-        if (lane == 7) {
-#pragma unroll
-            for (int r = 0; r < 7; ++r) Fn[LD::IF_DZ + r] = T.v[r];
-        }
+        const double v = mv(ifb + LD::IF_SC, LD::SCS, 1, eta[1]) - ifb[LD::IF_ZB + r];
+        dz[1] = mv(ifb + LD::IF_WI, 8, 1, v);
     }
-    WSYNC();
-    // ---- forward over the cuts: lanes 0..6 = rows
-#pragma unroll 1
-    for (int s = 1; s < S; ++s) {
-        double* F = ifb + s * LD::IFS;
-        if (s > 1) {
-            const double* Fp = ifb + (s - 1) * LD::IFS;             // dz_s = X_{s-1} dz_{s-1} + xr_{s-1}
-            double a = Fp[LD::IF_XR + c7];
+    dz[0] = 0.0; nu[0] = 0.0;
+    static_for<1, S>([&](auto sc_) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc_)::value;
+        const double* F = ifb + s * LD::IFS;
+        if constexpr (s > 1) dz[s] = mv(ifb + (s - 1) * LD::IFS + LD::IF_X, 8, 1, dz[s - 1]) + xr[s - 1];
+        nu[s] = eta[s] - mv(F + LD::IF_PI, 8, 1, dz[s]);
+    });
+    dz_own = 0.0; nu_next = 0.0;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) a = fma(Fp[LD::IF_X + c7 * 8 + k], Fp[LD::IF_DZ + k], a);
-            if (lane < 7) F[LD::IF_DZ + lane] = a;
-            WSYNC();
-        }
-        double a = F[LD::IF_ETA + c7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) a = fma(-F[LD::IF_PI + c7 * 8 + k], F[LD::IF_DZ + k], a);
-        if (lane < 7) F[LD::IF_NU + lane] = a;
-        WSYNC();
-    }
+    for (int s = 0; s < S; ++s) { if (w == s) { dz_own = dz[s]; if (s + 1 < S) nu_next = nu[s + 1]; } }
 }
 
 // Two segments, one cut: the coupling has a closed form in four 7 x 7 operators that depend on the factorisation only (seg_cut.h:
@@ -365,17 +353,15 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             if (lz_ < 7) { wvec[lz_] = first ? -a : a; if (!first) IFm[LD::IF_DZ + lz_] = a; }
             SEG_STAMP(7);
         } else {
-        if (wv_ == 0) interface_solve<S>(ifb, lz_);
-        XSYNC();
-        SEG_STAMP(7);
-        // unknowns of the border rows: dz_s on the z rows, -nu_{s+1} on the Bbar rows
-        if (lz_ < 16) {
-            const int b = lz_;
-            double w = 0.0;
-            if (!first && b < 7) w = IFm[LD::IF_DZ + b];
-            if (!last && b >= bslot && b < bslot + 7) w = -ifb[(wv_ + 1) * LD::IFS + LD::IF_NU + b - bslot];
-            wvec[b] = w;
-        }
+            double dzo, nun;
+            interface_apply<S>(ifb, wv_, lz_, dzo, nun);
+            // unknowns of the border rows: dz_s on the z rows, -nu_{s+1} on the Bbar rows
+            if (lz_ < 7) {
+                wvec[lz_] = first ? -nun : dzo;
+                wvec[7 + lz_] = (first || last) ? 0.0 : -nun;
+                if (!first) IFm[LD::IF_DZ + lz_] = dzo;
+            }
+            SEG_STAMP(7);
         }
         WSYNC();
         double x = y * invd[uz_ ? lz_ : 0];
@@ -809,7 +795,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 int lt = lane; asm volatile("" : "+v"(lt));
                 factorise(uact ? Rj : 1.0, 0.0, lt, false, h);
                 schur(lt); if (lt == 0) IFm[LD::IF_G56] = 0.0;
-                if constexpr (S == 2) { XSYNC(); if (wv_ == 0) interface_factor2(ifb, YM, lt); }
+                XSYNC(); if (wv_ == 0) { if constexpr (S == 2) interface_factor2(ifb, YM, lt); else interface_factor<S>(ifb, lt); }
                 const double zg = zgrad(lt);
                 const double xt = coupled_solve(uact ? -(g0 + zg) : (zact ? -(g0 + zg) : 0.0), lt);
                 const double duc = uact ? xt : 0.0;
@@ -981,7 +967,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 schur(lz);
                 if (lz == 0) IFm[LD::IF_G56] = g56_tot;
                 SEG_STAMP(5);
-                if constexpr (S == 2) { XSYNC(); if (wv_ == 0) interface_factor2(ifb, YM, lz); SEG_STAMP(13); }
+                XSYNC(); if (wv_ == 0) { if constexpr (S == 2) interface_factor2(ifb, YM, lz); else interface_factor<S>(ifb, lz); SEG_STAMP(13); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(t[i]), "+v"(lam[i]));
 #pragma unroll
