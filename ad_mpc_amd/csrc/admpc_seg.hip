@@ -50,6 +50,25 @@ __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// The wave's H (S = 4: and Hb behind it) from its slot in global memory (L2) straight into LDS: LDS-DMA (global_load_lds_dwordx4: destination =
+// wave-uniform base + lane * 16, no staging registers), issued as soon as the factor that occupies the buffer is dead -- behind the last back
+// substitution of an iteration -- so that the round trip hides under the step-length computations.  The caller waits vmcnt(0) before the first read.
+template <int CNT>
+__device__ __forceinline__ void slot_fetch(double* lds_dst, const double* gsrc, const int lane) {
+    constexpr int BYTES = CNT * 8, FULL = BYTES / 1024, REM = (BYTES % 1024) / 16;
+    static_assert(BYTES % 16 == 0, "slot_fetch copies 16 bytes per lane");
+    // 1 KiB pieces; four per base address (the instruction's 12-bit offset moves both the source and the LDS destination).  The base is laundered
+    // where the copy is issued: hipcc otherwise hoists one 64-bit address per piece out of the interior-point loop and spills them.
+    const char* g = reinterpret_cast<const char*>(gsrc) + lane * 16;
+    asm volatile("" : "+v"(g));
+    char* l = reinterpret_cast<char*>(lds_dst);
+    static_for<0, FULL + (REM > 0 ? 1 : 0)>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value, grp = p / 4, off = (p % 4) * 1024;
+        if (p < FULL || lane < REM)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + grp * 4096), (__attribute__((address_space(3))) void*)(l + grp * 4096), 16, off, 0);
+    });
+}
+
 // Cross-WAVE exchange through LDS: inline-assembly LDS stores are invisible to the compiler's wait-count tracking, so the barrier
 // waits for everything this wave has in flight first.
 #define XSYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
@@ -113,11 +132,18 @@ struct SegLds {
     // H (needed from the top of an iteration to the row build of its factorisation) and L (from the factorisation to the last back
     // substitution) are never live together: ONE buffer; H waits in the workgroup's slot of global memory (L2) and is fetched at the top
     // of every iteration -- 6.6 KB of LDS per wave, the difference between three and four workgroups per CU at S = 2
-    static constexpr int oH = 0, oL = oH, oHb = oH + NTRI, oLb = oHb + NB * 40, oPark = oLb + NB * 40, oCb = oPark + 5 * 64;
+    // S > 2 (14 border rows per wave): the constant border rows Hb and the factor's border rows Lb share their buffer the same way, Hb behind H in
+    // the slot -- 4.5 KB per wave, the difference between one and two workgroups per CU at S = 4
+    static constexpr bool share_b = S > 3;                                // (S = 3 has two workgroups per CU either way: measured slower with the extra fetch)
+    static constexpr bool bl_if = S > 2;                                  // bl of the linearisation in the interface block (below)
+    static constexpr int NSLOT = NTRI + (share_b ? NB * 40 : 0);          // doubles of a wave's slot
+    static constexpr int oH = 0, oL = oH, oHb = oH + NTRI, oLb = share_b ? oHb : oHb + NB * 40, oPark = oLb + NB * 40, oCb = oPark + 4 * 64;
     static constexpr int oWv = oCb + 4 * 64;
     static constexpr int JTS = 24, JTK = 4 * JTS + 2;
     static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
-    static constexpr int seg_ipm = oWv + 16, seg_lin = oBlA + N * NX;      // what the interior point needs / what phase A's tables need
+    // what the interior point needs / what phase A's tables need (S > 2: the residuals bl of the linearisation live in the interface block,
+    // over fields only the interior point uses)
+    static constexpr int seg_ipm = oWv + 16, seg_lin = oBlA + (bl_if ? 0 : N * NX);
     static constexpr int seg = seg_ipm > seg_lin ? seg_ipm : seg_lin;
     static_assert(seg % 2 == 0 && oGTC + N * GTS <= oDqC && oGam + (NX + 1) * 64 <= seg && oGam + (NX + 1) * 64 <= oCb, "LDS aliases");
     // interface block of a segment (the fields of the recursion over several cuts only exist for S > 2)
@@ -129,16 +155,16 @@ struct SegLds {
     static constexpr int IF_Z = IF_ZB + 16;                            // [8]      z_s of the interior point's iterate
     static constexpr int IF_ZC = IF_Z + 8;                             // [8]      z_s of the cold start (the free chain)
     static constexpr int IF_DZ = IF_ZC + 8;                            // [8]      Newton step of z_s
-    static constexpr int IF_NU = IF_DZ + 8;                            // [8]      multiplier of the cut in front of this segment
-    static constexpr int IF_RED = IF_NU + 8;                           // [4][8]   partial reductions, one slot per barrier phase
+    static constexpr int IF_RED = IF_DZ + 8;                           // [4][8]   partial reductions, one slot per barrier phase
     static constexpr int IF_BU = IF_RED + 32;                          // [8]      Bbar_s U_s + c_s of the returned inputs
-    static constexpr int IF_PI = IF_BU + 8;                            // [7][8]   Pi_s (backward recursion over the cuts)
-    static constexpr int IF_G56 = IF_PI + 56;                          // [2]      sum of the delta-box barrier ratios of the segment
+    static constexpr int IF_G56 = IF_BU + 8;                           // [2]      sum of the delta-box barrier ratios of the segment
     static constexpr int IF_ABAR = IF_G56 + 2;                         // [7][8]   Abar_s = Phi at the segment's end            (S > 2)
-    static constexpr int IF_X = IF_ABAR + (S > 2 ? 56 : 0);            // [7][8]   X_s = Lambda_s^-1 Ahat_s                     (S > 2)
-    static constexpr int IF_AH = IF_X + (S > 2 ? 56 : 0);              // [7][8]   Ahat_s = Abar_s - Pzb_s'                     (S > 2)
-    static constexpr int IF_WI = IF_AH + (S > 2 ? 56 : 0);             // [7][8]   Wi_s = Lambda_s^-1                           (S > 2)
+    static constexpr int IF_PI = IF_ABAR + (S > 2 ? 56 : 0);           // [7][8]   Pi_s (backward recursion over the cuts)
+    static constexpr int IF_X = IF_PI + 56;                            // [7][8]   X_s = Lambda_s^-1 Ahat_s                     (S > 2)
+    static constexpr int IF_WI = IF_X + (S > 2 ? 56 : 0);              // [7][8]   Wi_s = Lambda_s^-1                           (S > 2)
     static constexpr int IFS = IF_WI + (S > 2 ? 56 : 0);
+    static constexpr int IF_BL = IF_PI;                                // S > 2: bl [20][7] of phases A, C, E over Pi, X, Wi
+    static_assert(!bl_if || IFS - IF_BL >= N * NX, "bl over the interior point's interface fields");
     static constexpr int oIF = S * seg, oWG = oIF + S * IFS;
     static constexpr int oYM = oWG + 8;                                // [4][7][8] solution operators of the single cut (S = 2)
     static constexpr int total = oYM + (S == 2 ? 4 * 56 : 0);
@@ -156,7 +182,7 @@ __device__ __forceinline__ void ge7_solve(Col7& c) { cut_ge_solve<7>(c); }
 // Backward over the cuts:  nu_s = eta_s - Pi_s dz_s  with  Pi_{S-1} = Pzz, eta_{S-1} = yhat;  Lambda_s = I + Pbb_s Pi_{s+1},
 //   Pi_s = Pzz_s + Ahat_s' Pi_{s+1} Lambda_s^-1 Ahat_s,   eta_s = yhat_s + Ahat_s' (eta_{s+1} - Pi_{s+1} Lambda_s^-1 (dhat_s + Pbb_s eta_{s+1}))
 // Forward:  dz_{s+1} = Lambda_s^-1 (Ahat_s dz_s + dhat_s + Pbb_s eta_{s+1}),  nu_{s+1} = eta_{s+1} - Pi_{s+1} dz_{s+1}.
-// (tests/seg_spec.py: newton()).  What depends on the factorisation only -- Pi_s, Ahat_s, X_s = Lambda_s^-1 Ahat_s, Wi_s = Lambda_s^-1 -- is built ONCE
+// (tests/seg_spec.py: newton()).  What depends on the factorisation only -- Pi_s, X_s = Lambda_s^-1 Ahat_s, Wi_s = Lambda_s^-1 -- is built ONCE
 // per interior-point iteration by wave 0 (interface_factor, while the other waves run their forward substitutions); every right-hand side then
 // needs matrix-vector products only, which every wave runs for itself in registers (interface_apply: no barrier, the same bits in every wave).
 template <int S>
@@ -197,16 +223,15 @@ __device__ __forceinline__ void interface_factor(double* __restrict__ ifb, const
         if (!mid) break;
         if (grp == 1 && keep) {
 #pragma unroll
-            for (int r = 0; r < 7; ++r) { F[LD::IF_X + r * 8 + cl] = T.v[r]; F[LD::IF_AH + r * 8 + cl] = ah.v[r]; }
+            for (int r = 0; r < 7; ++r) F[LD::IF_X + r * 8 + cl] = T.v[r];
         }
-        WSYNC();                                                   // Ahat is read back transposed below
         Col7 Y = mat_col(Fn + LD::IF_PI, 8, 1, T);                 // group 1: Pi_{s+1} X
         if (grp == 1 && keep) {
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 double a = F[LD::IF_HZZ + r * 8 + cl] + ((r == 6 && cl == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + r * LD::SCS + cl];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_AH + k * 8 + r], Y.v[k], a);
+                for (int k = 0; k < 7; ++k) a = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k], Y.v[k], a);      // Ahat[k][r]
                 F[LD::IF_PI + r * 8 + cl] = a;
             }
         }
@@ -235,7 +260,10 @@ __device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, 
         const double v = mv(F + LD::IF_SC + 7 * LD::SCS + 7, LD::SCS, 1, eta[s + 1]) - F[LD::IF_ZB + 7 + r];
         xr[s] = mv(F + LD::IF_WI, 8, 1, v);
         const double wv = eta[s + 1] - mv(Fn + LD::IF_PI, 8, 1, xr[s]);
-        eta[s] = F[LD::IF_ZB + r] + mv(F + LD::IF_AH, 1, 8, wv);
+        double e = F[LD::IF_ZB + r];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) e = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k], rdlane(wv, k), e);      // Ahat' wv
+        eta[s] = e;
     });
     {
         const double v = mv(ifb + LD::IF_SC, LD::SCS, 1, eta[1]) - ifb[LD::IF_ZB + r];
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     double* const ifb = lds_raw + LD::oIF;                       // interface blocks of all segments
     double* const IFm = ifb + wv_ * LD::IFS;                     // this segment's
     int* const wgw = reinterpret_cast<int*>(lds_raw + LD::oWG);  // workgroup words: [0] instance of this round
-    double* const hsl = hslot + ((size_t)blockIdx.x * S + wv_) * LD::NTRI;      // this wave's H in global memory (L2), rewritten per instance
+    double* const hsl = hslot + ((size_t)blockIdx.x * S + wv_) * LD::NSLOT;      // this wave's H in global memory (L2), rewritten per instance
     double* const YM = lds_raw + LD::oYM;                        // S = 2: the cut's solution operators (interface_factor2)
     double* const Hp = lds_seg + LD::oH;
     double* const Hb = lds_seg + LD::oHb;
@@ -295,7 +323,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     double* const wvec = lds_seg + LD::oWv;
     double* const JT = lds_seg + LD::oJT;
     double* const GT = lds_seg + LD::oGTC;
-    double* const bl = lds_seg + LD::oBlA;
+    double* const bl = LD::bl_if ? IFm + LD::IF_BL : lds_seg + LD::oBlA;
     double* const dqC = lds_seg + LD::oDqC;
     double* const gam = lds_seg + LD::oGam;
     double* const dqE = lds_seg + LD::oDqC;
@@ -303,8 +331,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 #define PK_DL   park[0 * 64 + lane]
 #define PK_DUU  park[1 * 64 + lane]
 #define PK_G0   park[2 * 64 + lane]
-#define PK_DDL  park[3 * 64 + lane]
-#define PK_DDU  park[4 * 64 + lane]
+#define PK_DDL  park[3 * 64 + (lane & 31)]           // the steering box: stages = lanes < 20 (the two bounds share one row)
+#define PK_DDU  park[3 * 64 + 32 + (lane & 31)]
 #define LAUNDER_LANE(v) int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(v))
 #define LAUNDER_CFG(c) int c##_z = 0; asm volatile("" : "+s"(c##_z)); const AdmpcConfig* __restrict__ c = cfg + c##_z
     // partial reductions of the S waves: slot `ph` of every segment, combined in segment order by every wave (same bits everywhere)
@@ -720,6 +748,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             // H to the wave's slot: the factor of the trial takes its buffer.  The vector L1 does not follow the wave's own stores and may
             // still hold lines the PREVIOUS instance of this wave read here: drop them once the stores have retired.
             stage_in<LD::NTRI>(hsl, Hp, lane);
+            if constexpr (LD::share_b) { stage_in<7 * n>(hsl + LD::NTRI, Hb, lane); stage_in<7 * n>(hsl + LD::NTRI + 7 * n, Hb + 7 * n, lane); }      // Hb behind it (Lb takes its buffer)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // invalidate only: a release would write the L2's dirty lines back to HBM
             WSYNC();
@@ -773,7 +802,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 #pragma unroll
                 for (int i = 0; i < 2; ++i) { Dt[i] = r0[i] > thr ? r0[i] : thr; Dlam[i] = mu0 * rcp_nr(Dt[i]); }
             }
-            PK_DL = dl_i; PK_DUU = duu_i; PK_G0 = g0; PK_DDL = Ddl; PK_DDU = Ddu;
+            PK_DL = dl_i; PK_DUU = duu_i; PK_G0 = g0; if (lane < 32) { PK_DDL = Ddl; PK_DDU = Ddu; }
             WSYNC();
 
             // z part of the cost gradient at the current z_s (segments behind the first): the input lanes get Hzu' z, the z lanes Hzz z
@@ -791,13 +820,15 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 
             double rmax_prev = 0.0, step = 1e300, stp_local = 1e300, alpha_prev = 1.0, rstat = -1.0;
             bool solved = false, warmed = false, cons = false;
+            bool hres = false;                                           // H (and Hb) resident or on its way from the slot
             if (try_unc) {
                 int lt = lane; asm volatile("" : "+v"(lt));
+                const double zg = zgrad(lt);                                 // reads Hb: in front of the factorisation (S > 2: Lb takes Hb's buffer)
                 factorise(uact ? Rj : 1.0, 0.0, lt, false, h);
                 schur(lt); if (lt == 0) IFm[LD::IF_G56] = 0.0;
                 XSYNC(); if (wv_ == 0) { if constexpr (S == 2) interface_factor2(ifb, YM, lt); else interface_factor<S>(ifb, lt); }
-                const double zg = zgrad(lt);
                 const double xt = coupled_solve(uact ? -(g0 + zg) : (zact ? -(g0 + zg) : 0.0), lt);
+                slot_fetch<LD::NSLOT>(Hp, hsl, lt); hres = true;          // the trial's factor is dead
                 const double duc = uact ? xt : 0.0;
 #ifdef SEG_DEBUG
                 if (inst == g_seg_dbg_inst) {
@@ -879,7 +910,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     for (int i = 0; i < 2; ++i) { const double rci = Dt[i] * Dlam[i]; musum += dact ? rci : 0.0; cmax = fmax(cmax, dact ? rci : 0.0); }
                     const double G56 = Dlam[0] * rcp_nr(Dt[0]) + Dlam[1] * rcp_nr(Dt[1]);
                     Dbar = uact ? Rj + G0 * G2 * rcp_nr(G0 + G2) + G1 * G3 * rcp_nr(G1 + G3) : 1.0;
-                    stage_in<LD::NTRI>(Hp, hsl, lane);                      // H back from the slot (the last factor is dead)
+                    if (!hres) slot_fetch<LD::NSLOT>(Hp, hsl, lane);        // H (S = 4: and Hb) back from the slot, unless the last solve prefetched it
                     cb[lane] = uact ? du : 0.0;
                     const double dlam_pref = wave_scan_incl<OpSum>(dact ? (Dlam[1] - Dlam[0]) : 0.0);     // lanes = stages
                     dlam_tot = rdlane(dlam_pref, 63);
@@ -887,6 +918,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     const double Ssuf_incl = wave_scan_incl<OpSum>(dact ? G56 : 0.0);
                     g56_tot = rdlane(Ssuf_incl, 63);
                     sb2[lane] = g56_tot - Ssuf_incl;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // H has landed
                     WSYNC();
                     double hdu = 0.0;
                     {
@@ -964,6 +996,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     continue;
                 }
                 factorise(Dbar, (uz && ji) ? S_i : 0.0, lz, !first, h);
+                hres = false;
                 schur(lz);
                 if (lz == 0) IFm[LD::IF_G56] = g56_tot;
                 SEG_STAMP(5);
@@ -1000,6 +1033,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     WSYNC();
                     const double y = uact ? -(ru + etal + etau + (ji ? h * sb[ki] : 0.0)) : (zact ? -(ru + (lane == n + 6 ? ek_tot : 0.0)) : 0.0);
                     const double x = coupled_solve(y, lz);
+                    if (ps == 1) { slot_fetch<LD::NSLOT>(Hp, hsl, lz); hres = true; }      // the factor is dead: next iteration's H under the step-length work
                     ddu = uact ? x : 0.0;
                     cb[lane] = ddu;
                     WSYNC();
@@ -1082,12 +1116,13 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             }
         }
         if (failed) break;
-        // ---- the cut states of the returned inputs: Bbar_s U_s + c_s per segment (Hb is still in place), chained below
+        // ---- the cut states of the returned inputs: Bbar_s U_s + c_s per segment (Hb is in place: S = 4 brought it back with H behind the last solve), chained below
         if (S > 1 && !last) {
             LAUNDER_LANE(lane);
             const bool uact = lane < n;
             const double duv = uact ? du : 0.0;
             const int li = uact ? lane : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (S = 4: Hb came back with the last prefetch)
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 const double v = wave_reduce<OpSum>(Hb[(bslot + r) * n + li] * duv);
@@ -1295,7 +1330,8 @@ int admpc_debug_seg(double* out, int inst)
 }
 
 // doubles of the slot buffer: one packed H per resident wave (at most 8 waves per CU)
-__attribute__((visibility("hidden"))) size_t admpc_seg_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * 820; }
+__attribute__((visibility("hidden"))) // (at most eight waves per CU; S > 2 parks its 14 constant border rows behind H: SegLds::NSLOT)
+size_t admpc_seg_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * SegLds<4>::NSLOT; }
 
 // horizons this unit serves (fp64): N = 20 S, S = 2, 3, 4
 __attribute__((visibility("hidden"))) int admpc_seg_supports(int N) { return N == 40 || N == 60 || N == 80; }
@@ -1315,8 +1351,12 @@ __attribute__((visibility("hidden"))) void admpc_seg_launch(int N, int num_cu, h
         double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot)
 {
     switch (N / 20) {
+#ifndef SEG_DEV_ONLY_S4
         case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
-#ifndef SEG_DEV_ONLY_S2      // development builds: one instantiation compiles in a third of the time
+#endif
+#if defined(SEG_DEV_ONLY_S4)
+        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+#elif !defined(SEG_DEV_ONLY_S2)      // development builds: one instantiation compiles in a third of the time
         case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
         default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
 #else
