@@ -1286,7 +1286,7 @@ struct AdmpcSolver {
     int use_dense;           // condensed dense-Cholesky QP kernel available for this horizon (N == 20) and not disabled
     int dense_lds_bytes;
     int n20_fused;           // N = 20 fp64 steps run the fused persistent kernel (admpc_fused20.hip); 0: the four-kernel pipeline (ADMPC_N20=split)
-    int use_seg;             // N = 40 fp64 steps (N = 60 / 80 with ADMPC_QP=seg) run the segmented condensed kernel (admpc_seg.hip); ADMPC_QP=riccati: kernel R
+    int use_seg;             // N = 40 / 60 / 80 fp64 steps without GP models run the segmented condensed kernel (admpc_seg.hip; with GP models on ADMPC_QP=seg); ADMPC_QP=riccati: kernel R
     int* d_tick;             // [128 + 64 cap_fused] tickets, exit counter and work-order bins of the fused kernel (zeroed at allocation; the kernel re-arms them)
     int cap_fused;
     double* d_slot;          // per-wave slot buffers of the fused kernel (the linearisation across the interior point), allocated at its first launch
@@ -1436,13 +1436,12 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
 #else
         s->n20_fused = 1;                        // the product library carries the fused kernel only (`make legacy` for the older pipeline)
 #endif
-        // default at N = 40 (the reference's shipped horizon: 6.1 M solves/s against kernel R's 3.4 M at B = 4096); at N = 60 / 80 the
-        // segmented kernel is correct but LDS-bound (two / one workgroup per CU) and measured level with / behind kernel R
-        // (scripts/cmp_seg_rowqp.sh): there it runs on request only, ADMPC_QP=seg
+        // default at N = 40 (the reference's shipped horizon: 6.2 M solves/s against kernel R's 3.4 M at B = 4096), 60 and 80 (2.7 / 2.0 M against
+        // 1.7 / 1.2 M; scripts/cmp_seg_rowqp.sh); ADMPC_QP=riccati selects kernel R there
         // (nominal model only: with GP residuals in the dynamics the linearisation can have strongly unstable modes -- random regressors are
         // arbitrary dynamics -- and eliminating 20 stages at a time loses what the stage-wise Riccati recursion keeps: the N = 40 + GP census
-        // family came out 3e-6 off in the inputs on the segmented kernel, 1e-8 on kernel R; with GPs the default stays kernel R)
-        s->use_seg = admpc_seg_supports(cfg->N) && ((cfg->N == 40 && cfg->n_gp == 0) ? !(e && strcmp(e, "riccati") == 0) : (e && strcmp(e, "seg") == 0));
+        // family came out 3e-6 off in the inputs on the segmented kernel, 1e-8 on kernel R; with GPs the default stays kernel R, ADMPC_QP=seg selects kernel S)
+        s->use_seg = admpc_seg_supports(cfg->N) && (cfg->n_gp == 0 ? !(e && strcmp(e, "riccati") == 0) : (e && strcmp(e, "seg") == 0));
     }
     hipError_t e = hipMalloc((void**)&s->d_cfg, sizeof(AdmpcConfig));
     if (e != hipSuccess) { delete s; return fail(ADMPC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }

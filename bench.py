@@ -517,7 +517,7 @@ def main():
             wl = "BASELINE configs[1]: batch %d random (x0, curved ref) scenarios, N=%d, %s" % (B, N, args.dtype)
         dense = N == 20 and not f32 and os.environ.get("ADMPC_QP") != "riccati"
         fused = dense and os.environ.get("ADMPC_N20") != "split"
-        seg = not f32 and ((N == 40 and not args.gp and os.environ.get("ADMPC_QP") != "riccati") or (N in (40, 60, 80) and os.environ.get("ADMPC_QP") == "seg"))      # admpc_seg.hip: N / 20 cooperating waves per instance
+        seg = not f32 and N in (40, 60, 80) and ((not args.gp and os.environ.get("ADMPC_QP") != "riccati") or os.environ.get("ADMPC_QP") == "seg")      # admpc_seg.hip: N / 20 cooperating waves per instance
         out = {
             "metric": "MPC solves/sec (N=%d, nx=7, nu=2, %s)" % (N, "fp32" if f32 else "fp64"), "value": value, "unit": "solves/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,

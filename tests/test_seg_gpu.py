@@ -99,9 +99,9 @@ def test_segmented_kernel_failure_and_sqp_passes(gpu_engine_factory, oracle_omp)
 
 
 def test_default_kernel_by_horizon(gpu_engine_factory, monkeypatch):
-    """N = 40 runs the segmented kernel by default (its work-order pre-pass shows in the launch: the iterations of a solve are the same
-    either way, the bits are not); N = 80 runs kernel R by default -- the segmented kernel there is bit-different and on request."""
-    for N, seg_default in ((40, True), (80, False)):
+    """N = 40, 60 and 80 run the segmented kernel by default (the iterations of a solve are the same either way, the bits are not);
+    every other horizon kernel R, whatever ADMPC_QP says."""
+    for N, seg_default in ((40, True), (60, True), (80, True)):
         s = random_scenarios(64, N=N, seed=3, blend=(3.0, 5.0))
         cfg = default_config(N=N)
         monkeypatch.delenv("ADMPC_QP", raising=False)
