@@ -14,7 +14,10 @@ o64 = orc.solve_batch(cfg, s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s
 c32 = cfg.copy(); c32.ipm_tol_comp = 1e-3; c32.ipm_tol_res = 1e-2; c32.ipm_tol_step = 1e-3
 seg_spec.IPM_FLOOR = 1e-8
 seg_spec.MU_FLOOR = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0      # kernel R in fp32 has no centring floor (rowqp_core.h, rq_make_params)
-F64 = len(sys.argv) > 4 and sys.argv[4] == 'f64'      # control: fp64 arithmetic at the fp32 stop levels
+MODE = sys.argv[4] if len(sys.argv) > 4 else 'f32'
+F64 = MODE == 'f64'      # control: fp64 arithmetic at the fp32 stop levels
+# MODE 'mixed': problem data and condensed blocks rounded to float32 (factorisations, substitutions, products with them run in float32), numpy's own
+# promotion elsewhere (the vectors of the interior point that pass through a float64 array stay float64); 'f32': every array float32
 f32 = np.float64 if F64 else np.float32
 class Q32(seg_spec.SegQP):
     def __init__(self, *a, **k):
@@ -42,7 +45,7 @@ class _NP32:
         r = np.asarray(x, *a, **k); return r.astype(f32) if r.dtype == np.float64 else r
     def concatenate(self, xs, *a, **k):
         r = np.concatenate(xs, *a, **k); return r.astype(f32) if r.dtype == np.float64 else r
-seg_spec.np = _NP32()
+if MODE == 'f32': seg_spec.np = _NP32()
 err = []; its = []; fails = 0; leaks = 0
 for i in range(B):
     q = orc.qp_debug(cfg, s['x0'][i], s['yref'][i], s['yref_e'][i], s['p'][i], s['xbar'][i], s['ubar'][i])
@@ -58,4 +61,4 @@ for i in range(B):
     err.append(e); its.append(it)
 err = np.array(err)
 print("float64 results (leaks):", leaks)
-print("fp32 segmented (numpy emulation): B %d, failures %d, iterations mean %.2f max %d (fp64 oracle mean %.2f); |du - du64| quantiles 50/90/99/max: %.2e %.2e %.2e %.2e" % (B, fails, np.mean(its), max(its), o64[4].mean(), *np.quantile(err, [0.5, 0.9, 0.99, 1.0])))
+print(MODE, "mu floor", seg_spec.MU_FLOOR, "Ns", NS); print("fp32 segmented (numpy emulation): B %d, failures %d, iterations mean %.2f max %d (fp64 oracle mean %.2f); |du - du64| quantiles 50/90/99/max: %.2e %.2e %.2e %.2e" % (B, fails, np.mean(its), max(its), o64[4].mean(), *np.quantile(err, [0.5, 0.9, 0.99, 1.0])))
