@@ -245,7 +245,9 @@ template <int S>
 __device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, const int w, const int lane, double& dz_own, double& nu_next) {
     using LD = SegLds<S>;
     const int r = lane < 7 ? lane : 0;
-    auto mv = [&](const double* M, const int sr, const int sc, const double x) __attribute__((always_inline)) -> double {
+    // (one wait state between the multiply-add that produces a vector and the v_readlane that reads it: scripts/check_dpp_hazard.py, rule R2)
+    auto mv = [&](const double* M, const int sr, const int sc, double x) __attribute__((always_inline)) -> double {
+        asm volatile("s_nop 0" : "+v"(x));
         double a = 0.0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) a = fma(M[r * sr + k * sc], rdlane(x, k), a);
@@ -259,7 +261,8 @@ __device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, 
         const double* Fn = ifb + (s + 1) * LD::IFS;
         const double v = mv(F + LD::IF_SC + 7 * LD::SCS + 7, LD::SCS, 1, eta[s + 1]) - F[LD::IF_ZB + 7 + r];
         xr[s] = mv(F + LD::IF_WI, 8, 1, v);
-        const double wv = eta[s + 1] - mv(Fn + LD::IF_PI, 8, 1, xr[s]);
+        double wv = eta[s + 1] - mv(Fn + LD::IF_PI, 8, 1, xr[s]);
+        asm volatile("s_nop 0" : "+v"(wv));
         double e = F[LD::IF_ZB + r];
 #pragma unroll
         for (int k = 0; k < 7; ++k) e = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k], rdlane(wv, k), e);      // Ahat' wv
