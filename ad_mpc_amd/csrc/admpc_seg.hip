@@ -239,18 +239,21 @@ __device__ __forceinline__ void interface_factor(double* __restrict__ ifb, const
     }
 }
 
-// One right-hand side through the cuts (every wave for itself; lane r < 7 holds component r of every vector, products through v_readlane):
+// One right-hand side through the cuts (every wave for itself; lane r < 7 holds component r of every vector, products by DPP row broadcast):
 // returns dz_w (0 for the first segment) and nu_{w+1} (0 for the last) of the wave's segment w.
 template <int S>
 __device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, const int w, const int lane, double& dz_own, double& nu_next) {
     using LD = SegLds<S>;
     const int r = lane < 7 ? lane : 0;
-    // (one wait state between the multiply-add that produces a vector and the v_readlane that reads it: scripts/check_dpp_hazard.py, rule R2)
-    auto mv = [&](const double* M, const int sr, const int sc, double x) __attribute__((always_inline)) -> double {
-        asm volatile("s_nop 0" : "+v"(x));
-        double a = 0.0;
+    // y_r = sum_k M[r][k] x_k: the vector's component k comes from lane k of the 16-lane row inside the multiply-add (v_fmac_f64_dpp row_newbcast:k;
+    // the first one carries the two wait states a DPP read needs behind the VALU write of x)
+    auto mv = [&](const double* M, const int sr, const int sc, const double x) __attribute__((always_inline)) -> double {
+        double m[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) a = fma(M[r * sr + k * sc], rdlane(x, k), a);
+        for (int k = 0; k < 7; ++k) m[k] = M[r * sr + k * sc];
+        double a = 0.0;
+        fmac_rowbc<0>(a, x, m[0]);
+        static_for<1, 7>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; fmac_rowbc_ld<k>(a, x, m[k]); });
         return a;
     };
     double eta[S], xr[S], dz[S], nu[S];
@@ -261,11 +264,15 @@ __device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, 
         const double* Fn = ifb + (s + 1) * LD::IFS;
         const double v = mv(F + LD::IF_SC + 7 * LD::SCS + 7, LD::SCS, 1, eta[s + 1]) - F[LD::IF_ZB + 7 + r];
         xr[s] = mv(F + LD::IF_WI, 8, 1, v);
-        double wv = eta[s + 1] - mv(Fn + LD::IF_PI, 8, 1, xr[s]);
-        asm volatile("s_nop 0" : "+v"(wv));
+        const double wv = eta[s + 1] - mv(Fn + LD::IF_PI, 8, 1, xr[s]);
         double e = F[LD::IF_ZB + r];
+        {
+            double m[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) e = fma(F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k], rdlane(wv, k), e);      // Ahat' wv
+            for (int k = 0; k < 7; ++k) m[k] = F[LD::IF_ABAR + k * 8 + r] - F[LD::IF_SC + r * LD::SCS + 7 + k];      // Ahat[k][r]: Ahat' wv
+            fmac_rowbc<0>(e, wv, m[0]);
+            static_for<1, 7>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; fmac_rowbc_ld<k>(e, wv, m[k]); });
+        }
         eta[s] = e;
     });
     {
