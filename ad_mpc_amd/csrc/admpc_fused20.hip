@@ -1069,6 +1069,9 @@ __attribute__((visibility("hidden"))) int admpc_fused20_lds_bytes(void) { return
 __attribute__((visibility("hidden"))) size_t admpc_fused20_slot_doubles(int num_cu) { return (size_t)num_cu * 8 * FusedLds::SLOT; }
 
 // debug builds only: read and clear the phase counters (all zero in the shipped build)
+#ifdef F20_ORDER_HINT
+int admpc_debug_f20_order_hint(const int* d_hint) { return hipMemcpyToSymbol(HIP_SYMBOL(g_order_hint), &d_hint, sizeof(d_hint)) == hipSuccess ? 0 : -1; }
+#endif
 int admpc_debug_f20_ticks(unsigned long long* out16)
 {
 #ifdef ADMPC_PHASE_TIMERS

@@ -20,6 +20,9 @@
 #ifndef F20_ORDER_GAIN
 #define F20_ORDER_GAIN 3.0
 #endif
+#ifdef F20_ORDER_HINT      // experiment builds only (scripts/experiments/order_headroom.py): bins from a per-instance effort the caller knows
+__device__ const int* g_order_hint = nullptr;
+#endif
 __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig* __restrict__ cfg, int B, const double* __restrict__ x0g,
                                                                const double* __restrict__ yrefg, const double* __restrict__ yrefeg,
                                                                int* __restrict__ sched, int cap)
@@ -50,6 +53,9 @@ __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig*
         const double ov = fmax(areq - ub, lb - areq) / (ub - lb);          // < 0: that far inside the box
         q = 0;
         if (ov == ov && ov > -0.125) q = 1 + (int)fmin(fmax((ov + 0.125) * 32.0, 0.0), (double)(F20_NB - 2));
+#ifdef F20_ORDER_HINT
+        if (g_order_hint) { const int hq = g_order_hint[b]; q = hq < 0 ? 0 : (hq > F20_NB - 1 ? F20_NB - 1 : hq); }
+#endif
         rank = atomicAdd(&cnt[q], 1);
     }
     __syncthreads();
