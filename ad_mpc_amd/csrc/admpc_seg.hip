@@ -136,8 +136,15 @@ struct SegLds {
     // the slot -- 4.5 KB per wave, the difference between one and two workgroups per CU at S = 4
     static constexpr bool share_b = S > 3;                                // (S = 3 has two workgroups per CU either way: measured slower with the extra fetch)
     static constexpr bool bl_if = S > 2;                                  // bl of the linearisation in the interface block (below)
-    static constexpr int NSLOT = NTRI + (share_b ? NB * 40 : 0);          // doubles of a wave's slot
-    static constexpr int oH = 0, oL = oH, oHb = oH + NTRI, oLb = share_b ? oHb : oHb + NB * 40, oPark = oLb + NB * 40, oCb = oPark + 4 * 64;
+    static constexpr int BS = 42;                                         // row stride of Hb / Lb (seg_cut.h)
+    // LDS banks: a ds_read_b64 of a packed row start tri(i) = i (i + 1) / 2 is conflict-free over lanes 0..31 (triangular numbers are distinct mod 32) and
+    // over rows 32..39 (bank pairs 16 17 19 22 26 31 5 12); the border rows in lanes 40.. share that half of the wave: with stride 42 (10 mod 32) and a base
+    // that is 0 or 10 mod 32 doubles away from the packed rows, seven border rows sit on 0 10 20 30 8 18 28 (+ 10) -- clear of the rows above
+    static constexpr int oHbRel = 832;                                    // Hb behind H (820), 0 mod 32
+    static constexpr int NSLOT = share_b ? oHbRel + NB * BS : NTRI;       // doubles of a wave's slot (S = 4: H, the gap, Hb -- the LDS image)
+    static constexpr int oH = 0, oL = oH, oHb = oH + oHbRel;
+    static constexpr int oLb = share_b ? oHb : oHb + NB * BS + (((10 - (oHbRel + NB * BS)) % 32 + 32) % 32);
+    static constexpr int oPark = oLb + NB * BS, oCb = oPark + 4 * 64;
     static constexpr int oWv = oCb + 4 * 64;
     static constexpr int JTS = 24, JTK = 4 * JTS + 2;
     static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                                                                 double* __restrict__ hslot)
 {
     using LD = SegLds<S>;
-    constexpr int N = 20, n = 40, NT = N * S, NB = LD::NB, NR = LD::NR;
+    constexpr int N = 20, n = 40, NT = N * S, NB = LD::NB, NR = LD::NR, BS = LD::BS;
     extern __shared__ double lds_raw[];
     const int wv_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // segment of this wave (uniform)
     const bool first = wv_ == 0, last = wv_ == S - 1;
@@ -352,14 +359,14 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
     // LDS byte address of the row this lane holds: packed row of H / L (lanes < 40), border row (lanes 40 .. NR-1), else row 0
     auto row_addr = [&](double* tri, double* brd, const int lz_) __attribute__((always_inline)) -> unsigned {
         const int lb = lz_ - n;
-        return lds_byte_addr(lz_ < n ? tri + lz_ * (lz_ + 1) / 2 : (lz_ < NR ? brd + lb * n : tri));
+        return lds_byte_addr(lz_ < n ? tri + lz_ * (lz_ + 1) / 2 : (lz_ < NR ? brd + lb * BS : tri));
     };
 
     // Factorisation of the bordered Newton matrix: M = H + diag(dbar) + (s_odd on the odd columns of the u1 rows) = L D L' with the
     // border rows (lanes 40 .. NR-1: Hb, plus the delta-box barrier on the z6 row when zbar) riding along -> Lb = C L^-T D^-1.
     const Dense40bLds W{Hp, Hb, Lp, Lb, cb, invd};
     auto factorise = [&](const double dbar_, const double sodd_, const int lz_, const bool zbar, const double h_) __attribute__((always_inline)) {
-        dense40b_factorise<NR>(W, dbar_, lz_, sodd_, [&](double (&a)[n]) __attribute__((always_inline)) {
+        dense40b_factorise<NR, BS>(W, dbar_, lz_, sodd_, [&](double (&a)[n]) __attribute__((always_inline)) {
             // H's rows are in registers: its buffer becomes the factor's.  Diagonal slots of the packed factor: 0.0 (the factorisation stores the
             // strictly-lower part only; the substitution assembly lets the source lane of a step take part with this multiplier)
             if (lz_ < n) Lp[lz_ * (lz_ + 1) / 2 + lz_] = 0.0;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         });
     };
     // Schur blocks of the border: Sc = Lb D Lb' (NB x NB) in ten v_mfma_f64_16x16x4_f64 (seg_cut.h)
-    auto schur = [&](const int lane) __attribute__((always_inline)) { dense40b_schur<NB>(W, IFm + LD::IF_SC, LD::SCS, lane); };
+    auto schur = [&](const int lane) __attribute__((always_inline)) { dense40b_schur<NB, BS>(W, IFm + LD::IF_SC, LD::SCS, lane); };
     // The coupled Newton solve for one right-hand side: y on the input lanes, the reduced stationarity of z_s on the z lanes (0 on
     // the Bbar lanes).  Returns the step of this lane's input; dz_s / nu_{s+1} are in the interface blocks afterwards.
     auto coupled_solve = [&](double y, const int lz_) __attribute__((always_inline)) -> double {
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
         {
             const int li = uz_ ? lz_ : 0;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) x = fma(-Lb[b * n + li], wvec[b], x);
+            for (int b = 0; b < NB; ++b) x = fma(-Lb[b * BS + li], wvec[b], x);
         }
         bwd_subst_40(x, lds_byte_addr(Lp + (uz_ ? lz_ : 0)), pub);
         SEG_STAMP(8);
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         const int row = 16 * I + kq + 4 * v, col = 16 * J + r16;
                         if (row < n && col <= row) Hp[row * (row + 1) / 2 + col] = acc[I][J][v];
                         if (I == 2 && !first && row >= n && row < n + 7) {
-                            if (col < n) Hb[(row - n) * n + col] = acc[I][J][v];
+                            if (col < n) Hb[(row - n) * BS + col] = acc[I][J][v];
                             else if (col < n + 7) IFm[LD::IF_HZZ + (row - n) * 8 + col - n] = acc[I][J][v];
                         }
                     }
@@ -750,15 +757,15 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             if (uact) {
 #pragma unroll
                 for (int r = 0; r < 7; ++r) {
-                    if (!last) Hb[(bslot + r) * n + lane] = g[r];
-                    if (NB == 14 && (first || last)) Hb[(7 + r) * n + lane] = 0.0;
+                    if (!last) Hb[(bslot + r) * BS + lane] = g[r];
+                    if (NB == 14 && (first || last)) Hb[(7 + r) * BS + lane] = 0.0;
                 }
             }
             WSYNC();
             // H to the wave's slot: the factor of the trial takes its buffer.  The vector L1 does not follow the wave's own stores and may
             // still hold lines the PREVIOUS instance of this wave read here: drop them once the stores have retired.
             stage_in<LD::NTRI>(hsl, Hp, lane);
-            if constexpr (LD::share_b) { stage_in<7 * n>(hsl + LD::NTRI, Hb, lane); stage_in<7 * n>(hsl + LD::NTRI + 7 * n, Hb + 7 * n, lane); }      // Hb behind it (Lb takes its buffer)
+            if constexpr (LD::share_b) { stage_in<7 * BS>(hsl + LD::oHbRel, Hb, lane); stage_in<7 * BS>(hsl + LD::oHbRel + 7 * BS, Hb + 7 * BS, lane); }      // Hb behind it (Lb takes its buffer)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // invalidate only: a release would write the L2's dirty lines back to HBM
             WSYNC();
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 if (!first) {
                     const bool uz_ = lz_ < n;
                     const double* base = uz_ ? Hb + lz_ : IFm + LD::IF_HZZ + ((lz_ >= n && lz_ < n + 7) ? lz_ - n : 0) * 8;
-                    const int stride = uz_ ? n : 1;
+                    const int stride = uz_ ? BS : 1;
 #pragma unroll
                     for (int c = 0; c < 7; ++c) a = fma(base[c * stride], IFm[LD::IF_Z + c], a);
                 }
@@ -1135,7 +1142,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (S = 4: Hb came back with the last prefetch)
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
-                const double v = wave_reduce<OpSum>(Hb[(bslot + r) * n + li] * duv);
+                const double v = wave_reduce<OpSum>(Hb[(bslot + r) * BS + li] * duv);
                 if (lane == 0) IFm[LD::IF_BU + r] = v + IFm[LD::IF_C + r];
             }
         }

@@ -118,21 +118,24 @@ __device__ __forceinline__ double cut_apply2(const double* Y, const bool first, 
 // along: Lb = C L^-T D^-1.  LDS: Hp / Lp packed lower rows [820] (the diagonal slots of Lp hold 0.0), Hb / Lb [NR - 40][40], cb: exchange
 // buffers in the layout col_head assumes (cb [64], invd [64] = 1 / D_jj, second buffer at cb + 128).
 struct Dense40bLds { double *Hp, *Hb, *Lp, *Lb, *cb, *invd; };
-template <int NR>
+// BS = row stride of Hb / Lb in doubles (>= 40).  40 puts border rows b and b + 4 on the same LDS banks (80 dwords = 16 banks apart): every row-wise
+// access of the factorisation and the substitutions then carries a two-way conflict (SQ_LDS_BANK_CONFLICT: 44 % of the LDS-active cycles of the car's
+// kernel S against 4 % of kernel F's, which has no border); 42 spreads up to 14 rows over distinct bank pairs and keeps the rows 16-byte aligned.
+template <int NR, int BS = 40>
 __device__ __forceinline__ unsigned dense40b_row_addr(double* tri_, double* brd, const int lz_) {
-    return lds_byte_addr(lz_ < 40 ? tri_ + lz_ * (lz_ + 1) / 2 : (lz_ < NR ? brd + (lz_ - 40) * 40 : tri_));
+    return lds_byte_addr(lz_ < 40 ? tri_ + lz_ * (lz_ + 1) / 2 : (lz_ < NR ? brd + (lz_ - 40) * BS : tri_));
 }
 struct Dense40bNoFix { __device__ __forceinline__ void operator()(double (&)[40]) const {} };
 // fix(a): hook behind the row build (the rows are in registers, H's buffer is free): the car's kernel zeroes the factor's diagonal slots there
 // (H and L share one buffer) and adds the steering-box barrier to the z6 border row; s_odd: added to the odd columns of this lane's row
-template <int NR, class Fix = Dense40bNoFix>
+template <int NR, int BS = 40, class Fix = Dense40bNoFix>
 __device__ __forceinline__ void dense40b_factorise(const Dense40bLds& W, const double dbar_, const int lz_, const double sodd_ = 0.0, const Fix& fix = Fix())
 {
     constexpr int n = 40;
     double a[n];
-    newton_row_40_b<NR>(a, dense40b_row_addr<NR>(W.Hp, W.Hb, lz_), dbar_, sodd_);
+    newton_row_40_b<NR>(a, dense40b_row_addr<NR, BS>(W.Hp, W.Hb, lz_), dbar_, sodd_);
     fix(a);
-    const unsigned lrow = dense40b_row_addr<NR>(W.Lp, W.Lb, lz_);
+    const unsigned lrow = dense40b_row_addr<NR, BS>(W.Lp, W.Lb, lz_);
     const unsigned pub_wr = lds_byte_addr(W.cb + lz_), pub_rd = lds_byte_addr(W.cb + (lz_ & 15));
     double* const invd = W.invd;
     auto chain = [&](auto jc, double& nln) __attribute__((always_inline)) {
@@ -178,7 +181,7 @@ __device__ __forceinline__ void dense40b_factorise(const Dense40bLds& W, const d
     WSYNC();
 }
 // Schur blocks of the border: out [i * so + j] = (Lb D Lb')[i][j], i, j < NB <= 16, in ten v_mfma_f64_16x16x4_f64
-template <int NB>
+template <int NB, int BS = 40>
 __device__ __forceinline__ void dense40b_schur(const Dense40bLds& W, double* out, const int so, const int lane)
 {
     typedef double d4_ __attribute__((ext_vector_type(4)));
@@ -188,7 +191,7 @@ __device__ __forceinline__ void dense40b_schur(const Dense40bLds& W, double* out
 #pragma unroll
     for (int t = 0; t < 10; ++t) {
         const int c = 4 * t + kq;
-        const double lb = W.Lb[rb * 40 + c];
+        const double lb = W.Lb[rb * BS + c];
         const double dc = rcp_nr(W.invd[c]);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb * dc, lb, acc, 0, 0, 0);
     }
