@@ -197,8 +197,11 @@ __device__ __forceinline__ void interface_factor(double* __restrict__ ifb, const
     using LD = SegLds<S>;
     const int l49 = lane < 49 ? lane : 48;
     const int er = div7(l49), ec = l49 - 7 * er;                    // element (er, ec) for the element-wise step
-    const int grp = lane >> 3, cl = lane & 7, c7 = cl < 7 ? cl : 0;  // groups of eight lanes: 0 = columns of Lambda, 1 = of Ahat, 2 = of I
-    const bool keep = cl < 7;
+    // groups of eight lanes: columns of Lambda | of Ahat | of Lambda again (the DPP elimination wants the matrix in every 16-lane row) | of I
+    const int g8 = lane >> 3, cl = lane & 7, c7 = cl < 7 ? cl : 0;
+    const int grp = (g8 & 3) == 1 ? 1 : ((g8 & 3) == 3 ? 2 : 0);     // role: 0 = Lambda, 1 = Ahat, 2 = I
+    const bool owner = g8 == 1 || g8 == 3;
+    const bool keep = cl < 7 && owner;
     {                                                               // the last segment: Pi = Pzz
         double* F = ifb + (S - 1) * LD::IFS;
         const double v = F[LD::IF_HZZ + er * 8 + ec] + ((er == 6 && ec == 6) ? F[LD::IF_G56] : 0.0) - F[LD::IF_SC + er * LD::SCS + ec];
@@ -222,7 +225,7 @@ __device__ __forceinline__ void interface_factor(double* __restrict__ ifb, const
             const double id = r == c7 ? 1.0 : 0.0;
             T.v[r] = grp == 0 ? T.v[r] + id : (grp == 1 ? ah.v[r] : id);
         }
-        ge7_solve(T);                                              // group 1: columns of X = Lambda^-1 Ahat, group 2: of Wi = Lambda^-1
+        cut_ge_solve_dpp<7>(T);                                    // role 1: columns of X = Lambda^-1 Ahat, role 2: of Wi = Lambda^-1
         if (grp == 2 && keep) {
 #pragma unroll
             for (int r = 0; r < 7; ++r) F[LD::IF_WI + r * 8 + cl] = T.v[r];
@@ -303,7 +306,7 @@ __device__ __forceinline__ void interface_apply(const double* __restrict__ ifb, 
 __device__ __forceinline__ void interface_factor2(double* __restrict__ ifb, double* __restrict__ YM, const int lane) {
     using LD = SegLds<2>;
     double* F1 = ifb + LD::IFS;
-    cut_operators2<7, 8>(ifb + LD::IF_SC, LD::SCS, F1 + LD::IF_HZZ, 8, F1[LD::IF_G56], 6, F1 + LD::IF_SC, LD::SCS, F1 + LD::IF_PI, YM, lane);
+    cut_operators2<7, 8, true>(ifb + LD::IF_SC, LD::SCS, F1 + LD::IF_HZZ, 8, F1[LD::IF_G56], 6, F1 + LD::IF_SC, LD::SCS, F1 + LD::IF_PI, YM, lane);
 }
 
 template <int S, int QMASK>

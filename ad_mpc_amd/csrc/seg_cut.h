@@ -64,14 +64,64 @@ __device__ __forceinline__ void cut_ge_solve(ColD<D>& c) {
     });
 }
 
+// The same elimination without a v_readlane: every cross-lane operand -- pivot index, pivot, multipliers, the rows of U in the back substitution -- comes from
+// the matrix lane by DPP row broadcast (v_mov_*_dpp / v_fmac_f64_dpp row_newbcast), the pivot search runs on the vector unit in every lane (the one of
+// matrix lane p counts).  PRECONDITION: a DPP broadcast stays inside its 16-lane row, so every row that holds right-hand sides holds an identical replica of
+// the matrix in its lanes 0 .. D-1 (D <= 8 with groups of eight lanes: matrix | right-hand sides per row).  ~380 instructions against ~570 at D = 7.
+template <int L> __device__ __forceinline__ double cut_bc(double v) {
+    double r; asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L)); return r;
+}
+template <int L> __device__ __forceinline__ int cut_bc_i(int v) {
+    int r; asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L)); return r;
+}
+template <int D>
+__device__ __forceinline__ void cut_ge_solve_dpp(ColD<D>& c) {
+    static_assert(D <= 8, "matrix and right-hand sides share a 16-lane row");
+    double pinv[D];
+    static_for<0, D>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p + 1 < D) {
+            double best = fabs(c.v[p]);
+            int bi = p;
+            static_for<p + 1, D>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                const double v = fabs(c.v[r]);
+                const bool gt = v > best;
+                best = gt ? v : best; bi = gt ? r : bi;
+            });
+            const int bb = cut_bc_i<p>(bi);
+            static_for<p + 1, D>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                const bool sw = bb == r;
+                const double vp = c.v[p], vr = c.v[r];
+                c.v[p] = sw ? vr : vp; c.v[r] = sw ? vp : vr;
+            });
+        }
+        pinv[p] = rcp_nr(cut_bc<p>(c.v[p]));
+        double m[D];
+        static_for<p + 1, D>([&](auto rc) __attribute__((always_inline)) { constexpr int r = decltype(rc)::value; m[r] = -(c.v[r] * pinv[p]); });
+        static_for<p + 1, D>([&](auto rc) __attribute__((always_inline)) { constexpr int r = decltype(rc)::value; fmac_rowbc<p>(c.v[r], m[r], c.v[p]); });
+    });
+    static_for<0, D>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int r = D - 1 - decltype(qc)::value;
+        double sacc = 0.0;
+        static_for<r + 1, D>([&](auto cc) __attribute__((always_inline)) { constexpr int k = decltype(cc)::value; fmac_rowbc<k>(sacc, c.v[r], c.v[k]); });
+        c.v[r] = (c.v[r] - sacc) * pinv[r];
+    });
+}
+
 // The four operators of the cut (one wave).  GS = lanes per group (>= D, 3 GS <= 64): lanes [0, GS) hold the columns of Lambda, [GS, 2 GS) those
 // of Pbb, [2 GS, 3 GS) those of I.  Pbb [r * sb + c], Pi [r * GS + c] (written here from Qzz [r * sq + c] + e6 e6' g66 - Szz [r * ss + c]),
 // Y [4][D][GS] (Y1, Y2, Y3, Y4; row-major).
-template <int D, int GS>
+template <int D, int GS, bool DPPGE = false>
 __device__ __forceinline__ void cut_operators2(const double* Pbb, const int sb, const double* Qzz, const int sq, const double g66, const int i66,
                                                const double* Szz, const int ss, double* Pi, double* Y, const int lane) {
     static_assert(3 * GS <= 64 && GS >= D, "three groups of GS lanes");
-    const int cl = lane % GS, grp = lane / GS;
+    static_assert(!DPPGE || (GS == 8 && D <= 8), "DPP elimination: groups of eight lanes, matrix | right-hand sides in every 16-lane row");
+    // roles of the groups of GS lanes.  Plain: Lambda | Pbb | I.  DPPGE: Lambda | Pbb | Lambda (replica for the second 16-lane row) | I, and again
+    const int cl = lane % GS, g = lane / GS;
+    const int role = DPPGE ? ((g & 3) == 0 || (g & 3) == 2 ? 0 : ((g & 3) == 1 ? 1 : 2)) : (g < 2 ? g : 2);      // 0: Lambda, 1: Pbb, 2: I
+    const bool owner = DPPGE ? (g == 1 || g == 3) : (g == 1 || g == 2);                                           // the one copy of a role that stores
     const int cc = cl < D ? cl : 0;
     ColD<D> pi;
 #pragma unroll
@@ -85,18 +135,18 @@ __device__ __forceinline__ void cut_operators2(const double* Pbb, const int sb, 
     for (int r = 0; r < D; ++r) {
         const double pb = Pbb[r * sb + cc];
         const double id = r == cc ? 1.0 : 0.0;
-        T.v[r] = grp == 0 ? T.v[r] + id : (grp == 1 ? pb : id);
+        T.v[r] = role == 0 ? T.v[r] + id : (role == 1 ? pb : id);
     }
-    cut_ge_solve<D>(T);                                              // group 1: columns of Y2, group 2: columns of Y1
+    if constexpr (DPPGE) cut_ge_solve_dpp<D>(T); else cut_ge_solve<D>(T);      // role 1: columns of Y2, role 2: columns of Y1
     WSYNC();                                                         // Pi is in LDS
     ColD<D> P = cut_mat_col<D>(Pi, GS, T);                           // Pi X
-    if ((grp == 1 || grp == 2) && cl < D) {
-        double* Ya = Y + (grp == 2 ? 0 : D * GS);                    // Y1 / Y2
-        double* Yb = Y + (grp == 2 ? 2 * D * GS : 3 * D * GS);       // Y3 / Y4
+    if (owner && cl < D) {
+        double* Ya = Y + (role == 2 ? 0 : D * GS);                   // Y1 / Y2
+        double* Yb = Y + (role == 2 ? 2 * D * GS : 3 * D * GS);      // Y3 / Y4
 #pragma unroll
         for (int r = 0; r < D; ++r) {
             Ya[r * GS + cl] = T.v[r];
-            Yb[r * GS + cl] = grp == 2 ? -P.v[r] : (r == cl ? 1.0 : 0.0) - P.v[r];
+            Yb[r * GS + cl] = role == 2 ? -P.v[r] : (r == cl ? 1.0 : 0.0) - P.v[r];
         }
     }
 }
