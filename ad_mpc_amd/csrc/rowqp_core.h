@@ -53,8 +53,16 @@
 #define RQ_DBG(...) do { } while (0)
 #endif
 
-#ifndef RQ_PF
-#define RQ_PF 3        // stages in flight in the light sweeps (fp64: 4 would spill to scratch; 2 -> 3 gains 1 % at N = 40)
+// stages in flight in the light sweeps: 3 (2 -> 3 gained 1 % at N = 40).  4 costs fp64 1 % (246 AGPRs of spill space) and gains fp32 3.9 % at configs[4]
+// (3.04 -> 3.16 M solves/s: the kernel waits for its workspace half of the time, SQ_WAIT_ANY 49 % -- 200 MB of stage records live in the MALL, not in
+// L2), but the other build contracts its multiply-adds differently, and in fp32 that moved three instances of 393 216 to 2 - 4e-3 off the fp64
+// minimiser, outside the documented 2.5e-3 (with 3: none above 1.3e-3): not taken (profiles/r4/rowqp_prefetch_depth.txt).  -DRQ_PF=k sets both.
+#ifdef RQ_PF
+#define RQ_PF64 RQ_PF
+#define RQ_PF32 RQ_PF
+#else
+#define RQ_PF64 3
+#define RQ_PF32 3
 #endif
 #define RQ_HDR 16
 #define RQ_RS 31
@@ -97,6 +105,7 @@ struct RowQp {
     typedef typename X::I I;
     typedef typename X::M M;
     typedef typename X::Lds Lds;
+    static constexpr int PF = sizeof(T) == 4 ? RQ_PF32 : RQ_PF64;
 
     const RqParams<T>& q;
     const RqArrays<T>& io;
@@ -315,7 +324,7 @@ struct RowQp {
     }
 
     // S3: backward sweep of the gradient alone (corrector right-hand side: gu = U - smu * UB, gx6 term = X - smu * XB).
-    //     A light loop (about 60 instructions per stage) behind L2-latency loads: RQ_PF stages are kept in flight.
+    //     A light loop (about 60 instructions per stage) behind L2-latency loads: PF stages are kept in flight.
     struct BwdIn { V Gc[6], xk, rk, vu, va, vb, ka, kb; };
     RQ_FN void bwd_load(int k, BwdIn& B) {
         load_gc(k, B.Gc);
@@ -342,21 +351,21 @@ struct RowQp {
     }
     RQ_FN void sweep_backward(V smu) {
         V p = terminal_gx();
-        BwdIn buf[RQ_PF];
+        BwdIn buf[PF];
         RQ_UNROLL
-        for (int j = 0; j < RQ_PF; ++j) bwd_load(N - 1 - j > 0 ? N - 1 - j : 0, buf[j]);
+        for (int j = 0; j < PF; ++j) bwd_load(N - 1 - j > 0 ? N - 1 - j : 0, buf[j]);
         int k0 = N - 1;
         RQ_NOUNROLL
-        for (; k0 - (RQ_PF - 1) >= 0; k0 -= RQ_PF) {                // full groups: straight-line code, the ring slots are consumed in
+        for (; k0 - (PF - 1) >= 0; k0 -= PF) {                // full groups: straight-line code, the ring slots are consumed in
             RQ_UNROLL                                               // place and reloaded (no register rotation, exact wait counts)
-            for (int j = 0; j < RQ_PF; ++j) {
+            for (int j = 0; j < PF; ++j) {
                 const int k = k0 - j;
                 bwd_stage(k, buf[j], smu, p);
-                bwd_load(k - RQ_PF > 0 ? k - RQ_PF : 0, buf[j]);
+                bwd_load(k - PF > 0 ? k - PF : 0, buf[j]);
             }
         }
         RQ_UNROLL
-        for (int j = 0; j < RQ_PF - 1; ++j)                         // the last N mod RQ_PF stages (their data is in the first slots)
+        for (int j = 0; j < PF - 1; ++j)                         // the last N mod PF stages (their data is in the first slots)
             if (k0 - j >= 0) bwd_stage(k0 - j, buf[j], smu, p);
     }
 
@@ -398,7 +407,7 @@ struct RowQp {
 
     // S2 / S4: forward roll-out of the Newton step: ddu_k = K_k ddx_k + kff_k (into U), ddx_{k+1} = A ddx_k + B ddu_k.
     //     full = false (predictor): only ddx6_{k+1} is kept (Q1 of stage k+1);  full = true: ddx_{k+1} into D, ddx6 also into X.
-    //     A light loop (about 50 instructions per stage) behind L2-latency loads: RQ_PF stages are kept in flight.
+    //     A light loop (about 50 instructions per stage) behind L2-latency loads: PF stages are kept in flight.
     struct FwdIn { V Gr[7], ka, kb, kff; };
     RQ_FN void fwd_load(int k, FwdIn& F) {
         load_gr(k, F.Gr);
@@ -417,21 +426,21 @@ struct RowQp {
     }
     RQ_FN void sweep_forward(bool full) {
         V z = splat((T)0);
-        FwdIn buf[RQ_PF];
+        FwdIn buf[PF];
         RQ_UNROLL
-        for (int j = 0; j < RQ_PF; ++j) fwd_load(j < N ? j : N - 1, buf[j]);
+        for (int j = 0; j < PF; ++j) fwd_load(j < N ? j : N - 1, buf[j]);
         int k0 = 0;
         RQ_NOUNROLL
-        for (; k0 + RQ_PF <= N; k0 += RQ_PF) {                      // full groups: straight-line code (see sweep_backward)
+        for (; k0 + PF <= N; k0 += PF) {                      // full groups: straight-line code (see sweep_backward)
             RQ_UNROLL
-            for (int j = 0; j < RQ_PF; ++j) {
+            for (int j = 0; j < PF; ++j) {
                 const int k = k0 + j;
                 fwd_stage(k, buf[j], full, z);
-                fwd_load(k + RQ_PF < N ? k + RQ_PF : N - 1, buf[j]);
+                fwd_load(k + PF < N ? k + PF : N - 1, buf[j]);
             }
         }
         RQ_UNROLL
-        for (int j = 0; j < RQ_PF - 1; ++j)
+        for (int j = 0; j < PF - 1; ++j)
             if (k0 + j < N) fwd_stage(k0 + j, buf[j], full, z);
     }
 
@@ -614,7 +623,7 @@ struct RowQp {
     }
 
     // E3b + E1: apply the corrector step with step length alpha on the rows of rowact, then the quantities of the next iteration
-    //     from the updated state, still in registers.  Returns the row's max |alpha ddu|.
+    //     from the updated state, still in registers.  Returns the row's max |alpha ddu| (fp32: max |ddu|).
     RQ_FN V pass_e3b_e1(V smu, V alpha, M rowact, Red& R) {
         const V zero = splat((T)0);
         V stp = zero;
@@ -632,7 +641,12 @@ struct RowQp {
             S.tb = X::sel(rowact, X::vmax(fma(alpha, C.dtb, S.tb), fl), S.tb); S.lb = X::sel(rowact, X::vmax(fma(alpha, C.dlb, S.lb), fl), S.lb);
             S.ts = X::sel(rowact, X::vmax(fma(alpha, C.dts, S.ts), fl), S.ts); S.ls = X::sel(rowact, X::vmax(fma(alpha, C.dls, S.ls), fl), S.ls);
             const V au = X::sel(rowact, alpha * S.sc, zero);                 // alpha * ddu_j (inputs), alpha * ddx6 (steering)
-            stp = X::vmax(stp, X::sel(S.act & e_in, X::vabs(au), zero));
+            // what the step test sees.  fp64: the step taken, alpha * ddu (the oracle's rule).  fp32: the Newton step itself -- its looser
+            // complementarity / residual levels are no safety net, and a BLOCKED step (alpha ~ 1e-3) is short without being converged: one
+            // instance of 196 608 then stopped 0.3 off the minimiser with status 0 (found when a different FMA contraction moved the
+            // rounding: profiles/r4/f32_step_test.txt)
+            const V sv = sizeof(T) == 4 ? X::sel(rowact, S.sc, zero) : au;
+            stp = X::vmax(stp, X::sel(S.act & e_in, X::vabs(sv), zero));
             S.vabs = S.vabs + au;
             st(S.kl + jin + RQ_UA, 0, S.vabs, S.stv & e_in);
             st(S.kl + o_tb, RQ_T, S.tb, S.act); st(S.kl + o_tb, RQ_LAM, S.lb, S.act);
