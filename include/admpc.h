@@ -123,7 +123,8 @@ typedef struct AdmpcConfig {
                                 * test: tol_comp = tol_res = 1e-8, tol_step = 1e30 (off).  Tighter levels (1e-10 / 1e-9 / 1e-6, the
                                 * defaults of earlier versions) take instances with a nearly degenerate bound pair from ~1e-4 to within
                                 * 1e-8 of the exact minimiser for one to four more iterations.  fp32 entry point: floors 1e-3 / 1e-2 and
-                                * ALWAYS a step test (the configured one when it lies in [1e-3, 1], else 1e-3). */
+                                * ALWAYS a step test (the configured one when it lies in [1e-3, 1], else 1e-3), applied to the Newton step
+                                * max|ddu| itself: a blocked step (alpha ~ 1e-3) is short without being converged. */
     double  ipm_try_unconstrained; /* != 0: first solve the QP without its inequalities (one factorisation + one solve);
                                     * if that minimiser respects every bound it IS the QP solution (iters = 0) and the
                                     * interior point is skipped.  Default 1 (all device paths and the oracle). */
