@@ -20,7 +20,8 @@ def count(path, verbose=False):
     bad = 0
     for line in open(path):
         t = line.split(';')[0].strip()
-        if not t or t[0] == '.' or t.endswith(':'): continue
+        if t.endswith(':') and t.startswith('.LBB'): queue = []     # a basic-block entry: the text above is not (only) its predecessor.  The un-waited
+        if not t or t[0] == '.' or t.endswith(':'): continue        # reads this check is about live in straight-line, fully unrolled assembly
         op = t.split()[0]
         args = [a.strip() for a in t[len(op):].split(',')]
         if op.startswith('s_waitcnt'):
@@ -28,7 +29,7 @@ def count(path, verbose=False):
             if m:
                 n = int(m.group(1)); queue = queue[len(queue) - n:] if n else []
             continue
-        if op.startswith(('s_endpgm', 's_barrier')): queue = []; continue
+        if op.startswith(('s_endpgm', 's_barrier', 's_branch', 's_setpc')): queue = []; continue
         is_store = op.startswith(('ds_write', 'global_store', 'scratch_store', 'buffer_store'))
         srcs = set()
         for a in (args if is_store else args[1:]):
