@@ -1104,20 +1104,24 @@ __attribute__((visibility("hidden"))) void admpc_fused20_prepare(void)
     // 25.6 KB per workgroup: below the 64 KB default, no opt-in needed; kept for symmetry with the other units
 }
 
-// sched ints of a handle that solves up to `cap` instances per call (zeroed once at allocation; the kernel re-arms the header)
-__attribute__((visibility("hidden"))) size_t admpc_fused20_sched_ints(int cap) { return (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap; }
+// sched ints of a handle that solves up to `cap` instances per call: TWO scheduler states used alternately (zeroed at allocation; the order kernel of a
+// launch zeroes the header of the next launch's state, the last workgroup to leave re-arms its own: no memset in front of a launch -- a hipMemsetAsync
+// there cost 2 us per step at configs[1] and 26 us at N = 40)
+__attribute__((visibility("hidden"))) size_t admpc_fused20_sched_ints(int cap) { return 2 * ((size_t)F20_HDR + (size_t)F20_NB * (size_t)cap); }      // two states (work_order.h)
 
 // grid: persistent, eight one-wave workgroups per CU (two waves per SIMD); slotbuf: admpc_fused20_slot_doubles(num_cu) doubles
 __attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* slotbuf)
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched2, int cap, int flip, double* slotbuf)
 {
     const int lds = FusedLds::total * (int)sizeof(double);
     int grid = num_cu * 8; if (grid > B) grid = B;
     // every launch pair is self-contained: ticket counter, exit counter and bin counts start from zero on the caller's stream (the last
     // workgroup to leave re-arms them as well; a launch that failed half-way, or a handle misused from two streams, cannot poison the next)
-    (void)hipMemsetAsync(sched, 0, F20_HDR * sizeof(int), st);
-    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap);
+    const size_t one = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
+    int* const sched = sched2 + (flip ? one : 0);
+    int* const sched_next = sched2 + (flip ? 0 : one);
+    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap, sched_next);
     if (qmask == 7)
         hipLaunchKernelGGL((admpc_fused20_kernel<7>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);
     else

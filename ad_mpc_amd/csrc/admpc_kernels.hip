@@ -1287,7 +1287,8 @@ struct AdmpcSolver {
     int dense_lds_bytes;
     int n20_fused;           // N = 20 fp64 steps run the fused persistent kernel (admpc_fused20.hip); 0: the four-kernel pipeline (ADMPC_N20=split)
     int use_seg;             // N = 40 / 60 / 80 fp64 steps without GP models run the segmented condensed kernel (admpc_seg.hip; with GP models on ADMPC_QP=seg); ADMPC_QP=riccati: kernel R
-    int* d_tick;             // [128 + 64 cap_fused] tickets, exit counter and work-order bins of the fused kernel (zeroed at allocation; the kernel re-arms them)
+    int* d_tick;             // 2 x [128 + 64 cap_fused] tickets, exit counter and work-order bins of the persistent kernels: two states used alternately (work_order.h)
+    int tick_flip;           // which of the two the last launch used
     int cap_fused;
     double* d_slot;          // per-wave slot buffers of the fused kernel (the linearisation across the interior point), allocated at its first launch
     // Workspaces, each grown on demand by the path that needs it (admpc_reserve sizes the handle's default path up front):
@@ -1343,14 +1344,14 @@ extern "C" void admpc_rowqp_launch_f32(int grid, int lds_bytes, hipStream_t st, 
 // fused N = 20 step (admpc_fused20.hip)
 extern "C" void admpc_fused20_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* slotbuf);
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched2, int cap, int flip, double* slotbuf);
 extern "C" size_t admpc_fused20_slot_doubles(int num_cu);
 extern "C" size_t admpc_fused20_sched_ints(int cap);
 // segmented condensed step, N = 40 / 60 / 80 fp64 (admpc_seg.hip)
 extern "C" int admpc_seg_supports(int N);
 extern "C" void admpc_seg_launch(int N, int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot);
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched2, int cap, int flip, double* hslot);
 extern "C" size_t admpc_seg_slot_doubles(int num_cu);
 
 extern "C" {
@@ -1417,7 +1418,7 @@ int admpc_create(const AdmpcConfig* cfg, int device, AdmpcSolver** out)
         int r_, st_, lb_, g_;
         if (admpc_rowqp_plan(cfg->N, 8, 1, s->num_cu, &r_, &st_, &lb_, &g_) != 0) { delete s; return fail(ADMPC_EINVAL, "horizon too long for the LDS-resident kernel"); }
     }
-    s->cap = s->cap_lin = s->cap_dense = s->cap_row = 0; s->row_elem = 8; s->sched_cap = 0; s->d_tick = nullptr; s->d_slot = nullptr; s->cap_fused = 0;
+    s->cap = s->cap_lin = s->cap_dense = s->cap_row = 0; s->row_elem = 8; s->sched_cap = 0; s->d_tick = nullptr; s->tick_flip = 0; s->d_slot = nullptr; s->cap_fused = 0;
     s->d_GT = nullptr; s->d_bl = nullptr; s->d_status = nullptr; s->d_H = nullptr; s->d_aux = nullptr; s->d_ws = nullptr; s->d_pairs = nullptr; s->d_split = nullptr; s->d_dump = nullptr; s->d_mult = nullptr; s->cap_mult = 0; s->mult_elem = 0;
     {   // ADMPC_ROWQP_SPLIT=0 / 1: never / always run the row kernel in two phases (A/B tests); default: by batch size
         const char* e = getenv("ADMPC_ROWQP_SPLIT");
@@ -1710,7 +1711,7 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
         // N = 40 / 60 / 80: S cooperating waves per instance, each condensing 20 stages; no workspace, no kernel boundary (admpc_seg.hip)
         int rc = ensure_fused(s, B); if (rc) return rc;
         for (int sq = 0; sq < nsqp; ++sq)
-            admpc_seg_launch(N, s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (sq == 0 && !routed) ? 1 : 0, s->d_tick, s->cap_fused, s->d_slot);
+            admpc_seg_launch(N, s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, (sq == 0 && !routed) ? 1 : 0, s->d_tick, s->cap_fused, (s->tick_flip ^= 1), s->d_slot);
         HIPCHK(hipGetLastError());
         return ADMPC_OK;
     }
@@ -1728,7 +1729,7 @@ static int solve_impl(AdmpcSolver* s, int B, const double* x0, const double* yre
         const int first = (sq == 0 && !routed) ? 1 : 0;
         if (fused) {
             // shooting, condensing, interior point and expansion of an instance in one persistent kernel: no workspace, no kernel boundary
-            admpc_fused20_launch(s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, s->d_tick, s->cap_fused, s->d_slot);
+            admpc_fused20_launch(s->num_cu, st, s->d_cfg, B, s->qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, s->d_tick, s->cap_fused, (s->tick_flip ^= 1), s->d_slot);
             continue;
         }
 #ifdef ADMPC_LEGACY_N20      // the four-kernel pipeline of rounds 1-2 (`make legacy`, ADMPC_N20=split)

@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
 template <int S>
 static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot)
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched2, int cap, int flip, double* hslot)
 {
     const int lds = SegLds<S>::total * (int)sizeof(double);
     // persistent grid: as many workgroups per CU as LDS (160 KB) and wave slots (two per SIMD) allow
@@ -1293,10 +1293,11 @@ static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int
         (void)hipFuncSetAttribute((const void*)admpc_seg_kernel<S, 127>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         prepared = true;
     }
-    // every launch pair is self-contained: ticket counter, exit counter and bin counts start from zero on the caller's stream (the last
-    // workgroup to leave re-arms them as well; a launch that failed half-way, or a handle misused from two streams, cannot poison the next)
-    (void)hipMemsetAsync(sched, 0, F20_HDR * sizeof(int), st);
-    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap);
+    // two scheduler states, used alternately: the order kernel of this launch zeroes the header of the next (work_order.h)
+    const size_t one = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
+    int* const sched = sched2 + (flip ? one : 0);
+    int* const sched_next = sched2 + (flip ? 0 : one);
+    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap, sched_next);
     if (qmask == 7)
         hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot);
     else
@@ -1365,20 +1366,20 @@ __attribute__((visibility("hidden"))) int admpc_seg_lds_bytes(int N)
     }
 }
 
-// grid: persistent workgroups of S waves; sched: admpc_fused20_sched_ints(cap) ints, zeroed at allocation (the kernel re-arms them)
+// grid: persistent workgroups of S waves; sched2: admpc_fused20_sched_ints(cap) ints = two scheduler states, flip selects this launch's (admpc_fused20.hip)
 __attribute__((visibility("hidden"))) void admpc_seg_launch(int N, int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
         const double* x0, const double* yref, const double* yref_e, const double* p, double* xbar, double* ubar,
-        double* cost, int32_t* stat, int32_t* iters, int first, int* sched, int cap, double* hslot)
+        double* cost, int32_t* stat, int32_t* iters, int first, int* sched2, int cap, int flip, double* hslot)
 {
     switch (N / 20) {
 #ifndef SEG_DEV_ONLY_S4
-        case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+        case 2: seg_launch<2>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched2, cap, flip, hslot); break;
 #endif
 #if defined(SEG_DEV_ONLY_S4)
-        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched2, cap, flip, hslot); break;
 #elif !defined(SEG_DEV_ONLY_S2)      // development builds: one instantiation compiles in a third of the time
-        case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
-        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot); break;
+        case 3: seg_launch<3>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched2, cap, flip, hslot); break;
+        default: seg_launch<4>(num_cu, st, d_cfg, B, qmask, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched2, cap, flip, hslot); break;
 #else
         default: break;
 #endif

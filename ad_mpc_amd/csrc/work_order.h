@@ -25,8 +25,12 @@ __device__ const int* g_order_hint = nullptr;
 #endif
 __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig* __restrict__ cfg, int B, const double* __restrict__ x0g,
                                                                const double* __restrict__ yrefg, const double* __restrict__ yrefeg,
-                                                               int* __restrict__ sched, int cap)
+                                                               int* __restrict__ sched, int cap, int* __restrict__ sched_next)
 {
+    // The handle keeps TWO scheduler states and alternates between them: this launch zeroes the header of the NEXT one (nobody is using it: the
+    // previous launch of the stream is complete), so every launch pair starts from a clean header without a memset of its own in front of it
+    // (2 us of a 200 us step at configs[1]), and a launch that failed half-way cannot poison the one after the next either.
+    if (blockIdx.x == 0 && threadIdx.x < F20_HDR) sched_next[threadIdx.x] = 0;
     // Bin counts are aggregated per block in LDS and reach the global counters as ONE atomic per (block, bin): 2000 of 4096 config-2
     // instances share bin 0, and one global atomic each on that word took 22 us -- a tenth of the step.
     __shared__ int cnt[F20_NB], base[F20_NB];
