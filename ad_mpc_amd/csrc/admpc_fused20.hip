@@ -1121,11 +1121,12 @@ __attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipS
     const size_t one = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
     int* const sched = sched2 + (flip ? one : 0);
     int* const sched_next = sched2 + (flip ? 0 : one);
-    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap, sched_next);
+    const int kcap = grid == B ? 0 : cap;      // the batch fits the grid: no work order (work_order.h: f20_next)
+    if (kcap) hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap, sched_next);
     if (qmask == 7)
-        hipLaunchKernelGGL((admpc_fused20_kernel<7>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);
+        hipLaunchKernelGGL((admpc_fused20_kernel<7>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, kcap, slotbuf);
     else
-        hipLaunchKernelGGL((admpc_fused20_kernel<127>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, slotbuf);
+        hipLaunchKernelGGL((admpc_fused20_kernel<127>), dim3(grid), dim3(WAVE), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, kcap, slotbuf);
 }
 
 }

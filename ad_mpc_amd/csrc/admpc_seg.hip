@@ -1297,11 +1297,12 @@ static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int
     const size_t one = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
     int* const sched = sched2 + (flip ? one : 0);
     int* const sched_next = sched2 + (flip ? 0 : one);
-    hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap, sched_next);
+    const int kcap = grid == B ? 0 : cap;      // the batch fits the grid: no work order (work_order.h: f20_next)
+    if (kcap) hipLaunchKernelGGL(admpc_f20_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_cfg, B, x0, yref, yref_e, sched, cap, sched_next);
     if (qmask == 7)
-        hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot);
+        hipLaunchKernelGGL((admpc_seg_kernel<S, 7>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, kcap, hslot);
     else
-        hipLaunchKernelGGL((admpc_seg_kernel<S, 127>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, cap, hslot);
+        hipLaunchKernelGGL((admpc_seg_kernel<S, 127>), dim3(grid), dim3(WAVE * S), lds, st, d_cfg, B, x0, yref, yref_e, p, xbar, ubar, cost, stat, iters, first, sched, kcap, hslot);
 }
 
 // ---- host side (called by solve_impl in admpc_kernels.hip)

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig*
 
 // next instance for a persistent wave (wave-uniform), -1 when the batch is drained: tickets walk the bins from the most expensive
 // down.  First ticket = block index (2048 simultaneous atomics on one word queue up for ~20 us), later ones from the counter.
+// cap == 0: no work order -- the batch fits the grid (one instance per workgroup, all start at once: nothing to order, and the launch
+// function has not run the pre-pass: 5 - 8 us less latency for a small batch, the reference's own use is B = 1).
 __device__ __forceinline__ int f20_next(int* __restrict__ sched, int cap, bool first, int lane) {
+    if (cap == 0) return first ? (int)blockIdx.x : -1;
     int t = blockIdx.x;
 #if defined(F20_PAIR_REV) && F20_PAIR_REV        // experiment: the second wave of a SIMD takes the EASIEST of the first round's tickets (block b + G/2 shares the SIMD of block b)
     if (t >= (int)gridDim.x / 2) t = (int)gridDim.x + (int)gridDim.x / 2 - 1 - t;
