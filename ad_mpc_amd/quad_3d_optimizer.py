@@ -5,6 +5,7 @@ last-row padding of short trajectories, persistent never-shifted iterate).  One 
 from copy import copy
 
 import numpy as np
+import torch
 
 from .quad_config import default_quad_config, QNX, QNU
 
@@ -118,6 +119,10 @@ class Quad3DOptimizer:
         self.x_iter = [np.zeros((self.N + 1, QNX)) for _ in range(K)]; self.u_iter = [np.zeros((self.N, QNU)) for _ in range(K)]
         self.target = None
         self.status = 0
+        from .engine import PackedIO
+        from .quad_config import QNY
+        self._io = PackedIO(self.solver.device, (("x0", (1, QNX)), ("yref", (1, self.N, QNY)), ("yref_e", (1, QNX)), ("gp", (1, QNX)),
+                                                 ("x", (1, self.N + 1, QNX)), ("u", (1, self.N, QNU))), (("cost", (1,)),))
 
     def set_reference_state(self, x_target=None, u_target=None):
         """:430-463.  The velocity of the point reference goes to the body frame (the reference does that to the yref it sets)."""
@@ -164,10 +169,16 @@ class Quad3DOptimizer:
         gp_state = None
         if self.with_gp and gp_regression_state is not None:      # :546-552: p = [gp_state, 1] at node 0 (default: the initial state)
             gp_state = np.asarray(gp_regression_state, dtype=np.float64).reshape(1, QNX)
-        x, u, cost, st, it = self.solvers[m].solve_numpy(x_init, self.yref[m][None], self.yref_e[m][None], self.x_iter[m][None], self.u_iter[m][None],
-                                                         gp_state=gp_state)
-        self.status = int(st[0])
+        io, sv = self._io, self.solvers[m]
+        io.put("x0", x_init); io.put("yref", self.yref[m]); io.put("yref_e", self.yref_e[m]); io.put("gp", x_init if gp_state is None else gp_state)
+        io.put("x", self.x_iter[m]); io.put("u", self.u_iter[m])
+        with torch.cuda.device(io.device):
+            io.upload()
+            sv.solve(io.dev("x0"), io.dev("yref"), io.dev("yref_e"), io.dev("x"), io.dev("u"), io.dev("cost"), io.dint[0:1], io.dint[1:2],
+                     gp_state=None if gp_state is None else io.dev("gp"))
+            io.download("x")
+        self.status = int(io.hi[0])
         if self.status in (0, 2):                 # 2: solver_type "SQP" at its iteration limit -- acados keeps (and so returns) the last iterate
-            self.x_iter[m], self.u_iter[m] = x[0], u[0]
+            self.x_iter[m], self.u_iter[m] = io.take("x")[0], io.take("u")[0]
         w_opt = np.reshape(self.u_iter[m].copy(), (-1))
         return w_opt if not return_x else (w_opt, self.x_iter[m].copy())
