@@ -36,6 +36,12 @@
 #ifndef F20_MFMA
 #define F20_MFMA 1
 #endif
+#ifndef F20_CPREF
+#define F20_CPREF 0
+#endif
+#ifndef F20_TOKTRAP
+#define F20_TOKTRAP 0
+#endif
 
 namespace {
 
@@ -513,13 +519,14 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             double Qd[NX], Qe[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cf->W[i]; Qe[i] = cf->We[i]; }
-            double xh[NX];
+            // the carried columns in two sets used alternately (stage k reads set k & 1 and writes the other one): with one set the
+            // results of a stage were copied into it behind every stage (the stages are separate basic blocks: ten v_mov_b64 each)
+            double xh2[2][NX], g2[2][NX];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) xh[c] = x0g[(size_t)inst * NX + c] - xbg[c];      // uniform
+            for (int c = 0; c < NX; ++c) { xh2[0][c] = x0g[(size_t)inst * NX + c] - xbg[c]; xh2[1][c] = 0.0; }      // uniform
             WSYNC();
-            double g[NX];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) g[c] = 0.0;
+            for (int c = 0; c < NX; ++c) { g2[0][c] = 0.0; g2[1][c] = 0.0; }
 #if F20_MFMA
             // H on the matrix pipe: six 16 x 16 tiles (I >= J) of v_mfma_f64_16x16x4_f64.  One MFMA step takes K = 4 rows of the
             // 60 x 40 matrix G whose rows are the weighted components of Gamma_k: per stage the components of QMASK, four at a time
@@ -561,15 +568,41 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 constexpr int k = decltype(kc)::value;
                 constexpr int lim = 2 * k < n ? 2 * k : n;        // inputs of stages < k (even)
                 constexpr int nblk = (lim + 15) / 16;             // 16-lane blocks of Gamma that are non-zero at this stage
+                double (&g)[NX] = g2[k & 1]; double (&xh)[NX] = xh2[k & 1];
+                double (&gn)[NX] = g2[(k + 1) & 1]; double (&xn)[NX] = xh2[(k + 1) & 1];
                 // One stage = one basic block (an always-true test the compiler cannot see through): merged into one 21-stage block,
                 // hipcc hoists every LDS load of the whole instance and spills ~1600 registers.
                 int tok = B; asm volatile("" : "+s"(tok));
+#if F20_TOKTRAP
+                // the never-taken side of the test ends the program instead of joining the stage: no phi nodes behind the stage, i.e. no
+                // copies of the carried columns (g, xh: ten v_mov_b64 per stage) into the registers the skipped path would have kept
+                if (tok <= 0) __builtin_trap();
+                {
+#else
                 if (tok > 0) {
+#endif
                 double wg[NX];
 #if F20_MFMA
                 double blk[NSTEP][3];
 #else
                 double Rb[NX][3];
+#endif
+#if F20_CPREF
+                // Every LDS read of the stage's record is issued before anything else of the stage: left to itself hipcc keeps one or two
+                // ds_read_b128 in flight and the propagation (60 multiply-adds behind 21 reads) waits on each of them in turn.
+                double2 Av[15], Bv[3]; double blv[NX];
+                const bool mine_p = ki == k;
+                if constexpr (k < N) {
+                    const double* Gk = GT + k * GTS;
+                    const double* const bsrc = mine_p ? Gk + 5 * 6 + 6 * ji : gam + 7 * 64;
+#pragma unroll
+                    for (int q_ = 0; q_ < 15; ++q_) Av[q_] = *reinterpret_cast<const double2*>(Gk + 2 * q_);
+#pragma unroll
+                    for (int q_ = 0; q_ < 3; ++q_) Bv[q_] = *reinterpret_cast<const double2*>(bsrc + 2 * q_);
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) blv[r] = bl[k * 7 + r];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #endif
                 if constexpr (k >= 1) {
                     if (lane == k) xh6_own = xh[6];
@@ -597,12 +630,41 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                     });
 #endif
                 }
-                double xn[NX], gn[NX];
                 if constexpr (k < N) {
                     const double* Gk = GT + k * GTS;
+                    // The inputs of stage k enter with B_k: lanes 2k, 2k + 1 (whose column of Gamma is still zero) start the product from
+                    // their column of B_k, every other lane from the zero row of gam -- one per-lane LDS address instead of 28 selects
+                    // per stage (560 vector instructions per instance); 0 + A_k 0 = 0 exactly: the same bits as the selects gave.
+                    const bool mine = ki == k;
+#if F20_CPREF
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) { xn[r] = bl[k * 7 + r] + (r < 2 ? xh[r] : 0.0); gn[r] = r < 2 ? g[r] : 0.0; }
-                    xn[6] = bl[k * 7 + 6] + xh[6]; gn[6] = g[6];
+                    for (int r = 0; r < 6; r += 2) { gn[r] = Bv[r / 2].x; gn[r + 1] = Bv[r / 2].y; }
+                    gn[0] += g[0]; gn[1] += g[1];
+                    gn[6] = mine ? (ji ? h : 0.0) : g[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xn[r] = r < 2 ? blv[r] + xh[r] : blv[r];
+                    xn[6] = blv[6] + xh[6];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+#pragma unroll
+                        for (int r = 0; r < 6; r += 2) {
+                            const double2 a = Av[c * 3 + r / 2];
+                            xn[r] += a.x * xh[c + 2]; xn[r + 1] += a.y * xh[c + 2];
+                            gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
+                        }
+                    }
+#else
+                    const double* const bsrc = mine ? Gk + 5 * 6 + 6 * ji : gam + 7 * 64;
+#pragma unroll
+                    for (int r = 0; r < 6; r += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(bsrc + r);
+                        gn[r] = v.x; gn[r + 1] = v.y;
+                    }
+                    gn[0] += g[0]; gn[1] += g[1];
+                    gn[6] = mine ? (ji ? h : 0.0) : g[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xn[r] = r < 2 ? bl[k * 7 + r] + xh[r] : bl[k * 7 + r];
+                    xn[6] = bl[k * 7 + 6] + xh[6];
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
 #pragma unroll
@@ -612,18 +674,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                             gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
                         }
                     }
-                    const bool mine = ki == k;
-                    double bb[12];
-#pragma unroll
-                    for (int r = 0; r < 12; r += 2) {
-                        const double2 v = *reinterpret_cast<const double2*>(Gk + 5 * 6 + r);
-                        bb[r] = v.x; bb[r + 1] = v.y;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 12; ++r) asm volatile("" : "+v"(bb[r]));
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) gn[r] = mine ? (ji ? bb[6 + r] : bb[r]) : gn[r];
-                    gn[6] = mine ? (ji ? h : 0.0) : gn[6];
+#endif
                 }
 #if F20_MFMA
                 if constexpr (k >= 1) {
@@ -658,10 +709,6 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                     });
                 }
 #endif
-                if constexpr (k < N) {
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; }
-                }
                 }
             });
 #if F20_MFMA

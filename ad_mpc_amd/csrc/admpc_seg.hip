@@ -31,6 +31,9 @@
 #define IPM_FLOOR 1e-40
 #define GTS 42           // values per stage of the packed linearisation (see kernel A in admpc_kernels.hip)
 
+#ifndef SEG_CPREF
+#define SEG_CPREF 0
+#endif
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -572,13 +575,13 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
             double Qd[NX], Qe[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { Qd[i] = Ts * cf->W[i]; Qe[i] = cf->We[i]; }
-            double xh[NX];
+            // the carried columns in two sets used alternately (stage k reads set k & 1 and writes the other one, see admpc_fused20.hip)
+            double xh2[2][NX], g2[2][NX];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) xh[c] = first ? x0g[(size_t)inst * NX + c] - xbg[c] : 0.0;      // uniform
+            for (int c = 0; c < NX; ++c) { xh2[0][c] = first ? x0g[(size_t)inst * NX + c] - xbg[c] : 0.0; xh2[1][c] = 0.0; }      // uniform
             WSYNC();
-            double g[NX];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) g[c] = (!first && lane == n + c) ? 1.0 : 0.0;
+            for (int c = 0; c < NX; ++c) { g2[0][c] = (!first && lane == n + c) ? 1.0 : 0.0; g2[1][c] = 0.0; }
             constexpr int NCOMP = ((QMASK >> 0) & 1) + ((QMASK >> 1) & 1) + ((QMASK >> 2) & 1) + ((QMASK >> 3) & 1) + ((QMASK >> 4) & 1) + ((QMASK >> 5) & 1) + ((QMASK >> 6) & 1);
             constexpr int NSTEP = (NCOMP + 3) / 4;
             const int r16 = lane & 15, kq = lane >> 4;
@@ -608,6 +611,8 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 constexpr int k = decltype(kc)::value;
                 constexpr int lim = 2 * k < n ? 2 * k : n;
                 constexpr int nblk = (lim + 15) / 16;             // 16-lane blocks of Gamma that are non-zero at this stage (first segment)
+                double (&g)[NX] = g2[k & 1]; double (&xh)[NX] = xh2[k & 1];
+                double (&gn)[NX] = g2[(k + 1) & 1]; double (&xn)[NX] = xh2[(k + 1) & 1];
                 int tok = B; asm volatile("" : "+s"(tok));         // one stage = one basic block (see admpc_fused20.hip)
                 if (tok > 0) {
                 // the tracking cost of stage k0 + k belongs to this segment unless it is the fixed first stage of the horizon or the
@@ -615,6 +620,21 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 const bool cost_k = k == 0 ? !first : (k == N ? last : true);
                 double wg[NX];
                 double blk[NSTEP][3];
+#if SEG_CPREF
+                // every LDS read of the stage's record is issued before anything else of the stage (see admpc_fused20.hip)
+                double2 Av[15], Bv[3]; double blv[NX];
+                if constexpr (k < N) {
+                    const double* Gk = GT + k * GTS;
+                    const double* const bsrc = ki == k ? Gk + 5 * 6 + 6 * ji : gam + 7 * 64;
+#pragma unroll
+                    for (int q_ = 0; q_ < 15; ++q_) Av[q_] = *reinterpret_cast<const double2*>(Gk + 2 * q_);
+#pragma unroll
+                    for (int q_ = 0; q_ < 3; ++q_) Bv[q_] = *reinterpret_cast<const double2*>(bsrc + 2 * q_);
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) blv[r] = bl[k * 7 + r];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 if constexpr (k < N) { if (lane == k) xh6_own = xh[6]; }
                 if (cost_k) {
                     static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
@@ -634,33 +654,44 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                             else blk[st_][m] = 0.0;
                         }
                 }
-                double xn[NX], gn[NX];
                 if constexpr (k < N) {
                     const double* Gk = GT + k * GTS;
+                    // The inputs of stage k enter with B_k: lanes 2k, 2k + 1 (whose column of Gamma is still zero) start the product from
+                    // their column of B_k, every other lane from the zero row of gam -- one per-lane LDS address instead of 28 selects
+                    // per stage (560 vector instructions per instance); 0 + A_k 0 = 0 exactly: the same bits as the selects gave.
+                    const bool mine = ki == k;
+#if SEG_CPREF
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) { xn[r] = bl[k * 7 + r] + (r < 2 ? xh[r] : 0.0); gn[r] = r < 2 ? g[r] : 0.0; }
-                    xn[6] = bl[k * 7 + 6] + xh[6]; gn[6] = g[6];
+                    for (int r = 0; r < 6; r += 2) { gn[r] = Bv[r / 2].x; gn[r + 1] = Bv[r / 2].y; }
+#else
+                    const double* const bsrc = mine ? Gk + 5 * 6 + 6 * ji : gam + 7 * 64;
+#pragma unroll
+                    for (int r = 0; r < 6; r += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(bsrc + r);
+                        gn[r] = v.x; gn[r + 1] = v.y;
+                    }
+                    double blv[NX];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) blv[r] = bl[k * 7 + r];
+#endif
+                    gn[0] += g[0]; gn[1] += g[1];
+                    gn[6] = mine ? (ji ? h : 0.0) : g[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xn[r] = r < 2 ? blv[r] + xh[r] : blv[r];
+                    xn[6] = blv[6] + xh[6];
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
 #pragma unroll
                         for (int r = 0; r < 6; r += 2) {
+#if SEG_CPREF
+                            const double2 a = Av[c * 3 + r / 2];
+#else
                             const double2 a = *reinterpret_cast<const double2*>(Gk + c * 6 + r);
+#endif
                             xn[r] += a.x * xh[c + 2]; xn[r + 1] += a.y * xh[c + 2];
                             gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
                         }
                     }
-                    const bool mine = ki == k;
-                    double bb[12];
-#pragma unroll
-                    for (int r = 0; r < 12; r += 2) {
-                        const double2 v = *reinterpret_cast<const double2*>(Gk + 5 * 6 + r);
-                        bb[r] = v.x; bb[r + 1] = v.y;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 12; ++r) asm volatile("" : "+v"(bb[r]));
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) gn[r] = mine ? (ji ? bb[6 + r] : bb[r]) : gn[r];
-                    gn[6] = mine ? (ji ? h : 0.0) : gn[6];
                 }
                 if (cost_k) {
 #pragma unroll
@@ -677,12 +708,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         });
                     }
                 }
-                if constexpr (k < N) {
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) { g[r] = gn[r]; xh[r] = xn[r]; }
-                }
                 }
             });
+            double (&g)[NX] = g2[N & 1]; double (&xh)[NX] = xh2[N & 1];        // what the last stage left
             // ---- the cut behind the segment: Abar_s (columns in lanes 40..46), c_s; then the free chain z^cold of the cold start
             if (!last) {
                 if (!first && lane >= n && lane < n + 7) {

@@ -98,6 +98,11 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     const T psi = x[2], vx = x[3], vy = x[4], r = x[5], dl = x[6];
     const T m = (T)c->mass, LF = (T)c->L_F, LR = (T)c->L_R, Iz = (T)c->Iz, Cf = (T)c->Cf, Cr = (T)c->Cr;
     const T L = LR + LF;
+    // The wheelbase enters by its reciprocals: every `/ L` of the reference's expressions (ad_3d_optimizer.py:299, 306) is one IEEE
+    // division sequence of ~11 dependent fp64 instructions per lane, and there were thirteen of them per evaluation -- 64 % of the
+    // vector instructions of the shooting phase.  iL and LRL depend on the configuration only (one division each per phase: the four
+    // evaluations of a step share them); the products differ from the quotients in the last bit.
+    const T iL = (T)1 / L, LRL = LR / L;
     T sp, cp, sd, cd;
     sincos_small(psi, &sp, &cp);
     sincos_small(dl, &sd, &cd);
@@ -118,8 +123,8 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     const T dyn5 = iIz * (LF * Ffy * cd - LR * Fry);
     const T q = (T)1 - p;
     e.f[3] = p * dyn3 + q * u[0];
-    e.f[4] = p * dyn4 + q * (kk * LR / L);
-    e.f[5] = p * dyn5 + q * (kk / L);
+    e.f[4] = p * dyn4 + q * (kk * LRL);
+    e.f[5] = p * dyn5 + q * (kk * iL);
     e.f[6] = u[1];
     const T gF[4] = { 2 * Cf * (vy + LF * r) * iv * iv, -2 * Cf * iv, -2 * Cf * LF * iv, 2 * Cf };
     const T gR[4] = { -Fry * iv, -2 * Cr * iv, 2 * Cr * LR * iv, (T)0 };
@@ -133,8 +138,8 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
     d3[1] += r;  d3[2] += vy;  d3[3] += -Ffy * cd * im;
     d4[0] += -r; d4[2] += -vx; d4[3] += -Ffy * sd * im;
     d5[3] += -LF * Ffy * sd * iIz;
-    const T k4[4] = { u[1] * LR / L, (T)0, (T)0, u[0] * LR / L };
-    const T k5[4] = { u[1] / L, (T)0, (T)0, u[0] / L };
+    const T k4[4] = { u[1] * LRL, (T)0, (T)0, u[0] * LRL };
+    const T k5[4] = { u[1] * iL, (T)0, (T)0, u[0] * iL };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         e.a[0][i] = p * d3[i];
@@ -142,8 +147,8 @@ __device__ __forceinline__ void model_eval(const AdmpcConfig* __restrict__ c, co
         e.a[2][i] = p * d5[i] + q * k5[i];
     }
     e.bu[0][0] = (T)1;              e.bu[0][1] = (T)0;
-    e.bu[1][0] = q * dl * LR / L;  e.bu[1][1] = q * vx * LR / L;
-    e.bu[2][0] = q * dl / L;       e.bu[2][1] = q * vx / L;
+    e.bu[1][0] = q * dl * LRL;  e.bu[1][1] = q * vx * LRL;
+    e.bu[2][0] = q * dl * iL;   e.bu[2][1] = q * vx * iL;
     const int ngp = c->n_gp;
     for (int g = 0; g < ngp; ++g) {          // residual GPs: out in {3,4,5}, feat in {3..8} (validated on the host)
         const AdmpcGp& gp = c->gp[g];
