@@ -39,6 +39,22 @@
 #ifndef F20_CPREF
 #define F20_CPREF 0
 #endif
+#ifndef F20_TICKET_AHEAD
+#define F20_TICKET_AHEAD 1
+#endif
+// Deferred expansions (0, shipped: off; 1: the instances drawn by ticket push their expansion -- phase A once more and phase E -- into
+// queues that the waves pop when the ticket queue is dry: jobs of 15 us instead of 54 at the end of a launch).  Built, bit-identical
+// (scripts/defer_check.py), and measured SLOWER: 19.2 M against 20.9 M solves/s at configs[1], 22.1 against 24.1 M at B = 8192, two batches
+// in flight 20.6 against 23.1 M -- an expansion that changes waves pays ~6 us of dependent trips to the memory side (queue scan, pop,
+// entry, du; the instance's inputs miss the other XCD's L2) on a 15 us job, more than the shorter ramp returns.  With ONE queue the
+// counter line was the bottleneck (same-line atomics retire at ~10 ns: 35 % slower), as compare-and-swap pops 35 ms per step.  See
+// `expansion queue` in the kernel; kept as an A/B switch (make variant EXTRA=-DF20_DEFER=1).
+#ifndef F20_DEFER
+#define F20_DEFER 0
+#endif
+#if F20_DEFER && !F20_TICKET_AHEAD
+#error "F20_DEFER needs F20_TICKET_AHEAD"
+#endif
 #ifndef F20_TOKTRAP
 #define F20_TOKTRAP 0
 #endif
@@ -117,7 +133,8 @@ __device__ __forceinline__ void stage_dq_nt(double* __restrict__ dq, const doubl
 struct FusedLds {
     static constexpr int N = 20, NTRI = 820;
     static constexpr int oH = 0, oL = oH + NTRI, oPark = oL + NTRI, oCb = oPark + 5 * 64;
-    static constexpr int total = oCb + 4 * 64;                          // 2216 doubles = 17 728 B
+    static constexpr int oSch = oCb + 4 * 64;                           // [2][64] ints: inclusive scan of the bin counts (most expensive bin first), the counts
+    static constexpr int total = oSch + 64;                             // 2280 doubles = 18 240 B
     static constexpr int JTS = 24, JTK = 4 * JTS + 2;                   // Jacobian entries per (stage, RK stage); doubles per stage: 98, not 96 --
                                                                         // 768 B apart the 20 stages of a table access all hit one bank group
     static constexpr int oJT = 0, oBlA = N * JTK, oGTC = 0, oDqC = 860, oGam = oDqC + 148;
@@ -261,16 +278,125 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
     // ---------------- persistent loop: first ticket = block index, later ones from one global counter ----------------
     F20_DECL();
     bool first_ticket = true;
+    // Tickets.  Between two instances f20_next is three dependent trips to the L2 (the ticket counter, the bin counts, the bin's list) in
+    // front of the instance's own loads -- 3-4 us of a 36 us cheap instance when the wave is alone on its SIMD (the drain).  The bin counts
+    // do not change while the kernel runs: every wave scans them once into LDS.  The next ticket is drawn at the top of phase E and resolved
+    // behind its recursion, so both remaining trips run under the expansion (F20_TICKET_AHEAD=0: the plain f20_next between instances).
+    int* const sch_incl = reinterpret_cast<int*>(lds_raw + FusedLds::oSch);
+    int* const sch_cnt = sch_incl + 64;
+#if F20_TICKET_AHEAD
+    if (cap != 0) {
+        LAUNDER_LANE(lane_s);
+        const int c = sched[F20_BINS0 + F20_NB - 1 - lane_s];
+        sch_cnt[lane_s] = c;
+        sch_incl[lane_s] = wave_scan_incl_int(c);
+        WSYNC();
+    }
+    // instance of ticket t (wave-uniform), -1 behind the batch: f20_next's walk over the bins, the counts from LDS
+    auto ticket_entry_addr = [&](const int t, const int lane_) __attribute__((always_inline)) -> const int* {
+        const int incl = sch_incl[lane_], c = sch_cnt[lane_];
+        const unsigned long long m = __ballot(incl > t);
+        if (m == 0ull) return nullptr;
+        const int l = __ffsll((long long)m) - 1;
+        const int base = __builtin_amdgcn_readlane(incl - c, l);
+        return sched + F20_HDR + (size_t)(F20_NB - 1 - l) * cap + (t - base);
+    };
+    int next_inst = -2, next_tk = 0;                                    // -2: not drawn yet; next_tk: the ticket of next_inst
+#endif
+    // ---- expansion queue.  What follows the interior point -- phase A once more and phase E, ~15 of the ~54 us of an instance the trial
+    // solves -- needs nothing of the instance but its step du (40 doubles): the linearisation is recomputed from the inputs anyway.  A wave
+    // that has finished phase D of an instance therefore PUSHES the expansion (du into the per-instance buffer, the instance index into the
+    // queue) and draws the next ticket at once; the expansions are popped by the waves that find the ticket queue dry.  The batch is then a
+    // list of jobs whose last and most numerous ones take 15 us instead of 54: the ramp at the end of the launch (two jobs per wave slot at
+    // B = 4096: a quarter of the run time with half of the slots idle) is filled with them.  Pops are fetch-adds (a compare-and-swap
+    // on the pop counter serialised 2000 waves: 35 ms per step); what makes that safe is at the pop.  Visibility across the XCDs' L2s
+    // without cache-wide write-backs: du and the queue entries are agent-scope relaxed atomic stores and loads (sc1: coherent per location
+    // across the XCDs; as read-modify-write atomics the 80 accesses per expansion cost 70 us per step), ordered by the wave's own
+    // s_waitcnt between them; the counters are fetch-adds like the ticket counter.
+    // One queue would be one cache line of counters: same-line atomics retire at ~10 ns each, and the 15 us jobs of 2048 waves ask for more
+    // pops than that (measured: the step 35 % SLOWER).  So F20_NQ sub-queues, a counter line each; ticket t pushes into queue (t - grid) mod
+    // F20_NQ, which makes every queue's entry count known; a wave pops from the first queue at or behind its home (block mod F20_NQ) whose
+    // pop counter -- one vector load over all queues -- is below its count.
+    //   qh[q][32]: pushes at +0, pops at +1 (zeroed by the order kernel); qitems[q][qcap] = instance (-1 until published, -2: none); dubuf[inst][40]
+    int* const qh = sched + F20_HDR + (size_t)F20_NB * cap;
+    int* const qitems = qh + F20_NQ * 32;
+    const int qcap = cap / F20_NQ + 1;
+    double* const dubuf = reinterpret_cast<double*>(qitems + cap + F20_NQ + (cap & 1));
+    const int nent = B - (int)gridDim.x;                                // entries of all queues: one per instance drawn by ticket
+    const bool can_defer = F20_DEFER && cap != 0 && !park_gt;           // (a parked linearisation lives in the slot of the wave that shot it)
+    (void)qcap; (void)dubuf; (void)nent; (void)can_defer;               // (unused with F20_DEFER == 0)
     for (;;) {
         LAUNDER_LANE(lane0);
-        const int inst = f20_next(sched, cap, first_ticket, lane0);
+#if F20_TICKET_AHEAD
+        int inst;
+        if (cap == 0) inst = first_ticket ? (int)blockIdx.x : -1;
+        int cur_tk = next_tk;                                           // the ticket of this instance (its sub-queue)
+        if (cap == 0) { }
+        else if (next_inst != -2) inst = next_inst;
+        else {
+            int t = (int)blockIdx.x;
+            if (!first_ticket) { int v = 0; if (lane0 == 0) v = atomicAdd(sched, 1); t = (int)gridDim.x + __builtin_amdgcn_readfirstlane(v); }
+            const int* const e = ticket_entry_addr(t, lane0);
+            inst = e ? __builtin_amdgcn_readfirstlane(*e) : -1;
+            cur_tk = t;
+        }
+        next_inst = -2;
+#else
+        int inst = f20_next(sched, cap, first_ticket, lane0);
+#endif
+        bool ejob = false;
+#if F20_DEFER
+        if (inst < 0 && can_defer) {
+            // the ticket queue is dry: pop an expansion.  Every instance drawn by ticket pushes exactly one entry (its expansion, or -2 when it
+            // has none: failed, or skipped by its status), so every queue's number of entries is known.  A pop beyond it sends the wave to
+            // the next queue (and out when all are spent); a pop in front of its push waits for it -- the pusher holds a ticket, so it is
+            // a RUNNING wave (the workgroups that have not started yet hold first tickets only, and those never push): the wait cannot
+            // depend on a workgroup that needs this wave's slot.
+            const int home = (int)blockIdx.x & (F20_NQ - 1);
+            for (;;) {
+                const int ql = (lane0 + home) & (F20_NQ - 1);           // lane l looks at queue home + l
+                const int tot = nent > ql ? (nent - ql + F20_NQ - 1) / F20_NQ : 0;
+                const int popped = __hip_atomic_load(qh + ql * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long open = __ballot(popped < tot);
+                if (open == 0ull) break;                                // every queue is spent: the wave leaves
+                const int l = __ffsll((long long)open) - 1;
+                const int q = (l + home) & (F20_NQ - 1);
+                const int tq = __builtin_amdgcn_readlane(tot, l);
+                int pq = 0;
+                if (lane0 == 0) pq = atomicAdd(qh + q * 32 + 1, 1);
+                pq = __builtin_amdgcn_readfirstlane(pq);
+                if (pq >= tq) continue;                                 // somebody was faster: look again
+                int i = -1;
+                for (;;) {
+                    if (lane0 == 0) i = __hip_atomic_load(qitems + q * qcap + pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    i = __builtin_amdgcn_readfirstlane(i);
+                    if (i != -1) break;
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                if (i < 0) continue;                                    // an instance without an expansion
+                inst = i; ejob = true;
+                next_inst = -1;                                         // the ticket queue stays dry
+                break;
+            }
+        }
+#endif
 #if F20_CLASS_PRIO
         const bool first_class = first_ticket && (int)blockIdx.x < (int)gridDim.x / 2;
 #endif
+        const bool by_ticket = !first_ticket; (void)by_ticket; (void)cur_tk;
         first_ticket = false;
         if (inst < 0) break;
         F20_TRACE_BEGIN();
-        if (!first_pass && statusg[inst] != 0) continue;    // failed / converged in an earlier SQP iteration of this call
+        auto push_none = [&]() __attribute__((always_inline)) {       // an instance drawn by ticket that has no expansion still owes the queue its entry
+#if F20_DEFER
+            if (can_defer && by_ticket && !ejob) {
+                LAUNDER_LANE(lq);
+                const int q = (cur_tk - (int)gridDim.x) & (F20_NQ - 1);
+                if (lq == 0) { const int qs = atomicAdd(qh + q * 32, 1); __hip_atomic_store(qitems + q * qcap + qs, -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+#endif
+        };
+        if (!ejob && !first_pass && statusg[inst] != 0) { push_none(); continue; }    // failed / converged in an earlier SQP iteration of this call
         double* const xbg = xbarg + (size_t)inst * (N + 1) * NX;
         double* const ubg = ubarg + (size_t)inst * N * NU;
         const double* yrg = yrefg + (size_t)inst * N * NY;
@@ -284,8 +410,18 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         int it = 0;
         // without a slot buffer phase A runs a second time in front of phase E: pass 1 of this loop (one copy of the code)
         int npass = park_gt ? 1 : 2; asm volatile("" : "+s"(npass));
+        bool deferred = false;
+        int pass0 = 0;
+#if F20_DEFER
+        if (ejob) {                                                     // a popped expansion: its step, then pass 1 (phase A) and phase E
+            LAUNDER_LANE(lq);
+            du = lq < n ? __hip_atomic_load(dubuf + (size_t)inst * n + lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            pass0 = 1;
+        }
+#endif
+        asm volatile("" : "+s"(pass0));
 #pragma unroll 1
-        for (int pass = 0; pass < npass; ++pass) {
+        for (int pass = pass0; pass < npass; ++pass) {
         {
             LAUNDER_LANE(lane); LAUNDER_CFG(cf);
             const double h = cf->Ts;
@@ -1000,11 +1136,31 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
         }
         F20_STAMP(5);
         if (failed) break;
+#if F20_DEFER
+        if (can_defer && by_ticket && !ejob) {
+            // push the expansion; the next ticket and the queue slot travel together with the stores of du
+            LAUNDER_LANE(lq);
+            int tk = 0, qs = 0;
+            if (lq == 0) tk = atomicAdd(sched, 1);
+            if (lq < n) __hip_atomic_store(dubuf + (size_t)inst * n + lq, du, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int q = (cur_tk - (int)gridDim.x) & (F20_NQ - 1);
+            if (lq == 0) qs = atomicAdd(qh + q * 32, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // du is at the memory side before the entry can be seen
+            if (lq == 0) __hip_atomic_store(qitems + q * qcap + qs, inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next_tk = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tk);
+            const int* const e = ticket_entry_addr(next_tk, lq);
+            next_inst = e ? __builtin_amdgcn_readfirstlane(*e) : -1;
+            deferred = true;
+            break;
+        }
+#endif
         }   // pass
-        { LAUNDER_LANE(lw); if (lw == 0 && itersg) itersg[inst] = it; }
+        if (!ejob) { LAUNDER_LANE(lw); if (lw == 0 && itersg) itersg[inst] = it; }
+        if (deferred) { __builtin_amdgcn_s_setprio(0); continue; }
         if (failed) {
             // non-finite QP data: acados returns before the update -- the iterate stays as it is, status 4, cost +inf
             { LAUNDER_LANE(lw); if (lw == 0) { statusg[inst] = ADMPC_STATUS_QP_FAILURE; if (costg) costg[inst] = INFINITY; } }
+            push_none();
             WSYNC();
             __builtin_amdgcn_s_setprio(0);
             continue;
@@ -1024,6 +1180,10 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             const int r6 = lane < 6 ? lane : 0;                     // row of the packed linearisation this lane reads
             const int r7 = lane < NX ? lane : 0;
             const double wq = lane < NX ? Ts * cf->W[r7] : 0.0, wqe = lane < NX ? cf->We[r7] : 0.0;
+#if F20_TICKET_AHEAD
+            int tk_v = 0;
+            if (cap != 0 && !ejob && lane == 0) tk_v = atomicAdd(sched, 1);       // the next ticket: its trip to the L2 runs under the expansion
+#endif
             WSYNC();
             if (park_gt) {
                 // the slot buffer again: the wave's own stores of phase A have long retired, but the CU's vector L1 may still hold the
@@ -1063,6 +1223,14 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                     dx = lane < NX ? acc : 0.0;
                 }
             });
+#if F20_TICKET_AHEAD
+            int tk_e = -1;                                                // the list entry of the next ticket: loaded under the output stores
+            if (cap != 0 && !ejob) {
+                next_tk = (int)gridDim.x + __builtin_amdgcn_readfirstlane(tk_v);
+                const int* const e = ticket_entry_addr(next_tk, lane);
+                if (e) tk_e = *e;
+            }
+#endif
             const double unew = ubar_i + du;
             if (uact && !(fabs(unew) <= 1e300)) bad = true;
             const int status = __any(bad) ? ADMPC_STATUS_QP_FAILURE : ADMPC_STATUS_SUCCESS;
@@ -1085,6 +1253,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 statusg[inst] = status;
             }
             WSYNC();
+#if F20_TICKET_AHEAD
+            if (cap != 0 && !ejob) next_inst = __builtin_amdgcn_readfirstlane(tk_e);
+#endif
             F20_STAMP(6);
             F20_TRACE_END(inst);
         }
@@ -1154,7 +1325,9 @@ __attribute__((visibility("hidden"))) void admpc_fused20_prepare(void)
 // sched ints of a handle that solves up to `cap` instances per call: TWO scheduler states used alternately (zeroed at allocation; the order kernel of a
 // launch zeroes the header of the next launch's state, the last workgroup to leave re-arms its own: no memset in front of a launch -- a hipMemsetAsync
 // there cost 2 us per step at configs[1] and 26 us at N = 40)
-__attribute__((visibility("hidden"))) size_t admpc_fused20_sched_ints(int cap) { return 2 * ((size_t)F20_HDR + (size_t)F20_NB * (size_t)cap); }      // two states (work_order.h)
+// one state: header, the bins' lists, the expansion queues (F20_NQ counter lines, cap + F20_NQ entries, padded to an even count) and the steps of the pushed expansions (cap x 40 doubles)
+__attribute__((visibility("hidden"))) size_t admpc_fused20_state_ints(int cap) { return (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap + (size_t)F20_NQ * 32 + (size_t)(cap + F20_NQ + (cap & 1)) + 2 * (size_t)40 * (size_t)cap; }
+__attribute__((visibility("hidden"))) size_t admpc_fused20_sched_ints(int cap) { return 2 * admpc_fused20_state_ints(cap); }      // two states (work_order.h)
 
 // grid: persistent, eight one-wave workgroups per CU (two waves per SIMD); slotbuf: admpc_fused20_slot_doubles(num_cu) doubles
 __attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int B, int qmask,
@@ -1165,7 +1338,7 @@ __attribute__((visibility("hidden"))) void admpc_fused20_launch(int num_cu, hipS
     int grid = num_cu * 8; if (grid > B) grid = B;
     // every launch pair is self-contained: ticket counter, exit counter and bin counts start from zero on the caller's stream (the last
     // workgroup to leave re-arms them as well; a launch that failed half-way, or a handle misused from two streams, cannot poison the next)
-    const size_t one = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
+    const size_t one = admpc_fused20_state_ints(cap);
     int* const sched = sched2 + (flip ? one : 0);
     int* const sched_next = sched2 + (flip ? 0 : one);
     const int kcap = grid == B ? 0 : cap;      // the batch fits the grid: no work order (work_order.h: f20_next)

@@ -34,6 +34,7 @@
 #ifndef SEG_CPREF
 #define SEG_CPREF 0
 #endif
+extern "C" size_t admpc_fused20_state_ints(int cap);      // admpc_fused20.hip: ints of one scheduler state
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1322,7 +1323,7 @@ static void seg_launch(int num_cu, hipStream_t st, const AdmpcConfig* d_cfg, int
         prepared = true;
     }
     // two scheduler states, used alternately: the order kernel of this launch zeroes the header of the next (work_order.h)
-    const size_t one = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
+    const size_t one = admpc_fused20_state_ints(cap);      // the layout of a scheduler state is admpc_fused20.hip's (its order kernel also resets the expansion queue behind the lists)
     int* const sched = sched2 + (flip ? one : 0);
     int* const sched_next = sched2 + (flip ? 0 : one);
     const int kcap = grid == B ? 0 : cap;      // the batch fits the grid: no work order (work_order.h: f20_next)

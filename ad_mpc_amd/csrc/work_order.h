@@ -7,6 +7,7 @@
 #define F20_NB 64
 #define F20_BINS0 64
 #define F20_HDR 128
+#define F20_NQ 64           // sub-queues of the expansion queue (admpc_fused20.hip): a power of two, at most the wave size
 // The estimate (round 4): the longitudinal input saturates when the speed of the reference -- the distance between its first two points
 // per sampling interval -- differs from the vehicle's by more than the box allows the tracking controller to ask for: the acceleration an
 // LQ tracker of these weights starts with is ~ k (v_ref - v_x), k = 3 / s here (a double integrator with the reference's weights 10 / 1
@@ -38,6 +39,10 @@ __global__ __launch_bounds__(256) void admpc_f20_order_kernel(const AdmpcConfig*
     __syncthreads();
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     int q = -1, rank = 0;
+#if defined(F20_DEFER) && F20_DEFER
+    // expansion queues of admpc_fused20_kernel (this launch's state): counters zero, entries not published
+    for (int i = b; i < F20_NQ * 32 + cap + F20_NQ; i += (int)(gridDim.x * blockDim.x)) sched[F20_HDR + (size_t)F20_NB * cap + i] = i < F20_NQ * 32 ? 0 : -1;
+#endif
     if (b < B) {
         const double* x0 = x0g + (size_t)b * NX;
 #if F20_ORDER_TERMINAL
