@@ -36,8 +36,10 @@
 #ifndef F20_MFMA
 #define F20_MFMA 1
 #endif
+// 1 (shipped): every LDS read of a condensing stage is issued in front of the stage (458 -> 97 s_waitcnt in the phase; an instruction of
+// any kind costs its wave an issue slot, and the single-wave time is what the end of a launch runs at); 0: where hipcc puts them
 #ifndef F20_CPREF
-#define F20_CPREF 0
+#define F20_CPREF 1
 #endif
 #ifndef F20_TICKET_AHEAD
 #define F20_TICKET_AHEAD 1
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
 #endif
                 }
                 if constexpr (k < N) {
-                    const double* Gk = GT + k * GTS;
+                    const double* Gk = GT + k * GTS; (void)Gk;
                     // The inputs of stage k enter with B_k: lanes 2k, 2k + 1 (whose column of Gamma is still zero) start the product from
                     // their column of B_k, every other lane from the zero row of gam -- one per-lane LDS address instead of 28 selects
                     // per stage (560 vector instructions per instance); 0 + A_k 0 = 0 exactly: the same bits as the selects gave.
@@ -1018,9 +1020,9 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                         rmax = OpMaxNan::f(uact ? ra : 0.0, dact ? rb : 0.0);
                     }
                     mu = wave_reduce<OpSum>(musum) * inv_nineq;
-                    cmax = wave_reduce<OpMax>(cmax);
-                    rmax = wave_reduce<OpMaxNan>(rmax);
-                    step = wave_reduce<OpMax>(stp_local);
+                    cmax = wave_reduce<OpMax0>(cmax);
+                    rmax = wave_reduce<OpMaxNan0>(rmax);
+                    step = wave_reduce<OpMax0>(stp_local);
 #ifdef F20_DEBUG
                     if (lane == 0) printf("[f20] it %2d mu %.3e cmax %.3e rmax %.3e rmax_prev %.3e step %.3e alpha_prev %.6f\n", it, mu, cmax, rmax, rmax_prev, step, alpha_prev);
 #endif
@@ -1087,7 +1089,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                     Ddt[1] = -ddx6 + Drd1; Ddlam[1] = -Drc[1] * Dit[1] - G6 * Ddt[1];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) rr = fmax(rr, dact ? fmax(-Ddt[i] * Dit[i], -Ddlam[i] * Dil[i]) : 0.0);
-                    rr = wave_reduce<OpMax>(rr);
+                    rr = wave_reduce<OpMax0>(rr);
                     const double amax = rr > 1.0 ? rcp_nr(rr) : 1.0;
                     if (pass == 0) {
                         double s_aff = 0.0;
@@ -1212,15 +1214,19 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                 if constexpr (k < N) {
                     const double* Gk = GTe + k * GTS;
                     const double u0 = dus[2 * k], u1 = dus[2 * k + 1];
-                    double acc = ble[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                    // rows 0..5 from the packed record; every lane loads (lanes >= 6 read row 0 and drop the result): seven loads under their
+                    // own EXEC masks were 18 scalar instructions per stage.  Row 6 of [A B] is [e6, 0, h]: one multiply-add in lane 6.
+                    const double bk = ble[k * 7 + r7];
+                    double acc = bk + (lane < 2 ? dx : 0.0);
                     double gg[5];
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) gg[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
-                    const double b0 = lane < 6 ? Gk[5 * 6 + r6] : 0.0, b1 = lane < 6 ? Gk[6 * 6 + r6] : (lane == 6 ? h : 0.0);
+                    for (int c = 0; c < 5; ++c) gg[c] = Gk[c * 6 + r6];
+                    const double b0 = Gk[5 * 6 + r6], b1 = Gk[6 * 6 + r6];
                     acc += b0 * u0 + b1 * u1;
+                    const double acc6 = fma(h, u1, bk + dx);
                     fmac_rowbc<2>(acc, dx, gg[0]); fmac_rowbc<3>(acc, dx, gg[1]); fmac_rowbc<4>(acc, dx, gg[2]);
                     fmac_rowbc<5>(acc, dx, gg[3]); fmac_rowbc<6>(acc, dx, gg[4]);
-                    dx = lane < NX ? acc : 0.0;
+                    dx = lane < 6 ? acc : (lane == 6 ? acc6 : 0.0);
                 }
             });
 #if F20_TICKET_AHEAD

@@ -216,7 +216,7 @@ __device__ __forceinline__ double bcast(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 // wave reductions: DPP scans (dense40.h); every lane receives the result
-struct OpMin { static __device__ __forceinline__ double id() { return INFINITY; } static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); } };
+struct OpMin { static constexpr bool zf = false; static __device__ __forceinline__ double id() { return INFINITY; } static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); } };
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMaxNan>(v); }         // NaN-propagating
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }

@@ -759,13 +759,14 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                     m = fmax(m, row_here ? fabs((k < N ? wq : wqe) * e) : 0.0);
                     if constexpr (k < N) {
                         const double* Gk = GT + k * GTS;
-                        double a = bl[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                        const double bk = bl[k * 7 + r7];
+                        double a = bk + (lane < 2 ? dx : 0.0);
                         double gg[5];
 #pragma unroll
-                        for (int c = 0; c < 5; ++c) gg[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
+                        for (int c = 0; c < 5; ++c) gg[c] = Gk[c * 6 + r6];
                         fmac_rowbc<2>(a, dx, gg[0]); fmac_rowbc<3>(a, dx, gg[1]); fmac_rowbc<4>(a, dx, gg[2]);
                         fmac_rowbc<5>(a, dx, gg[3]); fmac_rowbc<6>(a, dx, gg[4]);
-                        dx = lane < NX ? a : 0.0;
+                        dx = lane < 6 ? a : (lane == 6 ? bk + dx : 0.0);
                     }
                 });
                 rsx = wave_reduce<OpMaxNan>(m);
@@ -1013,9 +1014,9 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         }
                     }
                     const double mus_w = wave_reduce<OpSum>(musum);
-                    const double cmx_w = wave_reduce<OpMax>(cmax);
+                    const double cmx_w = wave_reduce<OpMax0>(cmax);
                     const double rin_w = wave_reduce<OpMaxNan>(rineq);
-                    const double stp_w = wave_reduce<OpMax>(stp_local);
+                    const double stp_w = wave_reduce<OpMax0>(stp_local);
                     double rs0_w = 0.0;
                     if (rstat < 0.0) rs0_w = wave_reduce<OpMaxNan>(rs0);
                     if (lane == 0) {
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                         rr = fmax(rr, dact ? fmax(-Ddt[i] * Dit[i], -Ddlam[i] * Dil[i]) : 0.0);
                         sdd += dact ? Ddt[i] * Ddlam[i] : 0.0;
                     }
-                    const double rr_w = wave_reduce<OpMax>(rr);
+                    const double rr_w = wave_reduce<OpMax0>(rr);
                     const double sdd_w = wave_reduce<OpSum>(sdd);
                     if (lane == 0) { RED(wv_, 2 + ps, 0) = rr_w; RED(wv_, 2 + ps, 1) = sdd_w; }
                     XSYNC();
@@ -1239,15 +1240,18 @@ __global__ __launch_bounds__(WAVE * S, 2) void admpc_seg_kernel(const AdmpcConfi
                 if constexpr (k < N) {
                     const double* Gk = GT + k * GTS;
                     const double u0 = dus[2 * k], u1 = dus[2 * k + 1];
-                    double acc = bl[k * 7 + r7] + (lane < 2 || lane == 6 ? dx : 0.0);
+                    // every lane loads rows 0..5 (lanes >= 6 read row 0 and drop the result), row 6 = [e6, 0, h] in lane 6: see admpc_fused20.hip
+                    const double bk = bl[k * 7 + r7];
+                    double acc = bk + (lane < 2 ? dx : 0.0);
                     double gg[5];
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) gg[c] = lane < 6 ? Gk[c * 6 + r6] : 0.0;
-                    const double b0 = lane < 6 ? Gk[5 * 6 + r6] : 0.0, b1 = lane < 6 ? Gk[6 * 6 + r6] : (lane == 6 ? h : 0.0);
+                    for (int c = 0; c < 5; ++c) gg[c] = Gk[c * 6 + r6];
+                    const double b0 = Gk[5 * 6 + r6], b1 = Gk[6 * 6 + r6];
                     acc += b0 * u0 + b1 * u1;
+                    const double acc6 = fma(h, u1, bk + dx);
                     fmac_rowbc<2>(acc, dx, gg[0]); fmac_rowbc<3>(acc, dx, gg[1]); fmac_rowbc<4>(acc, dx, gg[2]);
                     fmac_rowbc<5>(acc, dx, gg[3]); fmac_rowbc<6>(acc, dx, gg[4]);
-                    dx = lane < NX ? acc : 0.0;
+                    dx = lane < 6 ? acc : (lane == 6 ? acc6 : 0.0);
                 }
             });
             const double unew = ubar_i + du;

@@ -10,10 +10,10 @@ __device__ __forceinline__ int div7(int x) { return (int)(((unsigned)x * 9363u) 
 
 template <class Op>
 __device__ __forceinline__ double wave_scan_incl(double v) {      // inclusive prefix over lanes 0..lane
-    v = Op::f(v, dpp_mov<0x111, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x112, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x114, 0xf>(Op::id(), v));
-    v = Op::f(v, dpp_mov<0x118, 0xf>(Op::id(), v));
+    v = Op::f(v, dpp_shr<0x111, Op::zf>(Op::id(), v));
+    v = Op::f(v, dpp_shr<0x112, Op::zf>(Op::id(), v));
+    v = Op::f(v, dpp_shr<0x114, Op::zf>(Op::id(), v));
+    v = Op::f(v, dpp_shr<0x118, Op::zf>(Op::id(), v));
     v = Op::f(v, dpp_mov<0x142, 0xa>(Op::id(), v));
     v = Op::f(v, dpp_mov<0x143, 0xc>(Op::id(), v));
     return v;
