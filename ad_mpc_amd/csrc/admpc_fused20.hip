@@ -41,6 +41,25 @@
 #ifndef F20_CPREF
 #define F20_CPREF 1
 #endif
+// 1: the free response xhat_k of the condensing rides in lane 40 as a 41st column of Gamma (b_k enters it through a per-lane LDS
+// address, the other lanes read the components they need from the exchange buffer every lane writes anyway) instead of being propagated
+// redundantly by all 64 lanes: 30 multiply-adds per stage.  Needs F20_CPREF and F20_MFMA == 1.  The same bits.
+#ifndef F20_XHLANE
+#define F20_XHLANE 1
+#endif
+// 1: the 30 entries of A_k reach the propagation's multiply-adds through DPP row broadcasts -- every 16-lane row holds them in TWO registers
+// (lane e: entries e and 16 + e, two ds_read_b64 per stage) -- instead of fifteen ds_read_b128 that hand all 64 lanes the same 16 bytes:
+// 15 KB of LDS return traffic per stage for 240 bytes of information.  The LDS pipe of a CU is shared by its eight waves and was 76 % busy
+// over the whole launch (SQ_ACTIVE_INST_LDS).  Needs F20_XHLANE (no uniform operands left in the phase).  The same bits.
+#ifndef F20_ADPP
+#define F20_ADPP 1
+#endif
+#if F20_ADPP && !F20_XHLANE
+#error "F20_ADPP needs F20_XHLANE"
+#endif
+#if F20_XHLANE && !(F20_CPREF && F20_MFMA == 1)
+#error "F20_XHLANE needs F20_CPREF and F20_MFMA == 1"
+#endif
 #ifndef F20_TICKET_AHEAD
 #define F20_TICKET_AHEAD 1
 #endif
@@ -664,7 +683,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
             for (int c = 0; c < NX; ++c) { xh2[0][c] = x0g[(size_t)inst * NX + c] - xbg[c]; xh2[1][c] = 0.0; }      // uniform
             WSYNC();
 #pragma unroll
-            for (int c = 0; c < NX; ++c) { g2[0][c] = 0.0; g2[1][c] = 0.0; }
+            for (int c = 0; c < NX; ++c) { g2[0][c] = (F20_XHLANE && lane == n) ? xh2[0][c] : 0.0; g2[1][c] = 0.0; }      // lane 40: xhat_0 = x0 - xbar_0
 #if F20_MFMA
             // H on the matrix pipe: six 16 x 16 tiles (I >= J) of v_mfma_f64_16x16x4_f64.  One MFMA step takes K = 4 rows of the
             // 60 x 40 matrix G whose rows are the weighted components of Gamma_k: per stage the components of QMASK, four at a time
@@ -728,21 +747,49 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
 #if F20_CPREF
                 // Every LDS read of the stage's record is issued before anything else of the stage: left to itself hipcc keeps one or two
                 // ds_read_b128 in flight and the propagation (60 multiply-adds behind 21 reads) waits on each of them in turn.
-                double2 Av[15], Bv[3]; double blv[NX];
+                double2 Av[15], Bv[3]; double blv[NX], Aq[2]; (void)Av; (void)Aq;
                 const bool mine_p = ki == k;
                 if constexpr (k < N) {
                     const double* Gk = GT + k * GTS;
-                    const double* const bsrc = mine_p ? Gk + 5 * 6 + 6 * ji : gam + 7 * 64;
+                    // (indices into the one LDS array, not selected pointers: hipcc turns a select of two LDS pointers into flat pointers and
+                    // converts every element address back with a null check -- five scalar instructions per load)
+                    const int bidx = mine_p ? FusedLds::oGTC + k * GTS + 5 * 6 + 6 * ji : FusedLds::oGam + 7 * 64;
+#if F20_ADPP
+                    { const int e16 = lane & 15; Aq[0] = Gk[e16]; Aq[1] = Gk[16 + (e16 < 14 ? e16 : 13)]; }
+#else
 #pragma unroll
                     for (int q_ = 0; q_ < 15; ++q_) Av[q_] = *reinterpret_cast<const double2*>(Gk + 2 * q_);
+#endif
 #pragma unroll
-                    for (int q_ = 0; q_ < 3; ++q_) Bv[q_] = *reinterpret_cast<const double2*>(bsrc + 2 * q_);
+                    for (int q_ = 0; q_ < 3; ++q_) Bv[q_] = *reinterpret_cast<const double2*>(lds_raw + bidx + 2 * q_);
+#if F20_XHLANE
+                    const int lidx = lane == n ? FusedLds::oBlA + k * 7 : FusedLds::oGam + 7 * 64;      // b_k for the column of the free response, zeros for the others
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) blv[r] = lds_raw[lidx + r];
+#else
 #pragma unroll
                     for (int r = 0; r < NX; ++r) blv[r] = bl[k * 7 + r];
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
                 if constexpr (k >= 1) {
+#if F20_XHLANE
+                    static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr ((QMASK >> c) & 1) {
+                            const double w = k < N ? Qd[c] : Qe[c];
+                            wg[c] = w * g[c];
+                            gam[c * 64 + lane] = g[c];
+                        }
+                    });
+                    if constexpr (!((QMASK >> 6) & 1)) gam[6 * 64 + lane] = g[6];      // xhat_k[6] for the steering rows
+                    static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr ((QMASK >> c) & 1) g0 += wg[c] * (gam[c * 64 + n] + dqC[k * 7 + c]);      // lane 40 has just published xhat_k[c]
+                    });
+                    { double x6 = gam[6 * 64 + n]; asm volatile("" : "+v"(x6)); xh6_own = lane == k ? x6 : xh6_own; }      // (an unconditional load)
+#else
                     if (lane == k) xh6_own = xh[6];
                     static_for<0, NX>([&](auto cc) __attribute__((always_inline)) {
                         constexpr int c = decltype(cc)::value;
@@ -753,6 +800,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                             gam[c * 64 + lane] = g[c];
                         }
                     });
+#endif
 #if F20_MFMA
 #pragma unroll
                     for (int st_ = 0; st_ < NSTEP; ++st_)
@@ -779,6 +827,29 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                     for (int r = 0; r < 6; r += 2) { gn[r] = Bv[r / 2].x; gn[r + 1] = Bv[r / 2].y; }
                     gn[0] += g[0]; gn[1] += g[1];
                     gn[6] = mine ? (ji ? h : 0.0) : g[6];
+#if F20_XHLANE
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) gn[r] += blv[r];                  // b_k in lane 40, + 0.0 elsewhere
+                    (void)xn; (void)xh;
+#if F20_ADPP
+                    static_for<0, 5>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(cc)::value;
+                        static_for<0, 6>([&](auto rc) __attribute__((always_inline)) {
+                            constexpr int r = decltype(rc)::value, q_ = c * 6 + r;
+                            fmac_rowbc_ld<q_ % 16>(gn[r], Aq[q_ / 16], g[c + 2]);      // gn[r] += A_k[r][c + 2] g[c + 2]
+                        });
+                    });
+#else
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+#pragma unroll
+                        for (int r = 0; r < 6; r += 2) {
+                            const double2 a = Av[c * 3 + r / 2];
+                            gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
+                        }
+                    }
+#endif
+#else
 #pragma unroll
                     for (int r = 0; r < 6; ++r) xn[r] = r < 2 ? blv[r] + xh[r] : blv[r];
                     xn[6] = blv[6] + xh[6];
@@ -791,6 +862,7 @@ __global__ __launch_bounds__(WAVE, 2) void admpc_fused20_kernel(const AdmpcConfi
                             gn[r] += a.x * g[c + 2];  gn[r + 1] += a.y * g[c + 2];
                         }
                     }
+#endif
 #else
                     const double* const bsrc = mine ? Gk + 5 * 6 + 6 * ji : gam + 7 * 64;
 #pragma unroll

@@ -292,6 +292,27 @@ def test_bitwise_repeatability(gpu_engine_factory):
                 np.testing.assert_array_equal(a, b)
 
 
+def test_ordered_batches_on_one_handle_are_draw_order_free(gpu_engine_factory, oracle_omp):
+    """More instances than persistent waves (B > 8 per CU): the work-order pre-pass, the ticket counter, the per-wave table of the bin
+    counts and the ticket drawn ahead under the expansion are all in play.  DIFFERENT batches solved one after another on ONE handle (the
+    two scheduler states alternate, nothing of a launch may leak into the next) must each give the bits a fresh handle gives, run after
+    run, and the oracle's answer."""
+    cfg = default_config(N=20)
+    eng = gpu_engine_factory(cfg)
+    for B, seed, blend in ((2500, 11, (3.0, 5.0)), (4096, 12, (100.0, 110.0)), (2049, 13, (3.0, 5.0)), (5000, 14, (100.0, 110.0))):
+        s = random_scenarios(B, N=20, seed=seed, blend=blend)
+        args = (s["x0"], s["yref"], s["yref_e"], s["p"], s["xbar"], s["ubar"])
+        g = eng.solve_numpy(*args)
+        fresh = gpu_engine_factory(cfg).solve_numpy(*args)
+        again = eng.solve_numpy(*args)
+        for a, b, c in zip(g, fresh, again):
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(a, c)
+        if B == 2500:
+            o = oracle_omp.solve_batch(cfg, *args, nthreads=16)
+            _assert_parity(g, o, tol_for(20))
+
+
 @pytest.mark.parametrize("N,B", [(24, 300), (40, 64), (40, 1500), (64, 600), (20, 5000)])
 def test_row_kernel_repeatable_and_ticket_order_free(gpu_engine_factory, oracle_omp, N, B, monkeypatch):
     """Kernel R draws quadruples of instances from a ticket counter and runs one to four instances per wave depending on the
