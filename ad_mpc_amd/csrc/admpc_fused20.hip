@@ -1403,8 +1403,15 @@ __attribute__((visibility("hidden"))) void admpc_fused20_prepare(void)
 // sched ints of a handle that solves up to `cap` instances per call: TWO scheduler states used alternately (zeroed at allocation; the order kernel of a
 // launch zeroes the header of the next launch's state, the last workgroup to leave re-arms its own: no memset in front of a launch -- a hipMemsetAsync
 // there cost 2 us per step at configs[1] and 26 us at N = 40)
-// one state: header, the bins' lists, the expansion queues (F20_NQ counter lines, cap + F20_NQ entries, padded to an even count) and the steps of the pushed expansions (cap x 40 doubles)
-__attribute__((visibility("hidden"))) size_t admpc_fused20_state_ints(int cap) { return (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap + (size_t)F20_NQ * 32 + (size_t)(cap + F20_NQ + (cap & 1)) + 2 * (size_t)40 * (size_t)cap; }
+// one state: header and the bins' lists; in a build with F20_DEFER also the expansion queues (F20_NQ counter lines, cap + F20_NQ entries, padded to an even
+// count) and the steps of the pushed expansions (cap x 40 doubles)
+__attribute__((visibility("hidden"))) size_t admpc_fused20_state_ints(int cap) {
+    size_t ints = (size_t)F20_HDR + (size_t)F20_NB * (size_t)cap;
+#if F20_DEFER
+    ints += (size_t)F20_NQ * 32 + (size_t)(cap + F20_NQ + (cap & 1)) + 2 * (size_t)40 * (size_t)cap;
+#endif
+    return ints;
+}
 __attribute__((visibility("hidden"))) size_t admpc_fused20_sched_ints(int cap) { return 2 * admpc_fused20_state_ints(cap); }      // two states (work_order.h)
 
 // grid: persistent, eight one-wave workgroups per CU (two waves per SIMD); slotbuf: admpc_fused20_slot_doubles(num_cu) doubles
