@@ -1,9 +1,10 @@
 // admpc_fused20.hip -- the N = 20 fp64 SQP-RTI step (BASELINE configs[1..3]) as ONE persistent kernel for gfx950.
 //
 // One wavefront (= one workgroup of 64 lanes) owns one MPC instance from its inputs to its outputs and then draws the next one
-// from a ticket counter.  Nothing but the algorithmic inputs and outputs of SURVEY 8a crosses HBM: the packed linearisation
-// (7.8 KB), the condensed Hessian (6.6 KB), its factor (6.6 KB) and every intermediate live in the wave's 25.6 KB of LDS or in
-// registers -- six instances per CU.  Phases of an instance (reference = data_driven_mpc/ros_gp_mpc/src/ad_mpc/...):
+// from a ticket counter.  Nothing but the algorithmic inputs and outputs of SURVEY 8a crosses HBM: the condensed Hessian (6.6 KB),
+// its factor (6.6 KB) and every intermediate live in the wave's 18.2 KB of LDS or in registers -- eight instances per CU, two waves
+// per SIMD; the packed linearisation (7.8 KB) aliases that space and is recomputed in front of the expansion (or parked in a per-wave
+// slot of global memory when the model carries GP residuals).  Phases of an instance (reference = data_driven_mpc/ros_gp_mpc/src/ad_mpc/...):
 //   A  H0/H1  ERK4 + forward sensitivities of all 20 stages           ad_3d_optimizer.py:280-310, acados ERK
 //             (A1: lanes (stage, third) integrate the state and table      (acados_solver_sim_car.c:655-665)
 //              the Jacobian entries of the four RK stages in LDS; A2: the same lanes integrate their 2-3 sensitivity columns
@@ -11,9 +12,9 @@
 //   C  H2-H4  Gauss-Newton cost, bounds, full condensing                ad_3d_optimizer.py:146-199; acados_solver_sim_car.c:145
 //   D  H5     unconstrained trial, Mehrotra predictor-corrector on the dense 40-input QP (reference: HPIPM, :688-692)
 //   E  H6     state expansion, full step, cost, status                  acados_solver_sim_car.c:647-648,677
-// The phase bodies are the ones of the four-kernel pipeline in admpc_kernels.hip (kernels A, C, D, E), which
-// stays as the A/B reference (ADMPC_N20=split); what changes is where the data lives and that no instance waits for a kernel
-// boundary: the slowest instance of a batch starts at once instead of after everybody's linearisation and condensing.
+// The phase bodies descend from the four-kernel pipeline of rounds 1-2 (kernels A, C, D, E in admpc_kernels.hip, `make legacy` only;
+// DESIGN section 4); what changed is where the data lives and that no instance waits for a kernel boundary: the slowest instance
+// of a batch starts at once instead of after everybody's linearisation and condensing.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
@@ -144,7 +145,7 @@ __device__ __forceinline__ void stage_dq_nt(double* __restrict__ dq, const doubl
     for (int it = 0; it < IT; ++it) { int i = lane + WAVE * it; i = i < CNT ? i : CNT - 1; dq[i] = xv[it] - yv[it]; }
 }
 
-// LDS map of one instance (doubles): what the interior point needs and nothing else -- 17.7 KB, eight instances per CU (two waves per
+// LDS map of one instance (doubles): what the interior point needs and nothing else -- 18.2 KB, eight instances per CU (two waves per
 // SIMD).  The exchange buffers keep the relative layout dense40.h's col_head assumes (sb = cb + 128).  The other phases alias it:
 //   A   JT [0, 1960) Jacobian tables of the RK stages, bl [1960, 2100) defects; then GT [0, 840) (written when the tables are dead)
 //   C   reads GT, bl; dq [860, 1008), gam [1008, 1456); leaves H in [0, 820) (row store after the last read of GT)
@@ -1397,7 +1398,7 @@ int admpc_debug_f20_trace(unsigned long long* out, int n_inst)
 
 __attribute__((visibility("hidden"))) void admpc_fused20_prepare(void)
 {
-    // 25.6 KB per workgroup: below the 64 KB default, no opt-in needed; kept for symmetry with the other units
+    // 18.2 KB per workgroup: below the 64 KB default, no opt-in needed; kept for symmetry with the other units
 }
 
 // sched ints of a handle that solves up to `cap` instances per call: TWO scheduler states used alternately (zeroed at allocation; the order kernel of a
